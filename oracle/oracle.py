@@ -1,0 +1,234 @@
+"""ctypes wrapper over oracle/liboracle.so -- the CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg; the product
+package (``board-game-simulator-python_amd/simulator``) never imports this module.  Provenance and pinning of the
+rules: see ``oracle/bgs_oracle.h``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+_i8p = ctypes.POINTER(ctypes.c_int8)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (plain C + OpenMP)."""
+    src = os.path.join(_HERE, "bgs_oracle.c")
+    hdr = os.path.join(_HERE, "bgs_oracle.h")
+    stale = (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    )
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.orc_draw.restype = ctypes.c_uint32
+        _lib.orc_draw.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
+        _lib.orc_sample_index.restype = ctypes.c_uint32
+        _lib.orc_sample_index.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
+    return _lib
+
+
+def _p(a: np.ndarray, t):
+    assert a.flags.c_contiguous
+    return a.ctypes.data_as(t)
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with code {rc}")
+
+
+def philox4x32_10(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(_p(c, _u32p), _p(k, _u32p), _p(out, _u32p))
+    return out
+
+
+def draw(seed: int, game: int, ply: int) -> int:
+    return int(lib().orc_draw(seed, game, ply))
+
+
+def sample_index(seed: int, game: int, ply: int, n: int) -> int:
+    return int(lib().orc_sample_index(seed, game, ply, n))
+
+
+def reward(winner: np.ndarray) -> np.ndarray:
+    winner = np.ascontiguousarray(winner, dtype=np.int8)
+    out = np.zeros((winner.shape[0], 2), dtype=np.int8)
+    _check(lib().orc_reward(ctypes.c_int64(winner.shape[0]), _p(winner, _i8p), _p(out, _i8p)), "reward")
+    return out
+
+
+class _Batch:
+    """Reference-layout batch: grid int8[n,h,w], player int8[n], winner int8[n], plies int32[n]."""
+
+    def __init__(self, n: int, h: int, w: int):
+        self.n, self.h, self.w = int(n), int(h), int(w)
+        self.grid = np.zeros((self.n, self.h, self.w), dtype=np.int8)
+        self.player = np.zeros(self.n, dtype=np.int8)
+        self.winner = np.zeros(self.n, dtype=np.int8)
+        self.plies = np.zeros(self.n, dtype=np.int32)
+
+    @property
+    def ended(self) -> np.ndarray:
+        return self.winner != -1
+
+    @property
+    def reward(self) -> np.ndarray:
+        return reward(self.winner)
+
+    def _state_args(self):
+        return (_p(self.grid, _i8p), _p(self.player, _i8p), _p(self.winner, _i8p), _p(self.plies, _i32p))
+
+
+class ConnectOracle(_Batch):
+    def __init__(self, height: int, width: int, count: int, n: int):
+        super().__init__(n, height, width)
+        self.k = int(count)
+        self.reset()
+
+    def reset(self) -> None:
+        _check(lib().orc_connect_reset(self.h, self.w, ctypes.c_int64(self.n), *self._state_args()), "connect_reset")
+
+    def legal(self) -> np.ndarray:
+        out = np.zeros((self.n, self.w), dtype=np.uint8)
+        _check(
+            lib().orc_connect_legal(self.h, self.w, ctypes.c_int64(self.n), _p(self.grid, _i8p), _p(self.winner, _i8p), _p(out, _u8p)),
+            "connect_legal",
+        )
+        return out
+
+    def step_actions(self, column: np.ndarray) -> np.ndarray:
+        column = np.ascontiguousarray(column, dtype=np.int32)
+        status = np.zeros(self.n, dtype=np.int32)
+        _check(
+            lib().orc_connect_step_actions(
+                self.h, self.w, self.k, ctypes.c_int64(self.n), *self._state_args(), _p(column, _i32p), _p(status, _i32p)
+            ),
+            "connect_step_actions",
+        )
+        return status
+
+    def step_random(self, seed: int, first_game: int = 0) -> int:
+        steps = ctypes.c_uint64(0)
+        _check(
+            lib().orc_connect_step_random(
+                self.h, self.w, self.k, ctypes.c_int64(self.n), *self._state_args(), ctypes.c_uint64(seed),
+                ctypes.c_uint64(first_game), ctypes.byref(steps),
+            ),
+            "connect_step_random",
+        )
+        return steps.value
+
+    def rollout(self, seed: int, first_game: int = 0, max_plies: int = 2**31 - 1) -> int:
+        steps = ctypes.c_uint64(0)
+        _check(
+            lib().orc_connect_rollout(
+                self.h, self.w, self.k, ctypes.c_int64(self.n), *self._state_args(), ctypes.c_uint64(seed),
+                ctypes.c_uint64(first_game), ctypes.c_int32(max_plies), ctypes.byref(steps),
+            ),
+            "connect_rollout",
+        )
+        return steps.value
+
+
+class BounceOracle(_Batch):
+    def __init__(self, cfg_grid: np.ndarray, n: int):
+        cfg = np.ascontiguousarray(cfg_grid, dtype=np.int8)
+        assert cfg.ndim == 2
+        super().__init__(n, cfg.shape[0], cfg.shape[1])
+        self.cfg = cfg
+        _check(lib().orc_bounce_validate(self.h, self.w, _p(cfg, _i8p)), "bounce_validate")
+        self.reset()
+
+    def reset(self) -> None:
+        _check(
+            lib().orc_bounce_reset(self.h, self.w, _p(self.cfg, _i8p), ctypes.c_int64(self.n), *self._state_args()),
+            "bounce_reset",
+        )
+
+    def targets(self, i: int, sx: int, sy: int) -> set:
+        out = np.zeros(self.h * self.w, dtype=np.uint8)
+        g = np.ascontiguousarray(self.grid[i])
+        _check(
+            lib().orc_bounce_targets(self.h, self.w, _p(g, _i8p), int(self.player[i]), int(self.winner[i]), sx, sy, _p(out, _u8p)),
+            "bounce_targets",
+        )
+        return {(int(c % self.w), int(c // self.w)) for c in np.flatnonzero(out)}
+
+    def actions(self, i: int):
+        g = np.ascontiguousarray(self.grid[i])
+        n = lib().orc_bounce_actions(self.h, self.w, _p(g, _i8p), int(self.player[i]), int(self.winner[i]), 0, None, None)
+        src = np.zeros((max(n, 1), 2), dtype=np.int32)
+        dst = np.zeros((max(n, 1), 2), dtype=np.int32)
+        lib().orc_bounce_actions(self.h, self.w, _p(g, _i8p), int(self.player[i]), int(self.winner[i]), n, _p(src, _i32p), _p(dst, _i32p))
+        return [((int(src[j, 0]), int(src[j, 1])), (int(dst[j, 0]), int(dst[j, 1]))) for j in range(n)]
+
+    def count_actions(self) -> np.ndarray:
+        out = np.zeros(self.n, dtype=np.int32)
+        _check(
+            lib().orc_bounce_count_actions(
+                self.h, self.w, ctypes.c_int64(self.n), _p(self.grid, _i8p), _p(self.player, _i8p), _p(self.winner, _i8p), _p(out, _i32p)
+            ),
+            "bounce_count_actions",
+        )
+        return out
+
+    def step_actions(self, move: np.ndarray) -> np.ndarray:
+        move = np.ascontiguousarray(move, dtype=np.int32).reshape(self.n, 4)
+        status = np.zeros(self.n, dtype=np.int32)
+        _check(
+            lib().orc_bounce_step_actions(
+                self.h, self.w, ctypes.c_int64(self.n), *self._state_args(), _p(move, _i32p), _p(status, _i32p)
+            ),
+            "bounce_step_actions",
+        )
+        return status
+
+    def step_random(self, seed: int, first_game: int = 0) -> int:
+        steps = ctypes.c_uint64(0)
+        _check(
+            lib().orc_bounce_step_random(
+                self.h, self.w, ctypes.c_int64(self.n), *self._state_args(), ctypes.c_uint64(seed),
+                ctypes.c_uint64(first_game), ctypes.byref(steps),
+            ),
+            "bounce_step_random",
+        )
+        return steps.value
+
+    def rollout(self, seed: int, first_game: int = 0, max_plies: int = 2**31 - 1) -> int:
+        steps = ctypes.c_uint64(0)
+        _check(
+            lib().orc_bounce_rollout(
+                self.h, self.w, ctypes.c_int64(self.n), *self._state_args(), ctypes.c_uint64(seed),
+                ctypes.c_uint64(first_game), ctypes.c_int32(max_plies), ctypes.byref(steps),
+            ),
+            "bounce_rollout",
+        )
+        return steps.value

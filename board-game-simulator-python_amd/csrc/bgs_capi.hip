@@ -1,0 +1,568 @@
+// bgs_capi.hip -- the C ABI of libbgs.so (include/bgs.h): batch lifetime, arena carving, host<->device staging and
+// kernel launches.  No game arithmetic happens on the host: every rule is evaluated by the HIP kernels in
+// connect_kernels.hip / bounce_kernels.hip.  There is NO CPU fallback; without a GPU every compute entry point fails
+// with BGS_ERR_NO_DEVICE.
+#include "../../include/bgs.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "bgs_common.h"
+#include "bgs_internal.h"
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(BGS_ERR_RUNTIME, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define NEED(cond, ...)                               \
+    do {                                              \
+        if (!(cond)) return fail(BGS_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+struct Layout {
+    size_t planes, status, plies, reward, steps, staging, total, staging_bytes;
+};
+
+Layout layout_for(int planes, int64_t n, int h, int w) {
+    Layout l;
+    size_t off = 0;
+    l.planes = off; off += align_up((size_t)planes * n * 8);
+    l.status = off; off += align_up((size_t)n);
+    l.plies = off; off += align_up((size_t)n * 2);
+    l.reward = off; off += align_up((size_t)n * 2);
+    l.steps = off; off += kAlign;
+    size_t per_board = (size_t)h * w;
+    if (per_board < (size_t)8 * (w + 1)) per_board = (size_t)8 * (w + 1);
+    if (per_board < 16) per_board = 16;
+    l.staging_bytes = (size_t)n * (per_board + 16) + 8 * kAlign;
+    l.staging = off; off += align_up(l.staging_bytes);
+    l.total = off;
+    return l;
+}
+
+int check_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(BGS_ERR_NO_DEVICE, "no HIP device available (%s); libbgs has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(BGS_ERR_ARG, "device %d out of range (0..%d)", device, count - 1);
+    return BGS_OK;
+}
+
+int connect_geom(int h, int w, int k, ConnectGeom* cg) {
+    NEED(h >= 1 && h <= BGS_CONNECT_MAX_H, "Connect height %d outside 1..%d", h, BGS_CONNECT_MAX_H);
+    NEED(w >= 1 && w <= BGS_CONNECT_MAX_W, "Connect width %d outside 1..%d", w, BGS_CONNECT_MAX_W);
+    NEED(k >= 1, "Connect count %d must be positive", k);
+    const int bits = w * (h + 1);
+    NEED(bits <= 64 * BGS_CONNECT_MAX_WORDS, "Connect board %dx%d needs %d bits per plane (max %d)", h, w, bits,
+         64 * BGS_CONNECT_MAX_WORDS);
+    cg->h = h; cg->w = w; cg->k = k; cg->nw = (bits + 63) / 64;
+    return BGS_OK;
+}
+
+int bounce_geom(const int8_t* cfg, int h, int w, BounceGeom* bg) {
+    NEED(cfg != nullptr, "Bounce config grid is NULL");
+    NEED(h >= 3 && w >= 1 && h * w <= BGS_BOUNCE_MAX_CELLS, "Bounce board %dx%d unsupported (need height >= 3, cells <= %d)",
+         h, w, BGS_BOUNCE_MAX_CELLS);
+    memset(bg, 0, sizeof(*bg));
+    bg->h = h; bg->w = w;
+    bg->inv_w = (65536u + (uint32_t)w - 1u) / (uint32_t)w;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int c = y * w + x;
+            const uint64_t bit = 1ull << c;
+            const int v = cfg[c];
+            NEED(v >= 0 && v <= BGS_BOUNCE_MAX_VALUE, "Bounce piece value %d at (%d,%d) outside 0..%d", v, x, y,
+                 BGS_BOUNCE_MAX_VALUE);
+            NEED(!(v > 0 && (y == 0 || y == h - 1)), "Bounce goal rows must be empty (piece at (%d,%d))", x, y);
+            bg->all |= bit;
+            if (y == 0) bg->goal_bottom |= bit;
+            else if (y == h - 1) bg->goal_top |= bit;
+            else bg->interior |= bit;
+            if (x > 0) bg->not_col0 |= bit;
+            if (x < w - 1) bg->not_collast |= bit;
+            for (int p = 0; p < 4; ++p)
+                if ((v >> p) & 1) bg->init[p] |= bit;
+        }
+    return BGS_OK;
+}
+
+int carve(bgs_batch* b, void* arena, size_t arena_bytes, const Layout& l) {
+    if (arena) {
+        NEED(((uintptr_t)arena % kAlign) == 0, "arena must be %zu-byte aligned", kAlign);
+        NEED(arena_bytes >= l.total, "arena too small: %zu < %zu bytes", arena_bytes, l.total);
+        b->arena = arena;
+        b->owns_arena = false;
+    } else {
+        HIP_TRY(hipMalloc(&b->arena, l.total));
+        b->owns_arena = true;
+    }
+    b->arena_bytes = l.total;
+    uint8_t* base = static_cast<uint8_t*>(b->arena);
+    b->d_planes = reinterpret_cast<uint64_t*>(base + l.planes);
+    b->d_status = base + l.status;
+    b->d_plies = reinterpret_cast<uint16_t*>(base + l.plies);
+    b->d_reward = reinterpret_cast<int8_t*>(base + l.reward);
+    b->d_steps = reinterpret_cast<unsigned long long*>(base + l.steps);
+    b->d_staging = base + l.staging;
+    b->staging_bytes = l.staging_bytes;
+    return BGS_OK;
+}
+
+// bump allocator over the staging region (one call = one arena lifetime)
+struct Stage {
+    uint8_t* base;
+    size_t cap, off;
+    explicit Stage(const bgs_batch* b) : base(b->d_staging), cap(b->staging_bytes), off(0) {}
+    template <class T>
+    T* take(size_t count) {
+        uint8_t* p = base + off;
+        off += align_up(count * sizeof(T));
+        return off <= cap ? reinterpret_cast<T*>(p) : nullptr;
+    }
+};
+
+int enter(const bgs_batch* b) {
+    NEED(b != nullptr, "batch handle is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    return BGS_OK;
+}
+
+int finish_launch() {
+    HIP_TRY(hipGetLastError());
+    return BGS_OK;
+}
+
+template <class T>
+int to_host(const bgs_batch* b, T* host, const T* dev, size_t count) {
+    HIP_TRY(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return BGS_OK;
+}
+
+template <class T>
+int to_device(const bgs_batch* b, T* dev, const T* host, size_t count) {
+    HIP_TRY(hipMemcpyAsync(dev, host, count * sizeof(T), hipMemcpyHostToDevice, b->stream));
+    return BGS_OK;
+}
+
+int reset_impl(bgs_batch* b) {
+    HIP_TRY(hipMemsetAsync(b->d_steps, 0, sizeof(unsigned long long), b->stream));
+    if (b->game == BGS_GAME_CONNECT) bgs::connect_reset(b);
+    else bgs::bounce_reset(b);
+    return finish_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int bgs_version(void) { return 100; }
+
+const char* bgs_last_error(void) { return g_error; }
+
+int bgs_device_count(int* count) {
+    NEED(count != nullptr, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *count = (e == hipSuccess) ? c : 0;
+    return BGS_OK;
+}
+
+int bgs_connect_arena_bytes(int height, int width, int count, int64_t n, size_t* bytes) {
+    ConnectGeom cg;
+    int rc = connect_geom(height, width, count, &cg);
+    if (rc) return rc;
+    NEED(n >= 1 && bytes, "n must be >= 1 and bytes non-NULL");
+    *bytes = layout_for(2 * cg.nw, n, height, width).total;
+    return BGS_OK;
+}
+
+int bgs_bounce_arena_bytes(int height, int width, int64_t n, size_t* bytes) {
+    NEED(height >= 3 && width >= 1 && height * width <= BGS_BOUNCE_MAX_CELLS, "Bounce board %dx%d unsupported", height, width);
+    NEED(n >= 1 && bytes, "n must be >= 1 and bytes non-NULL");
+    *bytes = layout_for(4, n, height, width).total;
+    return BGS_OK;
+}
+
+int bgs_connect_create(int height, int width, int count, int64_t n, int device, void* arena, size_t arena_bytes,
+                       bgs_batch** out) {
+    NEED(out != nullptr, "out is NULL");
+    *out = nullptr;
+    ConnectGeom cg;
+    int rc = connect_geom(height, width, count, &cg);
+    if (rc) return rc;
+    NEED(n >= 1, "batch size must be >= 1");
+    rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    bgs_batch* b = new (std::nothrow) bgs_batch();
+    NEED(b != nullptr, "out of host memory");
+    memset(b, 0, sizeof(*b));
+    b->game = BGS_GAME_CONNECT;
+    b->device = device;
+    b->n = n;
+    b->cg = cg;
+    b->planes = 2 * cg.nw;
+    rc = carve(b, arena, arena_bytes, layout_for(b->planes, n, height, width));
+    if (rc == BGS_OK) rc = reset_impl(b);
+    if (rc != BGS_OK) {
+        if (b->owns_arena && b->arena) (void)hipFree(b->arena);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return BGS_OK;
+}
+
+int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, int device, void* arena,
+                      size_t arena_bytes, bgs_batch** out) {
+    NEED(out != nullptr, "out is NULL");
+    *out = nullptr;
+    BounceGeom bg;
+    int rc = bounce_geom(cfg_grid, height, width, &bg);
+    if (rc) return rc;
+    NEED(n >= 1, "batch size must be >= 1");
+    rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    bgs_batch* b = new (std::nothrow) bgs_batch();
+    NEED(b != nullptr, "out of host memory");
+    memset(b, 0, sizeof(*b));
+    b->game = BGS_GAME_BOUNCE;
+    b->device = device;
+    b->n = n;
+    b->bg = bg;
+    b->planes = 4;
+    rc = carve(b, arena, arena_bytes, layout_for(4, n, height, width));
+    if (rc == BGS_OK) {
+        // a start position whose first player cannot move is already over: let the device settle board 0 once
+        // and remember the verdict (the kernels own every rule; the host evaluates none)
+        rc = [&]() -> int {
+            Stage st(b);
+            int8_t* d_grid = st.take<int8_t>((size_t)height * width);
+            bgs_batch one = *b;
+            one.n = 1;
+            HIP_TRY(hipMemcpyAsync(d_grid, cfg_grid, (size_t)height * width, hipMemcpyHostToDevice, b->stream));
+            bgs::bounce_pack(&one, d_grid, nullptr, nullptr, nullptr, nullptr);
+            HIP_TRY(hipGetLastError());
+            uint8_t status0 = 0;
+            HIP_TRY(hipMemcpyAsync(&status0, b->d_status, 1, hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            b->bg.init_status = status0;
+            return BGS_OK;
+        }();
+    }
+    if (rc == BGS_OK) rc = reset_impl(b);
+    if (rc != BGS_OK) {
+        if (b->owns_arena && b->arena) (void)hipFree(b->arena);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return BGS_OK;
+}
+
+int bgs_destroy(bgs_batch* b) {
+    if (!b) return BGS_OK;
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    if (b->owns_arena && b->arena) (void)hipFree(b->arena);
+    delete b;
+    return BGS_OK;
+}
+
+int bgs_set_stream(bgs_batch* b, void* hip_stream) {
+    NEED(b != nullptr, "batch handle is NULL");
+    b->stream = static_cast<hipStream_t>(hip_stream);
+    return BGS_OK;
+}
+
+int bgs_set_first_game(bgs_batch* b, uint64_t first_game) {
+    NEED(b != nullptr, "batch handle is NULL");
+    b->first_game = first_game;
+    return BGS_OK;
+}
+
+int bgs_synchronize(bgs_batch* b) {
+    int rc = enter(b);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return BGS_OK;
+}
+
+int bgs_info(const bgs_batch* b, int* game, int* height, int* width, int* count, int64_t* n, int* planes) {
+    NEED(b != nullptr, "batch handle is NULL");
+    const bool connect = b->game == BGS_GAME_CONNECT;
+    if (game) *game = b->game;
+    if (height) *height = connect ? b->cg.h : b->bg.h;
+    if (width) *width = connect ? b->cg.w : b->bg.w;
+    if (count) *count = connect ? b->cg.k : 0;
+    if (n) *n = b->n;
+    if (planes) *planes = b->planes;
+    return BGS_OK;
+}
+
+int bgs_buffer(const bgs_batch* b, int buffer_id, void** device_ptr, size_t* bytes) {
+    NEED(b != nullptr && device_ptr != nullptr, "NULL argument");
+    size_t sz = 0;
+    void* p = nullptr;
+    switch (buffer_id) {
+        case BGS_BUF_PLANES: p = b->d_planes; sz = (size_t)b->planes * b->n * 8; break;
+        case BGS_BUF_STATUS: p = b->d_status; sz = (size_t)b->n; break;
+        case BGS_BUF_PLIES: p = b->d_plies; sz = (size_t)b->n * 2; break;
+        case BGS_BUF_REWARD: p = b->d_reward; sz = (size_t)b->n * 2; break;
+        case BGS_BUF_STEPS: p = b->d_steps; sz = 8; break;
+        case BGS_BUF_STAGING: p = b->d_staging; sz = b->staging_bytes; break;
+        default: return fail(BGS_ERR_ARG, "unknown buffer id %d", buffer_id);
+    }
+    *device_ptr = p;
+    if (bytes) *bytes = sz;
+    return BGS_OK;
+}
+
+int bgs_reset(bgs_batch* b) {
+    int rc = enter(b);
+    if (rc) return rc;
+    return reset_impl(b);
+}
+
+int bgs_step_random(bgs_batch* b, uint64_t seed) {
+    int rc = enter(b);
+    if (rc) return rc;
+    if (b->game == BGS_GAME_CONNECT) bgs::connect_step_random(b, seed);
+    else bgs::bounce_step_random(b, seed);
+    return finish_launch();
+}
+
+int bgs_step_actions(bgs_batch* b, const int32_t* actions, int actions_on_device, int32_t* status) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(actions != nullptr, "actions is NULL");
+    const size_t per = b->game == BGS_GAME_CONNECT ? 1 : 4;
+    Stage st(b);
+    int32_t* d_result = status ? st.take<int32_t>((size_t)b->n) : nullptr;
+    const int32_t* d_actions = actions;
+    if (!actions_on_device) {
+        int32_t* tmp = st.take<int32_t>((size_t)b->n * per);
+        NEED(tmp != nullptr, "staging buffer too small");
+        rc = to_device(b, tmp, actions, (size_t)b->n * per);
+        if (rc) return rc;
+        d_actions = tmp;
+    }
+    if (b->game == BGS_GAME_CONNECT) bgs::connect_step_actions(b, d_actions, d_result);
+    else bgs::bounce_step_actions(b, d_actions, d_result);
+    rc = finish_launch();
+    if (rc) return rc;
+    if (status) return to_host(b, status, d_result, (size_t)b->n);
+    if (!actions_on_device) HIP_TRY(hipStreamSynchronize(b->stream));  // the host buffer may be reused by the caller
+    return BGS_OK;
+}
+
+int bgs_rollout(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(max_plies >= 0, "max_plies must be >= 0");
+    if (b->game == BGS_GAME_CONNECT) bgs::connect_rollout(b, seed, max_plies, flags);
+    else bgs::bounce_rollout(b, seed, max_plies, flags);
+    return finish_launch();
+}
+
+int bgs_steps(bgs_batch* b, uint64_t* steps) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(steps != nullptr, "steps is NULL");
+    unsigned long long v = 0;
+    rc = to_host(b, &v, b->d_steps, 1);
+    *steps = v;
+    return rc;
+}
+
+int bgs_reset_steps(bgs_batch* b) {
+    int rc = enter(b);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(b->d_steps, 0, sizeof(unsigned long long), b->stream));
+    return BGS_OK;
+}
+
+int bgs_read_grid(bgs_batch* b, int8_t* grid) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(grid != nullptr, "grid is NULL");
+    const bool connect = b->game == BGS_GAME_CONNECT;
+    const size_t cells = (size_t)b->n * (connect ? b->cg.h * b->cg.w : b->bg.h * b->bg.w);
+    Stage st(b);
+    int8_t* d = st.take<int8_t>(cells);
+    if (connect) bgs::connect_unpack_grid(b, d);
+    else bgs::bounce_unpack_grid(b, d);
+    rc = finish_launch();
+    if (rc) return rc;
+    return to_host(b, grid, d, cells);
+}
+
+static int read_meta(bgs_batch* b, int8_t* player, uint8_t* ended, int8_t* winner, int32_t* plies) {
+    int rc = enter(b);
+    if (rc) return rc;
+    Stage st(b);
+    int8_t* dp = player ? st.take<int8_t>((size_t)b->n) : nullptr;
+    uint8_t* de = ended ? st.take<uint8_t>((size_t)b->n) : nullptr;
+    int8_t* dw = winner ? st.take<int8_t>((size_t)b->n) : nullptr;
+    int32_t* dl = plies ? st.take<int32_t>((size_t)b->n) : nullptr;
+    if (b->game == BGS_GAME_CONNECT) bgs::connect_meta(b, dp, de, dw, dl);
+    else bgs::bounce_meta(b, dp, de, dw, dl);
+    rc = finish_launch();
+    if (rc) return rc;
+    if (player) HIP_TRY(hipMemcpyAsync(player, dp, (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    if (ended) HIP_TRY(hipMemcpyAsync(ended, de, (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    if (winner) HIP_TRY(hipMemcpyAsync(winner, dw, (size_t)b->n, hipMemcpyDeviceToHost, b->stream));
+    if (plies) HIP_TRY(hipMemcpyAsync(plies, dl, (size_t)b->n * 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return BGS_OK;
+}
+
+int bgs_read_player(bgs_batch* b, int8_t* player) {
+    NEED(player != nullptr, "player is NULL");
+    return read_meta(b, player, nullptr, nullptr, nullptr);
+}
+
+int bgs_read_ended(bgs_batch* b, uint8_t* ended) {
+    NEED(ended != nullptr, "ended is NULL");
+    return read_meta(b, nullptr, ended, nullptr, nullptr);
+}
+
+int bgs_read_winner(bgs_batch* b, int8_t* winner) {
+    NEED(winner != nullptr, "winner is NULL");
+    return read_meta(b, nullptr, nullptr, winner, nullptr);
+}
+
+int bgs_read_plies(bgs_batch* b, int32_t* plies) {
+    NEED(plies != nullptr, "plies is NULL");
+    return read_meta(b, nullptr, nullptr, nullptr, plies);
+}
+
+int bgs_read_reward(bgs_batch* b, int8_t* reward) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(reward != nullptr, "reward is NULL");
+    return to_host(b, reward, b->d_reward, (size_t)b->n * 2);
+}
+
+int bgs_read_legal(bgs_batch* b, uint8_t* legal) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(legal != nullptr, "legal is NULL");
+    NEED(b->game == BGS_GAME_CONNECT, "bgs_read_legal is a Connect entry point; use bgs_bounce_read_targets");
+    Stage st(b);
+    uint8_t* d = st.take<uint8_t>((size_t)b->n * b->cg.w);
+    bgs::connect_legal(b, d, nullptr);
+    rc = finish_launch();
+    if (rc) return rc;
+    return to_host(b, legal, d, (size_t)b->n * b->cg.w);
+}
+
+int bgs_read_action_count(bgs_batch* b, int32_t* count) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(count != nullptr, "count is NULL");
+    Stage st(b);
+    int32_t* d = st.take<int32_t>((size_t)b->n);
+    if (b->game == BGS_GAME_CONNECT) bgs::connect_legal(b, nullptr, d);
+    else bgs::bounce_targets(b, nullptr, d);
+    rc = finish_launch();
+    if (rc) return rc;
+    return to_host(b, count, d, (size_t)b->n);
+}
+
+int bgs_bounce_read_targets(bgs_batch* b, uint64_t* targets) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(targets != nullptr, "targets is NULL");
+    NEED(b->game == BGS_GAME_BOUNCE, "bgs_bounce_read_targets needs a Bounce batch");
+    Stage st(b);
+    uint64_t* d = st.take<uint64_t>((size_t)b->n * (b->bg.w + 1));
+    NEED(d != nullptr, "staging buffer too small");
+    bgs::bounce_targets(b, d, nullptr);
+    rc = finish_launch();
+    if (rc) return rc;
+    return to_host(b, targets, d, (size_t)b->n * (b->bg.w + 1));
+}
+
+int bgs_export_device(bgs_batch* b, int what, void* device_dst) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(device_dst != nullptr, "destination is NULL");
+    switch (what) {
+        case 'g':
+            if (b->game == BGS_GAME_CONNECT) bgs::connect_unpack_grid(b, static_cast<int8_t*>(device_dst));
+            else bgs::bounce_unpack_grid(b, static_cast<int8_t*>(device_dst));
+            break;
+        case 'l':
+            NEED(b->game == BGS_GAME_CONNECT, "'l' (legal mask) is Connect only");
+            bgs::connect_legal(b, static_cast<uint8_t*>(device_dst), nullptr);
+            break;
+        case 'c':
+            if (b->game == BGS_GAME_CONNECT) bgs::connect_legal(b, nullptr, static_cast<int32_t*>(device_dst));
+            else bgs::bounce_targets(b, nullptr, static_cast<int32_t*>(device_dst));
+            break;
+        case 't':
+            NEED(b->game == BGS_GAME_BOUNCE, "'t' (target masks) is Bounce only");
+            bgs::bounce_targets(b, static_cast<uint64_t*>(device_dst), nullptr);
+            break;
+        case 'r':
+            HIP_TRY(hipMemcpyAsync(device_dst, b->d_reward, (size_t)b->n * 2, hipMemcpyDeviceToDevice, b->stream));
+            break;
+        default:
+            return fail(BGS_ERR_ARG, "unknown export kind '%c'", what);
+    }
+    return finish_launch();
+}
+
+int bgs_write_state(bgs_batch* b, const int8_t* grid, const int8_t* player, const int8_t* winner, const int32_t* plies,
+                    int32_t* status) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(grid != nullptr, "grid is NULL");
+    const bool connect = b->game == BGS_GAME_CONNECT;
+    const size_t cells = (size_t)b->n * (connect ? b->cg.h * b->cg.w : b->bg.h * b->bg.w);
+    Stage st(b);
+    int8_t* dg = st.take<int8_t>(cells);
+    int8_t* dp = player ? st.take<int8_t>((size_t)b->n) : nullptr;
+    int8_t* dw = winner ? st.take<int8_t>((size_t)b->n) : nullptr;
+    int32_t* dl = (plies && !connect) ? st.take<int32_t>((size_t)b->n) : nullptr;
+    int32_t* dr = st.take<int32_t>((size_t)b->n);
+    NEED(dr != nullptr, "staging buffer too small");
+    if ((rc = to_device(b, dg, grid, cells))) return rc;
+    if (player && (rc = to_device(b, dp, player, (size_t)b->n))) return rc;
+    if (winner && (rc = to_device(b, dw, winner, (size_t)b->n))) return rc;
+    if (dl && (rc = to_device(b, dl, plies, (size_t)b->n))) return rc;
+    if (connect) bgs::connect_pack(b, dg, dp, dw, dr);
+    else bgs::bounce_pack(b, dg, dp, dw, dl, dr);
+    rc = finish_launch();
+    if (rc) return rc;
+    if (status) return to_host(b, status, dr, (size_t)b->n);
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return BGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// bgs_common.h -- shared device/host definitions for libbgs (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BGS_WAVE 64
+#define BGS_BLOCK 256
+
+// status byte of a board: 0 running, 1 player 0 won, 2 player 1 won, 3 draw
+#define BGS_ST_RUNNING 0u
+#define BGS_ST_DRAW 3u
+
+namespace bgs {
+
+// ------------------------------------------------------------------------------------------------
+// RNG contract: philox4x32-10, key = seed, counter = (game lo, game hi, ply >> 2, 0); the draw of a ply is
+// output word (ply & 3).  One block serves four consecutive plies of a game.
+// ------------------------------------------------------------------------------------------------
+struct Philox4 {
+    uint32_t v[4];
+};
+
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t game, uint32_t block) {
+    uint32_t c0 = (uint32_t)game, c1 = (uint32_t)(game >> 32), c2 = block, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    Philox4 out;
+    out.v[0] = c0; out.v[1] = c1; out.v[2] = c2; out.v[3] = c3;
+    return out;
+}
+
+__host__ __device__ __forceinline__ uint32_t philox_word(const Philox4& p, uint32_t ply) {
+    const uint32_t j = ply & 3u;
+    const uint32_t lo = (j & 1u) ? p.v[1] : p.v[0];
+    const uint32_t hi = (j & 1u) ? p.v[3] : p.v[2];
+    return (j & 2u) ? hi : lo;
+}
+
+__host__ __device__ __forceinline__ uint32_t sample_index(uint32_t draw, uint32_t n_actions) {
+    return (uint32_t)(((uint64_t)draw * n_actions) >> 32);
+}
+
+// reward pair packed as two int8 in one uint16 (little endian: byte 0 = player 0)
+__host__ __device__ __forceinline__ uint16_t reward_pair(uint32_t status) {
+    return status == 1u ? (uint16_t)0xFF01u : status == 2u ? (uint16_t)0x01FFu : (uint16_t)0u;
+}
+
+// add this lane's step count into the batch counter: one atomic per wave
+__device__ __forceinline__ void add_steps(unsigned long long* counter, uint32_t mine) {
+    uint32_t total = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, BGS_WAVE);
+    if ((threadIdx.x & (BGS_WAVE - 1)) == 0 && total) atomicAdd(counter, (unsigned long long)total);
+}
+
+}  // namespace bgs

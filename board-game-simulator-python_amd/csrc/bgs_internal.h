@@ -1,0 +1,82 @@
+// bgs_internal.h -- host-side batch object and kernel launcher prototypes (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+enum { BGS_GAME_CONNECT = 1, BGS_GAME_BOUNCE = 2 };
+
+// limits of the packed representations
+enum {
+    BGS_CONNECT_MAX_WORDS = 3,   // width * (height + 1) <= 192 bits per plane
+    BGS_CONNECT_MAX_H = 15,      // column heights are kept 4 bits per column
+    BGS_CONNECT_MAX_W = 16,
+    BGS_BOUNCE_MAX_CELLS = 64,   // height * width <= 64: one bit per cell in a uint64
+    BGS_BOUNCE_MAX_VALUE = 15    // 4 value bit-planes
+};
+
+struct ConnectGeom {
+    int h, w, k, nw;   // nw = 64-bit words per plane
+};
+
+struct BounceGeom {
+    int h, w;
+    uint32_t inv_w;          // ceil(2^16 / w): y = (cell * inv_w) >> 16 for cell < 64
+    uint64_t all;            // every cell
+    uint64_t interior;       // rows 1 .. h-2
+    uint64_t goal_top;       // row h-1 (player 0's goal)
+    uint64_t goal_bottom;    // row 0   (player 1's goal)
+    uint64_t not_col0;       // cells with x > 0
+    uint64_t not_collast;    // cells with x < w-1
+    uint64_t init[4];        // value bit-planes of the configured start position
+    uint32_t init_status;    // 0, or the terminal code of a start position without legal moves
+};
+
+struct bgs_batch {
+    int game;
+    int device;
+    int64_t n;
+    hipStream_t stream;
+    uint64_t first_game;
+    ConnectGeom cg;
+    BounceGeom bg;
+    int planes;              // uint64 planes per board
+    // device buffers (inside the arena)
+    void* arena;
+    size_t arena_bytes;
+    bool owns_arena;
+    uint64_t* d_planes;      // [planes][n]
+    uint8_t* d_status;       // [n]
+    uint16_t* d_plies;       // [n] (Bounce)
+    int8_t* d_reward;        // [n][2]
+    unsigned long long* d_steps;
+    uint8_t* d_staging;
+    size_t staging_bytes;
+};
+
+namespace bgs {
+
+// ---- Connect (connect_kernels.hip) ----
+void connect_reset(const bgs_batch* b);
+void connect_step_random(const bgs_batch* b, uint64_t seed);
+void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out);
+void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags);
+void connect_unpack_grid(const bgs_batch* b, int8_t* d_grid);
+void connect_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies);
+void connect_legal(const bgs_batch* b, uint8_t* d_legal, int32_t* d_count);
+void connect_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_player, const int8_t* d_winner,
+                  int32_t* d_status_out);
+
+// ---- Bounce (bounce_kernels.hip) ----
+void bounce_reset(const bgs_batch* b);
+void bounce_step_random(const bgs_batch* b, uint64_t seed);
+void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out);
+void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags);
+void bounce_unpack_grid(const bgs_batch* b, int8_t* d_grid);
+void bounce_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies);
+void bounce_targets(const bgs_batch* b, uint64_t* d_targets, int32_t* d_count);
+void bounce_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_player, const int8_t* d_winner,
+                 const int32_t* d_plies, int32_t* d_status_out);
+
+}  // namespace bgs

@@ -1,0 +1,418 @@
+// bounce_kernels.hip -- "Bounce" hot path on gfx950: active row -> reachable targets of every movable piece ->
+// uniform (source, target) sample -> move -> goal / blocked / draw -> reward.
+//
+// Replaces, N boards per launch, what the reference reaches through
+//   State::get_actions / get_actions_at / get_action_at  (src/simulator/game/bounce.cpp:40-42)
+//   Action::sample_next_state                            (bounce.cpp:51)
+//   State::has_ended / get_reward                        (bounce.cpp:36,38)
+// Rules as pinned by reference tests/test_bounce.py:92-362 (plain restatement in
+// oracle/bgs_oracle.c).
+//
+// Board packing.  height * width <= 64 cells, cell index c = y * width + x (y = 0 bottom row).  Piece values
+// (1..15) are bit-sliced into four uint64 planes: plane j holds bit j of every cell's value; occupancy is the OR
+// of the planes.  32 bytes per board, planes stored SoA over the batch.
+//
+// The move search is bit-parallel instead of a per-cell recursion: a segment of v steps is v rounds of three
+// frontier masks (arrived by a forward / left / right step); a forward step shifts by +-width, a sideways step by
+// +-1 under an edge mask, "no immediate left<->right reversal" is the rule that a left frontier only feeds forward
+// and left.  Landing on a piece queues that cell; every queued cell is expanded once (its continuation does not
+// depend on how it was reached), which is the closure the recursive search computes.
+#include "bgs_common.h"
+#include "bgs_internal.h"
+
+namespace bgs {
+namespace {
+
+struct Board {
+    uint64_t v[4];
+};
+
+__device__ __forceinline__ uint64_t occupancy(const Board& b) { return b.v[0] | b.v[1] | b.v[2] | b.v[3]; }
+
+__device__ __forceinline__ uint32_t value_at(const Board& b, int c) {
+    return (uint32_t)((b.v[0] >> c) & 1ull) | ((uint32_t)((b.v[1] >> c) & 1ull) << 1) |
+           ((uint32_t)((b.v[2] >> c) & 1ull) << 2) | ((uint32_t)((b.v[3] >> c) & 1ull) << 3);
+}
+
+// every legal landing cell of the piece on cell `src` for `player` (SURVEY Appendix B rules 4-5)
+__device__ __forceinline__ uint64_t reach(const BounceGeom& g, const Board& b, uint64_t occ, uint32_t player, int src) {
+    const uint64_t empty_interior = ~occ & g.interior;
+    const uint64_t landing = empty_interior | (player ? g.goal_bottom : g.goal_top);
+    uint64_t pending = 1ull << src, done = 0, targets = 0;
+    while (pending) {
+        const int c = __ffsll((unsigned long long)pending) - 1;
+        pending &= pending - 1;
+        done |= 1ull << c;
+        const uint32_t v = value_at(b, c);
+        uint64_t a0 = 1ull << c, al = 0, ar = 0, land = 0;
+        for (uint32_t s = 1; s <= v; ++s) {
+            const uint64_t from_any = a0 | al | ar;
+            const uint64_t nf = (player ? (from_any >> g.w) : (from_any << g.w)) & g.all;
+            const uint64_t nl = ((a0 | al) & g.not_col0) >> 1;
+            const uint64_t nr = ((a0 | ar) & g.not_collast) << 1;
+            if (s < v) {
+                a0 = nf & empty_interior;
+                al = nl & empty_interior;
+                ar = nr & empty_interior;
+                if (!(a0 | al | ar)) break;
+            } else {
+                land = nf | nl | nr;
+            }
+        }
+        targets |= land & landing;
+        pending |= land & occ & g.interior & ~done;
+    }
+    return targets;
+}
+
+// pieces the side to move may pick: those in the occupied non-goal row nearest its own side (Appendix B rule 3)
+__device__ __forceinline__ uint64_t movable(const BounceGeom& g, uint64_t occ, uint32_t player) {
+    const uint64_t oi = occ & g.interior;
+    if (!oi) return 0;
+    const int cell = player ? 63 - __clzll((long long)oi) : __ffsll((unsigned long long)oi) - 1;
+    const int row = (int)(((uint32_t)cell * g.inv_w) >> 16);
+    return oi & (((1ull << g.w) - 1ull) << (row * g.w));
+}
+
+__device__ __forceinline__ uint32_t count_actions(const BounceGeom& g, const Board& b, uint64_t occ, uint32_t player) {
+    uint64_t src = movable(g, occ, player);
+    uint32_t n = 0;
+    while (src) {
+        const int s = __ffsll((unsigned long long)src) - 1;
+        src &= src - 1;
+        n += (uint32_t)__popcll(reach(g, b, occ, player, s));
+    }
+    return n;
+}
+
+// the idx-th action of the canonical list: sources by ascending x, targets by ascending (y, x)
+__device__ __forceinline__ void pick_action(const BounceGeom& g, const Board& b, uint64_t occ, uint32_t player,
+                                            uint32_t idx, int& src_cell, int& dst_cell) {
+    uint64_t src = movable(g, occ, player);
+    src_cell = -1;
+    dst_cell = -1;
+    while (src) {
+        const int s = __ffsll((unsigned long long)src) - 1;
+        src &= src - 1;
+        uint64_t t = reach(g, b, occ, player, s);
+        const uint32_t cnt = (uint32_t)__popcll(t);
+        if (idx < cnt) {
+            for (uint32_t j = 0; j < idx; ++j) t &= t - 1;
+            src_cell = s;
+            dst_cell = __ffsll((unsigned long long)t) - 1;
+            return;
+        }
+        idx -= cnt;
+    }
+}
+
+__device__ __forceinline__ void move_piece(Board& b, int src_cell, int dst_cell) {
+    const uint32_t v = value_at(b, src_cell);
+    const uint64_t keep = ~(1ull << src_cell);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b.v[j] = (b.v[j] & keep) | ((uint64_t)((v >> j) & 1u) << dst_cell);
+}
+
+// terminal test after `mover` moved to dst_cell (Appendix B rule 7); n_next = action count of the next player
+__device__ __forceinline__ uint32_t settle(const BounceGeom& g, const Board& b, uint32_t mover, int dst_cell,
+                                           uint32_t& n_next) {
+    n_next = 0;
+    if ((1ull << dst_cell) & (g.goal_top | g.goal_bottom)) return mover + 1u;
+    const uint64_t occ = occupancy(b);
+    n_next = count_actions(g, b, occ, 1u - mover);
+    if (n_next) return BGS_ST_RUNNING;
+    return count_actions(g, b, occ, mover) ? mover + 1u : BGS_ST_DRAW;
+}
+
+// a board whose side to move has no action although nobody ended the game (start positions, loaded boards)
+__device__ __forceinline__ uint32_t settle_blocked(const BounceGeom& g, const Board& b, uint32_t player) {
+    return count_actions(g, b, occupancy(b), 1u - player) ? (1u - player) + 1u : BGS_ST_DRAW;
+}
+
+__device__ __forceinline__ Board load_board(const uint64_t* __restrict__ planes, int64_t n, int64_t i) {
+    Board b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b.v[j] = planes[(int64_t)j * n + i];
+    return b;
+}
+
+__device__ __forceinline__ void store_board(uint64_t* __restrict__ planes, int64_t n, int64_t i, const Board& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) planes[(int64_t)j * n + i] = b.v[j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_reset(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies,
+               uint16_t* __restrict__ reward, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) planes[(int64_t)j * n + i] = g.init[j];
+    status[i] = (uint8_t)g.init_status;
+    plies[i] = 0;
+    reward[i] = reward_pair(g.init_status);
+}
+
+// plies of one board, in registers, until it ends, reaches max_plies, or (SINGLE) one ply was played
+template <bool SINGLE>
+__device__ __forceinline__ uint32_t play(const BounceGeom& g, Board& b, uint32_t& st, uint32_t& plies, uint64_t seed,
+                                         uint64_t game, uint32_t max_plies) {
+    uint32_t stepped = 0;
+    if (st != BGS_ST_RUNNING) return 0;
+    uint32_t n_act = count_actions(g, b, occupancy(b), plies & 1u);
+    if (n_act == 0) {
+        st = settle_blocked(g, b, plies & 1u);
+        return 0;
+    }
+    Philox4 blk = philox4x32_10(seed, game, plies >> 2);
+    while (st == BGS_ST_RUNNING && plies < max_plies) {
+        const uint32_t mover = plies & 1u;
+        const uint32_t idx = sample_index(philox_word(blk, plies), n_act);
+        int s, t;
+        pick_action(g, b, occupancy(b), mover, idx, s, t);
+        move_piece(b, s, t);
+        ++plies;
+        ++stepped;
+        st = settle(g, b, mover, t, n_act);
+        if (SINGLE) break;
+        if ((plies & 3u) == 0u) blk = philox4x32_10(seed, game, plies >> 2);
+    }
+    return stepped;
+}
+
+template <bool SINGLE, bool FROM_INITIAL>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_play(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+              uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
+              unsigned long long* __restrict__ steps) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    uint32_t stepped = 0;
+    if (i < n) {
+        Board b;
+        uint32_t st, plies;
+        if (FROM_INITIAL) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b.v[j] = g.init[j];
+            st = g.init_status;
+            plies = 0;
+        } else {
+            b = load_board(planes, n, i);
+            st = status[i];
+            plies = plies_buf[i];
+        }
+        const uint32_t st_in = st;
+        stepped = play<SINGLE>(g, b, st, plies, seed, first_game + (uint64_t)i, max_plies);
+        if (FROM_INITIAL || stepped || st != st_in) {
+            store_board(planes, n, i, b);
+            status[i] = (uint8_t)st;
+            plies_buf[i] = (uint16_t)plies;
+            reward[i] = reward_pair(st);
+        }
+    }
+    add_steps(steps, stepped);
+}
+
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_step_actions(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
+                      uint16_t* __restrict__ plies_buf, uint16_t* __restrict__ reward, int64_t n,
+                      const int32_t* __restrict__ moves, int32_t* __restrict__ result,
+                      unsigned long long* __restrict__ steps) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    uint32_t stepped = 0;
+    if (i < n) {
+        const int sx = moves[4 * i], sy = moves[4 * i + 1], tx = moves[4 * i + 2], ty = moves[4 * i + 3];
+        int32_t rc = 0;
+        if (sx >= 0) {
+            rc = -2;  // BGS_ERR_ILLEGAL
+            const bool inside = sx < g.w && sy >= 0 && sy < g.h && tx >= 0 && tx < g.w && ty >= 0 && ty < g.h;
+            if (inside && status[i] == BGS_ST_RUNNING) {
+                Board b = load_board(planes, n, i);
+                uint32_t plies = plies_buf[i];
+                const uint32_t mover = plies & 1u;
+                const uint64_t occ = occupancy(b);
+                const int s = sy * g.w + sx, t = ty * g.w + tx;
+                if (((movable(g, occ, mover) >> s) & 1ull) && ((reach(g, b, occ, mover, s) >> t) & 1ull)) {
+                    move_piece(b, s, t);
+                    ++plies;
+                    uint32_t n_next;
+                    const uint32_t st = settle(g, b, mover, t, n_next);
+                    store_board(planes, n, i, b);
+                    plies_buf[i] = (uint16_t)plies;
+                    if (st != BGS_ST_RUNNING) {
+                        status[i] = (uint8_t)st;
+                        reward[i] = reward_pair(st);
+                    }
+                    stepped = 1;
+                    rc = 0;
+                }
+            }
+        }
+        if (result) result[i] = rc;
+    }
+    add_steps(steps, stepped);
+}
+
+// packed planes -> reference layout int8[n][H][W]; 4 output bytes per thread
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_unpack(BounceGeom g, const uint64_t* __restrict__ planes, int64_t n, int8_t* __restrict__ grid) {
+    const int hw = g.h * g.w;
+    const int64_t total = n * hw;
+    const int64_t f = ((int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x) * 4;
+    if (f >= total) return;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t idx = f + j;
+        uint32_t v = 0;
+        if (idx < total) {
+            const int64_t bi = idx / hw;
+            const int c = (int)(idx - bi * hw);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) v |= (uint32_t)((planes[(int64_t)p * n + bi] >> c) & 1ull) << p;
+        }
+        packed |= v << (8 * j);
+    }
+    if (f + 3 < total) {
+        *reinterpret_cast<uint32_t*>(grid + f) = packed;
+    } else {
+        for (int j = 0; j < 4 && f + j < total; ++j) grid[f + j] = (int8_t)(packed >> (8 * j));
+    }
+}
+
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_meta(const uint8_t* __restrict__ status, const uint16_t* __restrict__ plies_buf, int64_t n,
+              int8_t* __restrict__ player, uint8_t* __restrict__ ended, int8_t* __restrict__ winner,
+              int32_t* __restrict__ plies) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t st = status[i];
+    const uint32_t p = plies_buf[i];
+    if (player) player[i] = (int8_t)(p & 1u);
+    if (ended) ended[i] = st != 0;
+    if (winner) winner[i] = st == 0 ? -1 : (st == BGS_ST_DRAW ? 2 : (int8_t)(st - 1));
+    if (plies) plies[i] = (int32_t)p;
+}
+
+// targets[n][W + 1]: legal landing cells of the piece in column x of the active row, then the active row itself
+// (all ones when the board has ended or nothing can move); count[n] = number of actions
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_targets(BounceGeom g, const uint64_t* __restrict__ planes, const uint8_t* __restrict__ status,
+                 const uint16_t* __restrict__ plies_buf, int64_t n, uint64_t* __restrict__ targets,
+                 int32_t* __restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Board b = load_board(planes, n, i);
+    const uint64_t occ = occupancy(b);
+    const uint32_t player = plies_buf[i] & 1u;
+    const uint64_t src = status[i] == BGS_ST_RUNNING ? movable(g, occ, player) : 0ull;
+    const int row = src ? (int)(((uint32_t)(__ffsll((unsigned long long)src) - 1) * g.inv_w) >> 16) : 0;
+    int32_t total = 0;
+    for (int x = 0; x < g.w; ++x) {
+        const int c = row * g.w + x;
+        const uint64_t t = ((src >> c) & 1ull) ? reach(g, b, occ, player, c) : 0ull;
+        if (targets) targets[i * (g.w + 1) + x] = t;
+        total += __popcll(t);
+    }
+    if (targets) targets[i * (g.w + 1) + g.w] = src ? (uint64_t)row : ~0ull;
+    if (count) count[i] = total;
+}
+
+// reference layout -> packed planes.  Running boards must keep the goal rows empty; a running board whose side to
+// move is blocked is settled here, exactly as a transition would have settled it.
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_pack(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+              uint16_t* __restrict__ reward, int64_t n, const int8_t* __restrict__ grid, const int8_t* __restrict__ player,
+              const int8_t* __restrict__ winner, const int32_t* __restrict__ plies, int32_t* __restrict__ result) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int hw = g.h * g.w;
+    Board b;
+    b.v[0] = b.v[1] = b.v[2] = b.v[3] = 0;
+    bool ok = true;
+    for (int c = 0; c < hw; ++c) {
+        const int v = grid[i * hw + c];
+        if (v < 0 || v > BGS_BOUNCE_MAX_VALUE) ok = false;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) b.v[p] |= (uint64_t)((v >> p) & 1) << c;
+    }
+    const int wv = winner ? winner[i] : -1;
+    if (wv < -1 || wv > 2) ok = false;
+    uint32_t st = wv == -1 ? 0u : (wv == 2 ? BGS_ST_DRAW : (uint32_t)(wv + 1));
+    if (st == BGS_ST_RUNNING && (occupancy(b) & (g.goal_top | g.goal_bottom))) ok = false;
+    const int pl = player ? player[i] : 0;
+    if (pl != 0 && pl != 1) ok = false;
+    int32_t np = plies ? plies[i] : pl;
+    if (np < 0 || np > 65535 || (np & 1) != pl) ok = false;
+    if (ok) {
+        if (st == BGS_ST_RUNNING && count_actions(g, b, occupancy(b), (uint32_t)pl) == 0)
+            st = settle_blocked(g, b, (uint32_t)pl);
+        store_board(planes, n, i, b);
+        status[i] = (uint8_t)st;
+        plies_buf[i] = (uint16_t)np;
+        reward[i] = reward_pair(st);
+    }
+    if (result) result[i] = ok ? 0 : -1;
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + BGS_BLOCK - 1) / BGS_BLOCK); }
+
+}  // namespace
+
+void bounce_reset(const bgs_batch* b) {
+    hipLaunchKernelGGL(k_bounce_reset, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->d_status,
+                       b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n);
+}
+
+void bounce_step_random(const bgs_batch* b, uint64_t seed) {
+    hipLaunchKernelGGL((k_bounce_play<true, false>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
+                       b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
+                       0xFFFFFFFFu, b->d_steps);
+}
+
+void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
+    uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
+    if (cap > 65535u) cap = 65535u;  // plies are stored as uint16
+    if (flags & 1u)
+        hipLaunchKernelGGL((k_bounce_play<false, true>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg,
+                           b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
+                           b->first_game, cap, b->d_steps);
+    else
+        hipLaunchKernelGGL((k_bounce_play<false, false>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg,
+                           b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
+                           b->first_game, cap, b->d_steps);
+}
+
+void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out) {
+    hipLaunchKernelGGL(k_bounce_step_actions, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
+                       b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_moves, d_status_out,
+                       b->d_steps);
+}
+
+void bounce_unpack_grid(const bgs_batch* b, int8_t* d_grid) {
+    const int64_t quads = (b->n * b->bg.h * b->bg.w + 3) / 4;
+    hipLaunchKernelGGL(k_bounce_unpack, dim3(grid_for(quads)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->n,
+                       d_grid);
+}
+
+void bounce_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies) {
+    hipLaunchKernelGGL(k_bounce_meta, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->d_status, b->d_plies, b->n,
+                       d_player, d_ended, d_winner, d_plies);
+}
+
+void bounce_targets(const bgs_batch* b, uint64_t* d_targets, int32_t* d_count) {
+    hipLaunchKernelGGL(k_bounce_targets, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
+                       b->d_status, b->d_plies, b->n, d_targets, d_count);
+}
+
+void bounce_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_player, const int8_t* d_winner,
+                 const int32_t* d_plies, int32_t* d_status_out) {
+    hipLaunchKernelGGL(k_bounce_pack, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->d_status,
+                       b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_grid, d_player, d_winner, d_plies,
+                       d_status_out);
+}
+
+}  // namespace bgs

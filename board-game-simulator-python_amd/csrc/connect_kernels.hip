@@ -1,0 +1,578 @@
+// connect_kernels.hip -- Connect-k hot path on gfx950: enumerate -> sample -> drop -> k-in-a-row / draw -> reward.
+//
+// Replaces, N boards per launch, what the reference reaches through
+//   State::get_actions / get_action_at   (src/simulator/game/connect.cpp:43-44)
+//   Action::sample_next_state            (connect.cpp:52)
+//   State::has_ended / get_reward        (connect.cpp:39,41)
+// Rules as pinned by reference tests/test_connect.py:68-145 (see oracle/bgs_oracle.c for the plain restatement).
+//
+// Board packing.  Two bit-planes per board (stones of player 0, stones of player 1), column-major with one
+// always-empty sentinel bit on top of every column: bit(x, y) = x * (H + 1) + y.  The sentinel stops vertical and
+// diagonal shift-and-AND runs from leaking into the next column.  A plane is NW = ceil(W * (H + 1) / 64) uint64
+// words; the batch stores plane-word j of all boards contiguously (SoA: planes[j][n]) so a wave reads 512
+// contiguous bytes per word.  The side to move and the ply count are popcount parity / popcount of the planes.
+//
+// This is integer bit manipulation: no MFMA.  The per-ply kernels are HBM/L2 bound; the fused rollout keeps the
+// board in registers and is VALU-issue bound.
+#include "bgs_common.h"
+#include "bgs_internal.h"
+
+namespace bgs {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// multi-word bitboards
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+struct Bits {
+    uint64_t w[NW];
+};
+
+template <int NW>
+__device__ __forceinline__ Bits<NW> zero_bits() {
+    Bits<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = 0;
+    return r;
+}
+
+template <int NW>
+__device__ __forceinline__ Bits<NW> operator&(const Bits<NW>& a, const Bits<NW>& b) {
+    Bits<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = a.w[i] & b.w[i];
+    return r;
+}
+
+template <int NW>
+__device__ __forceinline__ Bits<NW> operator|(const Bits<NW>& a, const Bits<NW>& b) {
+    Bits<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = a.w[i] | b.w[i];
+    return r;
+}
+
+template <int NW>
+__device__ __forceinline__ bool any(const Bits<NW>& a) {
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) acc |= a.w[i];
+    return acc != 0;
+}
+
+template <int NW>
+__device__ __forceinline__ uint32_t popcount(const Bits<NW>& a) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) c += (uint32_t)__popcll(a.w[i]);
+    return c;
+}
+
+// word `idx` of a (0 beyond the top); idx may be a run-time value: resolved with selects, never with
+// dynamically indexed registers
+template <int NW>
+__device__ __forceinline__ uint64_t word_at(const Bits<NW>& a, int idx) {
+    uint64_t r = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r = (idx == i) ? a.w[i] : r;
+    return r;
+}
+
+// logical shift right by s bits, 0 <= s < 64 * NW (folds to constants when s is known at compile time)
+template <int NW>
+__device__ __forceinline__ Bits<NW> shr(const Bits<NW>& a, int s) {
+    Bits<NW> r;
+    if (NW == 1) {
+        r.w[0] = s < 64 ? (a.w[0] >> s) : 0ull;
+        return r;
+    }
+    const int ws = s >> 6, bs = s & 63;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const uint64_t lo = word_at(a, i + ws);
+        const uint64_t hi = word_at(a, i + ws + 1);
+        r.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+    }
+    return r;
+}
+
+template <int NW>
+__device__ __forceinline__ void set_bit(Bits<NW>& a, int t) {
+    if (NW == 1) {
+        a.w[0] |= 1ull << t;
+        return;
+    }
+    const int ws = t >> 6;
+    const uint64_t m = 1ull << (t & 63);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) a.w[i] |= (ws == i) ? m : 0ull;
+}
+
+template <int NW>
+__device__ __forceinline__ bool test_bit(const Bits<NW>& a, int t) {
+    return (word_at(a, t >> 6) >> (t & 63)) & 1ull;
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry: SH/SW/SK are compile-time dimensions (0 = take the run-time value)
+// ------------------------------------------------------------------------------------------------
+template <int NW_, int SH, int SW, int SK>
+struct Geo {
+    static constexpr int NW = NW_;
+    static constexpr int MAXW = SW ? SW : BGS_CONNECT_MAX_W;  // unroll bound of per-column loops
+    int rh, rw, rk;
+    __device__ __forceinline__ int h() const { return SH ? SH : rh; }
+    __device__ __forceinline__ int w() const { return SW ? SW : rw; }
+    __device__ __forceinline__ int k() const { return SK ? SK : rk; }
+    __device__ __forceinline__ uint32_t all_columns() const { return (1u << w()) - 1u; }
+};
+
+// k stones in a row anywhere on bitboard b: shift-and-AND with run doubling.
+// directions: vertical 1, horizontal H+1, rising diagonal H+2, falling diagonal H.
+template <class G>
+__device__ __forceinline__ bool has_run(const G& g, const Bits<G::NW>& b) {
+    const int k = g.k();
+    const int dirs[4] = {1, g.h() + 1, g.h() + 2, g.h()};
+    Bits<G::NW> hit = zero_bits<G::NW>();
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        Bits<G::NW> m = b;
+        int len = 1;
+        while (2 * len <= k) {
+            m = m & shr(m, len * dirs[d]);
+            len *= 2;
+        }
+        if (len < k) m = m & shr(m, (k - len) * dirs[d]);
+        hit = hit | m;
+    }
+    return any(hit);
+}
+
+// index of the i-th set bit of m (i < popcount(m))
+__device__ __forceinline__ int select_bit(uint32_t m, uint32_t i, int max_bits) {
+    for (int j = 0; j + 1 < max_bits; ++j) {
+        const uint32_t t = m & (m - 1u);
+        m = ((uint32_t)j < i) ? t : m;
+    }
+    return __ffs((int)m) - 1;
+}
+
+// one board in registers: stones of the side to move / of the other side, packed column heights, full columns
+template <int NW>
+struct Lane {
+    Bits<NW> cur, opp;
+    uint64_t hts;    // 4 bits per column
+    uint32_t full;   // bit x set when column x is full
+    uint32_t plies;
+};
+
+template <class G>
+__device__ __forceinline__ Lane<G::NW> empty_lane() {
+    Lane<G::NW> l;
+    l.cur = zero_bits<G::NW>();
+    l.opp = zero_bits<G::NW>();
+    l.hts = 0;
+    l.full = 0;
+    l.plies = 0;
+    return l;
+}
+
+template <class G>
+__device__ __forceinline__ Lane<G::NW> make_lane(const G& g, const Bits<G::NW>& p0, const Bits<G::NW>& p1) {
+    Lane<G::NW> l;
+    l.plies = popcount(p0) + popcount(p1);
+    const bool second = l.plies & 1u;
+    l.cur = second ? p1 : p0;
+    l.opp = second ? p0 : p1;
+    const Bits<G::NW> occ = p0 | p1;
+    const int h = g.h(), w = g.w();
+    const uint64_t colmask = (1ull << (h + 1)) - 1ull;
+    l.hts = 0;
+    l.full = 0;
+#pragma unroll
+    for (int x = 0; x < G::MAXW; ++x) {
+        if (x < w) {
+            const uint32_t hx = (uint32_t)__popcll(shr(occ, x * (h + 1)).w[0] & colmask);
+            l.hts |= (uint64_t)hx << (4 * x);
+            l.full |= (hx == (uint32_t)h) ? (1u << x) : 0u;
+        }
+    }
+    return l;
+}
+
+// one ply: pick the i-th legal column (ascending), drop, test for a win of the mover, then for a draw.
+// returns the new status byte (0 running, 1 / 2 winner, 3 draw)
+template <class G>
+__device__ __forceinline__ uint32_t play_ply(const G& g, Lane<G::NW>& l, uint32_t draw) {
+    const int h = g.h();
+    const uint32_t legal = ~l.full & g.all_columns();
+    const uint32_t n = (uint32_t)__popc(legal);
+    const int col = select_bit(legal, sample_index(draw, n), G::MAXW);
+    const uint32_t hx = (uint32_t)(l.hts >> (4 * col)) & 15u;
+    set_bit(l.cur, col * (h + 1) + (int)hx);
+    l.hts += 1ull << (4 * col);
+    l.full |= (hx + 1u == (uint32_t)h) ? (1u << col) : 0u;
+    const uint32_t mover = l.plies & 1u;
+    const bool won = has_run(g, l.cur);
+    const uint32_t st = won ? mover + 1u : (l.full == g.all_columns() ? BGS_ST_DRAW : BGS_ST_RUNNING);
+    const Bits<G::NW> t = l.cur;
+    l.cur = l.opp;
+    l.opp = t;
+    l.plies += 1u;
+    return st;
+}
+
+// a caller-chosen column; returns false (board untouched) when the column is full or out of range
+template <class G>
+__device__ __forceinline__ bool play_column(const G& g, Lane<G::NW>& l, int col, uint32_t& st) {
+    if (col < 0 || col >= g.w() || ((l.full >> col) & 1u)) return false;
+    const int h = g.h();
+    const uint32_t hx = (uint32_t)(l.hts >> (4 * col)) & 15u;
+    set_bit(l.cur, col * (h + 1) + (int)hx);
+    l.hts += 1ull << (4 * col);
+    l.full |= (hx + 1u == (uint32_t)h) ? (1u << col) : 0u;
+    const uint32_t mover = l.plies & 1u;
+    const bool won = has_run(g, l.cur);
+    st = won ? mover + 1u : (l.full == g.all_columns() ? BGS_ST_DRAW : BGS_ST_RUNNING);
+    const Bits<G::NW> t = l.cur;
+    l.cur = l.opp;
+    l.opp = t;
+    l.plies += 1u;
+    return true;
+}
+
+template <int NW>
+__device__ __forceinline__ void load_planes(const uint64_t* __restrict__ planes, int64_t n, int64_t i, Bits<NW>& p0,
+                                            Bits<NW>& p1) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        p0.w[j] = planes[(int64_t)j * n + i];
+        p1.w[j] = planes[(int64_t)(NW + j) * n + i];
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void lane_planes(const Lane<NW>& l, Bits<NW>& p0, Bits<NW>& p1) {
+    const bool second = l.plies & 1u;  // side to move is player 1: cur holds player 1's stones
+    p0 = second ? l.opp : l.cur;
+    p1 = second ? l.cur : l.opp;
+}
+
+template <int NW>
+__device__ __forceinline__ void store_planes(uint64_t* __restrict__ planes, int64_t n, int64_t i, const Bits<NW>& p0,
+                                             const Bits<NW>& p1) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        planes[(int64_t)j * n + i] = p0.w[j];
+        planes[(int64_t)(NW + j) * n + i] = p1.w[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(BGS_BLOCK) k_connect_reset(uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
+                                                             uint16_t* __restrict__ reward, int64_t n, int words) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    for (int j = 0; j < words; ++j) planes[(int64_t)j * n + i] = 0;
+    status[i] = 0;
+    reward[i] = 0;
+}
+
+// K1: one uniformly sampled ply per running board.  Algorithmic traffic per env-step: both planes in, the
+// mover's plane out, status in/out.
+template <class G>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
+                      int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps) {
+    constexpr int NW = G::NW;
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    uint32_t stepped = 0;
+    if (i < n && status[i] == BGS_ST_RUNNING) {
+        Bits<NW> p0, p1;
+        load_planes<NW>(planes, n, i, p0, p1);
+        Lane<NW> l = make_lane(g, p0, p1);
+        const uint32_t mover = l.plies & 1u;
+        const Philox4 blk = philox4x32_10(seed, first_game + (uint64_t)i, l.plies >> 2);
+        const uint32_t st = play_ply(g, l, philox_word(blk, l.plies));
+        // after the swap the mover's stones are in l.opp; only that plane changed
+#pragma unroll
+        for (int j = 0; j < NW; ++j) planes[(int64_t)(mover * NW + j) * n + i] = l.opp.w[j];
+        if (st != BGS_ST_RUNNING) {
+            status[i] = (uint8_t)st;
+            reward[i] = reward_pair(st);
+        }
+        stepped = 1;
+    }
+    add_steps(steps, stepped);
+}
+
+template <class G>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_step_actions(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
+                       int64_t n, const int32_t* __restrict__ actions, int32_t* __restrict__ result,
+                       unsigned long long* __restrict__ steps) {
+    constexpr int NW = G::NW;
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    uint32_t stepped = 0;
+    if (i < n) {
+        const int col = actions[i];
+        int32_t rc = 0;
+        if (col >= 0) {
+            rc = -2;  // BGS_ERR_ILLEGAL
+            if (status[i] == BGS_ST_RUNNING) {
+                Bits<NW> p0, p1;
+                load_planes<NW>(planes, n, i, p0, p1);
+                Lane<NW> l = make_lane(g, p0, p1);
+                uint32_t st = 0;
+                if (play_column(g, l, col, st)) {
+                    lane_planes(l, p0, p1);
+                    store_planes<NW>(planes, n, i, p0, p1);
+                    if (st != BGS_ST_RUNNING) {
+                        status[i] = (uint8_t)st;
+                        reward[i] = reward_pair(st);
+                    }
+                    stepped = 1;
+                    rc = 0;
+                }
+            }
+        }
+        if (result) result[i] = rc;
+    }
+    add_steps(steps, stepped);
+}
+
+// K2 (first version): one lane plays one board to its end with the board in registers.
+template <class G, bool FROM_INITIAL>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_rollout(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
+                  int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
+                  unsigned long long* __restrict__ steps) {
+    constexpr int NW = G::NW;
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    uint32_t stepped = 0;
+    if (i < n) {
+        uint32_t st = FROM_INITIAL ? BGS_ST_RUNNING : (uint32_t)status[i];
+        Lane<NW> l;
+        if (FROM_INITIAL) {
+            l = empty_lane<G>();
+        } else {
+            Bits<NW> p0, p1;
+            load_planes<NW>(planes, n, i, p0, p1);
+            l = make_lane(g, p0, p1);
+        }
+        const uint64_t game = first_game + (uint64_t)i;
+        Philox4 blk = philox4x32_10(seed, game, l.plies >> 2);
+        while (st == BGS_ST_RUNNING && l.plies < max_plies) {
+            st = play_ply(g, l, philox_word(blk, l.plies));
+            ++stepped;
+            if ((l.plies & 3u) == 0u) blk = philox4x32_10(seed, game, l.plies >> 2);
+        }
+        if (FROM_INITIAL || stepped) {
+            Bits<NW> p0, p1;
+            lane_planes(l, p0, p1);
+            store_planes<NW>(planes, n, i, p0, p1);
+            status[i] = (uint8_t)st;
+            reward[i] = reward_pair(st);
+        }
+    }
+    add_steps(steps, stepped);
+}
+
+// K4: packed planes -> reference layout int8[n][H][W] (row 0 = bottom; -1 empty, 0, 1); 4 output bytes per thread
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_unpack(ConnectGeom cg, const uint64_t* __restrict__ planes, int64_t n, int8_t* __restrict__ grid) {
+    const int64_t total = n * cg.h * cg.w;
+    const int64_t f = ((int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x) * 4;
+    if (f >= total) return;
+    const int hw = cg.h * cg.w;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t idx = f + j;
+        int8_t v = 0;
+        if (idx < total) {
+            const int64_t b = idx / hw;
+            const int cell = (int)(idx - b * hw);
+            const int y = cell / cg.w, x = cell - y * cg.w;
+            const int bit = x * (cg.h + 1) + y;
+            const uint64_t m = 1ull << (bit & 63);
+            const uint64_t w0 = planes[(int64_t)(bit >> 6) * n + b];
+            const uint64_t w1 = planes[(int64_t)(cg.nw + (bit >> 6)) * n + b];
+            v = (w1 & m) ? 1 : ((w0 & m) ? 0 : -1);
+        }
+        packed |= (uint32_t)(uint8_t)v << (8 * j);
+    }
+    if (f + 3 < total) {
+        *reinterpret_cast<uint32_t*>(grid + f) = packed;
+    } else {
+        for (int j = 0; j < 4 && f + j < total; ++j) grid[f + j] = (int8_t)(packed >> (8 * j));
+    }
+}
+
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_meta(ConnectGeom cg, const uint64_t* __restrict__ planes, const uint8_t* __restrict__ status, int64_t n,
+               int8_t* __restrict__ player, uint8_t* __restrict__ ended, int8_t* __restrict__ winner,
+               int32_t* __restrict__ plies) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t count = 0;
+    for (int j = 0; j < 2 * cg.nw; ++j) count += (uint32_t)__popcll(planes[(int64_t)j * n + i]);
+    const uint32_t st = status[i];
+    if (player) player[i] = (int8_t)(count & 1u);
+    if (ended) ended[i] = st != 0;
+    if (winner) winner[i] = st == 0 ? -1 : (st == BGS_ST_DRAW ? 2 : (int8_t)(st - 1));
+    if (plies) plies[i] = (int32_t)count;
+}
+
+template <class G>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_legal(G g, const uint64_t* __restrict__ planes, const uint8_t* __restrict__ status, int64_t n,
+                uint8_t* __restrict__ legal, int32_t* __restrict__ count) {
+    constexpr int NW = G::NW;
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Bits<NW> p0, p1;
+    load_planes<NW>(planes, n, i, p0, p1);
+    const Lane<NW> l = make_lane(g, p0, p1);
+    const uint32_t open = status[i] == BGS_ST_RUNNING ? (~l.full & g.all_columns()) : 0u;
+    if (legal)
+        for (int x = 0; x < g.w(); ++x) legal[i * g.w() + x] = (open >> x) & 1u;
+    if (count) count[i] = __popc(open);
+}
+
+// reference layout -> packed planes, with validation (gravity, stone counts, cell codes)
+template <class G>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_pack(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward, int64_t n,
+               const int8_t* __restrict__ grid, const int8_t* __restrict__ player, const int8_t* __restrict__ winner,
+               int32_t* __restrict__ result) {
+    constexpr int NW = G::NW;
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int h = g.h(), w = g.w();
+    const int8_t* cells = grid + i * h * w;
+    Bits<NW> p0 = zero_bits<NW>(), p1 = zero_bits<NW>();
+    bool ok = true;
+    int c0 = 0, c1 = 0;
+    for (int x = 0; x < w; ++x) {
+        bool open = false;  // an empty cell was seen lower in this column
+        for (int y = 0; y < h; ++y) {
+            const int v = cells[y * w + x];
+            if (v == -1) {
+                open = true;
+            } else if (v == 0 || v == 1) {
+                if (open) ok = false;
+                if (v == 0) { set_bit(p0, x * (h + 1) + y); ++c0; }
+                else { set_bit(p1, x * (h + 1) + y); ++c1; }
+            } else {
+                ok = false;
+            }
+        }
+    }
+    if (!(c0 == c1 || c0 == c1 + 1)) ok = false;
+    if (player && ok && player[i] != ((c0 + c1) & 1)) ok = false;
+    uint32_t st = BGS_ST_RUNNING;
+    if (winner) {
+        const int wv = winner[i];
+        if (wv < -1 || wv > 2) ok = false;
+        st = wv == -1 ? 0u : (wv == 2 ? BGS_ST_DRAW : (uint32_t)(wv + 1));
+    } else if (ok) {
+        if (has_run(g, p0)) st = 1u;
+        else if (has_run(g, p1)) st = 2u;
+        else if (c0 + c1 == h * w) st = BGS_ST_DRAW;
+    }
+    if (ok) {
+        store_planes<NW>(planes, n, i, p0, p1);
+        status[i] = (uint8_t)st;
+        reward[i] = reward_pair(st);
+    }
+    if (result) result[i] = ok ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch: static instantiations for the BASELINE geometries, run-time geometry otherwise
+// ------------------------------------------------------------------------------------------------
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + BGS_BLOCK - 1) / BGS_BLOCK); }
+
+template <class F>
+void dispatch(const ConnectGeom& cg, F&& f) {
+    if (cg.h == 6 && cg.w == 7 && cg.k == 4) { f(Geo<1, 6, 7, 4>{6, 7, 4}); return; }
+    if (cg.h == 12 && cg.w == 13 && cg.k == 5) { f(Geo<3, 12, 13, 5>{12, 13, 5}); return; }
+    switch (cg.nw) {
+        case 1: f(Geo<1, 0, 0, 0>{cg.h, cg.w, cg.k}); return;
+        case 2: f(Geo<2, 0, 0, 0>{cg.h, cg.w, cg.k}); return;
+        default: f(Geo<3, 0, 0, 0>{cg.h, cg.w, cg.k}); return;
+    }
+}
+
+}  // namespace
+
+void connect_reset(const bgs_batch* b) {
+    hipLaunchKernelGGL(k_connect_reset, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->d_planes, b->d_status,
+                       reinterpret_cast<uint16_t*>(b->d_reward), b->n, b->planes);
+}
+
+void connect_step_random(const bgs_batch* b, uint64_t seed) {
+    dispatch(b->cg, [&](auto g) {
+        using G = decltype(g);
+        hipLaunchKernelGGL((k_connect_step_random<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g, b->d_planes,
+                           b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, b->d_steps);
+    });
+}
+
+void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out) {
+    dispatch(b->cg, [&](auto g) {
+        using G = decltype(g);
+        hipLaunchKernelGGL((k_connect_step_actions<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g, b->d_planes,
+                           b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_actions, d_status_out, b->d_steps);
+    });
+}
+
+void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
+    const uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
+    dispatch(b->cg, [&](auto g) {
+        using G = decltype(g);
+        if (flags & 1u)
+            hipLaunchKernelGGL((k_connect_rollout<G, true>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g,
+                               b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
+                               cap, b->d_steps);
+        else
+            hipLaunchKernelGGL((k_connect_rollout<G, false>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g,
+                               b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
+                               cap, b->d_steps);
+    });
+}
+
+void connect_unpack_grid(const bgs_batch* b, int8_t* d_grid) {
+    const int64_t quads = (b->n * b->cg.h * b->cg.w + 3) / 4;
+    hipLaunchKernelGGL(k_connect_unpack, dim3(grid_for(quads)), dim3(BGS_BLOCK), 0, b->stream, b->cg, b->d_planes, b->n,
+                       d_grid);
+}
+
+void connect_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies) {
+    hipLaunchKernelGGL(k_connect_meta, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->cg, b->d_planes, b->d_status,
+                       b->n, d_player, d_ended, d_winner, d_plies);
+}
+
+void connect_legal(const bgs_batch* b, uint8_t* d_legal, int32_t* d_count) {
+    dispatch(b->cg, [&](auto g) {
+        using G = decltype(g);
+        hipLaunchKernelGGL((k_connect_legal<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g, b->d_planes,
+                           b->d_status, b->n, d_legal, d_count);
+    });
+}
+
+void connect_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_player, const int8_t* d_winner,
+                  int32_t* d_status_out) {
+    dispatch(b->cg, [&](auto g) {
+        using G = decltype(g);
+        hipLaunchKernelGGL((k_connect_pack<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g, b->d_planes,
+                           b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_grid, d_player, d_winner,
+                           d_status_out);
+    });
+}
+
+}  // namespace bgs

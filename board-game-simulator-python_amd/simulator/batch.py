@@ -1,0 +1,300 @@
+"""Batched boards on one MI355X: the host-side mirror of the reference's Config/State/Action loop, N boards a call.
+
+The reference loop (README.md:45-72)::
+
+    state = config.sample_initial_state()
+    while not state.has_ended:
+        action = random.choice(state.actions)
+        state = action.sample_next_state()
+    reward = state.reward
+
+becomes ``batch = ConnectBatch(6, 7, 4, n); batch.rollout(seed); batch.reward`` -- one HIP launch.  Every method is
+a thin call into libbgs.so (include/bgs.h); arrays come back in the reference layout (``grid`` int8[n, H, W], row 0 =
+bottom row).  PyTorch, when present with a GPU, only provides the device arena and the stream (plumbing).
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from .game import _abi
+
+DEFAULT_SEED = 0x0123456789ABCDEF
+
+
+def _ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+def _torch_cuda():
+    try:
+        import torch
+    except ImportError:  # torch is optional: the library then owns its device memory
+        return None
+    return torch if torch.cuda.is_available() else None
+
+
+class _Batch:
+    """Common part of ConnectBatch / BounceBatch: lifetime, stepping, observation."""
+
+    game = 0
+
+    def __init__(self, n: int, height: int, width: int, device: int, use_torch: Optional[bool]):
+        self.n = int(n)
+        self.height = int(height)
+        self.width = int(width)
+        self.device = int(device)
+        self._handle = _abi.c_handle()
+        self._arena = None
+        self._torch = None
+        if use_torch is None or use_torch:
+            self._torch = _torch_cuda()
+            if use_torch and self._torch is None:
+                raise RuntimeError("use_torch=True but torch with a visible GPU is not available")
+
+    # ---- lifetime -------------------------------------------------------------------------------
+    def _make_arena(self, nbytes: int):
+        if self._torch is None:
+            return None, 0
+        self._arena = self._torch.empty(nbytes, dtype=self._torch.uint8, device=f"cuda:{self.device}")
+        return ctypes.c_void_p(self._arena.data_ptr()), nbytes
+
+    def _after_create(self):
+        if self._torch is not None:
+            self.set_stream(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self) -> None:
+        if self._handle:
+            _abi.lib().bgs_destroy(self._handle)
+            self._handle = _abi.c_handle()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: int) -> None:
+        _abi.check(_abi.lib().bgs_set_stream(self._handle, ctypes.c_void_p(hip_stream)))
+
+    def set_first_game(self, first_game: int) -> None:
+        """Global id of board 0: RNG streams are keyed by global game id, so shards reproduce the unsharded run."""
+        _abi.check(_abi.lib().bgs_set_first_game(self._handle, ctypes.c_uint64(first_game)))
+
+    def synchronize(self) -> None:
+        _abi.check(_abi.lib().bgs_synchronize(self._handle))
+
+    # ---- the hot path ---------------------------------------------------------------------------
+    def reset(self) -> None:
+        _abi.check(_abi.lib().bgs_reset(self._handle))
+
+    def step_random(self, seed: int = DEFAULT_SEED) -> None:
+        _abi.check(_abi.lib().bgs_step_random(self._handle, ctypes.c_uint64(seed)))
+
+    def rollout(self, seed: int = DEFAULT_SEED, max_plies: int = 2**31 - 1, from_initial: bool = False) -> None:
+        flags = _abi.ROLLOUT_FROM_INITIAL if from_initial else 0
+        _abi.check(_abi.lib().bgs_rollout(self._handle, ctypes.c_uint64(seed), ctypes.c_int32(max_plies), ctypes.c_uint32(flags)))
+
+    def _step_actions(self, actions, per_board: int, want_status: bool):
+        status = np.zeros(self.n, dtype=np.int32) if want_status else None
+        sp = _ptr(status, ctypes.c_int32) if want_status else None
+        if self._torch is not None and isinstance(actions, self._torch.Tensor):
+            t = actions
+            if not (t.is_cuda and t.dtype == self._torch.int32 and t.is_contiguous() and t.numel() == self.n * per_board):
+                raise TypeError("device actions must be a contiguous int32 CUDA tensor of the batch's shape")
+            _abi.check(_abi.lib().bgs_step_actions(self._handle, ctypes.c_void_p(t.data_ptr()), 1, sp))
+        else:
+            a = np.ascontiguousarray(actions, dtype=np.int32)
+            if a.size != self.n * per_board:
+                raise TypeError(f"expected {self.n * per_board} action entries, got {a.size}")
+            _abi.check(_abi.lib().bgs_step_actions(self._handle, ctypes.c_void_p(a.ctypes.data), 0, sp))
+        return status
+
+    @property
+    def steps(self) -> int:
+        """env-steps applied since the last reset (transitions on running boards)."""
+        v = ctypes.c_uint64(0)
+        _abi.check(_abi.lib().bgs_steps(self._handle, ctypes.byref(v)))
+        return v.value
+
+    def reset_steps(self) -> None:
+        _abi.check(_abi.lib().bgs_reset_steps(self._handle))
+
+    # ---- observation (reference layout, host copies) ------------------------------------------------
+    @property
+    def grid(self) -> np.ndarray:
+        out = np.empty((self.n, self.height, self.width), dtype=np.int8)
+        _abi.check(_abi.lib().bgs_read_grid(self._handle, _ptr(out, ctypes.c_int8)))
+        return out
+
+    @property
+    def player(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.int8)
+        _abi.check(_abi.lib().bgs_read_player(self._handle, _ptr(out, ctypes.c_int8)))
+        return out
+
+    @property
+    def has_ended(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.uint8)
+        _abi.check(_abi.lib().bgs_read_ended(self._handle, _ptr(out, ctypes.c_uint8)))
+        return out.astype(bool)
+
+    @property
+    def winner(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.int8)
+        _abi.check(_abi.lib().bgs_read_winner(self._handle, _ptr(out, ctypes.c_int8)))
+        return out
+
+    @property
+    def reward(self) -> np.ndarray:
+        out = np.empty((self.n, 2), dtype=np.int8)
+        _abi.check(_abi.lib().bgs_read_reward(self._handle, _ptr(out, ctypes.c_int8)))
+        return out
+
+    @property
+    def plies(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.int32)
+        _abi.check(_abi.lib().bgs_read_plies(self._handle, _ptr(out, ctypes.c_int32)))
+        return out
+
+    @property
+    def action_count(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.int32)
+        _abi.check(_abi.lib().bgs_read_action_count(self._handle, _ptr(out, ctypes.c_int32)))
+        return out
+
+    def write_state(self, grid, player=None, winner=None, plies=None) -> np.ndarray:
+        """Load boards in the reference layout; returns per-board status (0 ok, -1 malformed and left untouched)."""
+        g = np.ascontiguousarray(grid, dtype=np.int8)
+        if g.shape != (self.n, self.height, self.width):
+            raise TypeError(f"grid must have shape {(self.n, self.height, self.width)}, got {g.shape}")
+        p = None if player is None else np.ascontiguousarray(player, dtype=np.int8)
+        w = None if winner is None else np.ascontiguousarray(winner, dtype=np.int8)
+        l = None if plies is None else np.ascontiguousarray(plies, dtype=np.int32)
+        status = np.zeros(self.n, dtype=np.int32)
+        _abi.check(
+            _abi.lib().bgs_write_state(
+                self._handle,
+                _ptr(g, ctypes.c_int8),
+                None if p is None else _ptr(p, ctypes.c_int8),
+                None if w is None else _ptr(w, ctypes.c_int8),
+                None if l is None else _ptr(l, ctypes.c_int32),
+                _ptr(status, ctypes.c_int32),
+            )
+        )
+        return status
+
+    # ---- device-side hand-over (torch / RCCL plumbing) -----------------------------------------------
+    def buffer(self, buffer_id: int):
+        """(device pointer, bytes) of one of the batch's buffers (see bgs_buffer_id in include/bgs.h)."""
+        p = ctypes.c_void_p()
+        sz = ctypes.c_size_t()
+        _abi.check(_abi.lib().bgs_buffer(self._handle, buffer_id, ctypes.byref(p), ctypes.byref(sz)))
+        return p.value, sz.value
+
+    def _arena_view(self, buffer_id: int):
+        if self._arena is None:
+            raise RuntimeError("device views need the torch-owned arena (construct the batch with torch + GPU available)")
+        ptr, nbytes = self.buffer(buffer_id)
+        off = ptr - self._arena.data_ptr()
+        return self._arena[off : off + nbytes]
+
+    def reward_tensor(self):
+        """Zero-copy torch view int8[n, 2] of the device reward buffer (what the RCCL gather ships)."""
+        return self._arena_view(_abi.BUF_REWARD).view(self._torch.int8).view(self.n, 2)
+
+    def status_tensor(self):
+        return self._arena_view(_abi.BUF_STATUS)
+
+    def steps_tensor(self):
+        return self._arena_view(_abi.BUF_STEPS).view(self._torch.int64)
+
+    def grid_tensor(self, out=None):
+        """Observation tensor int8[n, H, W] on the device (no host round trip), e.g. as policy-network input."""
+        t = self._torch
+        if t is None:
+            raise RuntimeError("grid_tensor needs torch with a GPU")
+        if out is None:
+            out = t.empty((self.n, self.height, self.width), dtype=t.int8, device=f"cuda:{self.device}")
+        _abi.check(_abi.lib().bgs_export_device(self._handle, ord("g"), ctypes.c_void_p(out.data_ptr())))
+        return out
+
+
+class ConnectBatch(_Batch):
+    """N Connect-k boards: ``Config(height, width, count)`` (reference connect.cpp:26) times n."""
+
+    game = _abi.GAME_CONNECT
+
+    def __init__(self, height: int, width: int, count: int, n: int, device: int = 0, use_torch: Optional[bool] = None):
+        super().__init__(n, height, width, device, use_torch)
+        self.count = int(count)
+        nbytes = ctypes.c_size_t()
+        _abi.check(_abi.lib().bgs_connect_arena_bytes(self.height, self.width, self.count, self.n, ctypes.byref(nbytes)))
+        arena, arena_bytes = self._make_arena(nbytes.value)
+        _abi.check(
+            _abi.lib().bgs_connect_create(
+                self.height, self.width, self.count, self.n, self.device, arena, arena_bytes, ctypes.byref(self._handle)
+            )
+        )
+        self._after_create()
+
+    def step_actions(self, columns, want_status: bool = True):
+        """columns int32[n]; a negative entry skips the board.  Returns per-board status (0 / -2 illegal)."""
+        return self._step_actions(columns, 1, want_status)
+
+    @property
+    def legal(self) -> np.ndarray:
+        out = np.empty((self.n, self.width), dtype=np.uint8)
+        _abi.check(_abi.lib().bgs_read_legal(self._handle, _ptr(out, ctypes.c_uint8)))
+        return out
+
+    def legal_tensor(self, out=None):
+        t = self._torch
+        if t is None:
+            raise RuntimeError("legal_tensor needs torch with a GPU")
+        if out is None:
+            out = t.empty((self.n, self.width), dtype=t.uint8, device=f"cuda:{self.device}")
+        _abi.check(_abi.lib().bgs_export_device(self._handle, ord("l"), ctypes.c_void_p(out.data_ptr())))
+        return out
+
+
+class BounceBatch(_Batch):
+    """N Bounce boards sharing one start grid: ``Config(grid)`` (reference bounce.cpp:26) times n."""
+
+    game = _abi.GAME_BOUNCE
+
+    def __init__(self, grid, n: int, device: int = 0, use_torch: Optional[bool] = None):
+        cfg = np.ascontiguousarray(grid)
+        if cfg.ndim != 2:
+            raise TypeError("Bounce config grid must be 2-dimensional")
+        if not np.issubdtype(cfg.dtype, np.integer):
+            raise TypeError("Bounce config grid must be an integer array")
+        if cfg.size and (cfg.min() < -128 or cfg.max() > 127):
+            raise TypeError("Bounce config grid does not fit int8")
+        cfg = cfg.astype(np.int8)
+        super().__init__(n, cfg.shape[0], cfg.shape[1], device, use_torch)
+        self.config_grid = cfg
+        nbytes = ctypes.c_size_t()
+        _abi.check(_abi.lib().bgs_bounce_arena_bytes(self.height, self.width, self.n, ctypes.byref(nbytes)))
+        arena, arena_bytes = self._make_arena(nbytes.value)
+        _abi.check(
+            _abi.lib().bgs_bounce_create(
+                _ptr(cfg, ctypes.c_int8), self.height, self.width, self.n, self.device, arena, arena_bytes, ctypes.byref(self._handle)
+            )
+        )
+        self._after_create()
+
+    def step_actions(self, moves, want_status: bool = True):
+        """moves int32[n, 4] = source x, y, target x, y; a negative first entry skips the board."""
+        return self._step_actions(moves, 4, want_status)
+
+    @property
+    def targets(self) -> np.ndarray:
+        """uint64[n, W + 1]: entry i < W has bit (y * W + x) set for each legal target of the piece in column i of the
+        active row; entry W is the active row's y (all ones when nothing can move)."""
+        out = np.empty((self.n, self.width + 1), dtype=np.uint64)
+        _abi.check(_abi.lib().bgs_bounce_read_targets(self._handle, _ptr(out, ctypes.c_uint64)))
+        return out

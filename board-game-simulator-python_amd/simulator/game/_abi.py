@@ -1,0 +1,123 @@
+"""ctypes binding of libbgs.so (C ABI: include/bgs.h) -- the only door from Python into the HIP kernels.
+
+There is no CPU fallback: if the library is missing or no GPU is visible, the compute entry points raise.
+The nanobind modules of the reference (src/simulator/game/connect.cpp, bounce.cpp) are replaced by this file plus
+the thin Python classes in connect.py / bounce.py / ../batch.py.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_PATH = os.environ.get("BGS_LIBRARY", os.path.join(_PKG_DIR, "libbgs.so"))
+
+BGS_OK = 0
+BGS_ERR_ARG = -1
+BGS_ERR_ILLEGAL = -2
+BGS_ERR_RUNTIME = -3
+BGS_ERR_NO_DEVICE = -4
+
+BUF_PLANES, BUF_STATUS, BUF_PLIES, BUF_REWARD, BUF_STEPS, BUF_STAGING = range(6)
+ROLLOUT_FROM_INITIAL = 1
+
+GAME_CONNECT = 1
+GAME_BOUNCE = 2
+
+c_handle = ctypes.c_void_p
+_i8p = ctypes.POINTER(ctypes.c_int8)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+# name -> (restype, argtypes): every symbol include/bgs.h declares
+SIGNATURES = {
+    "bgs_version": (ctypes.c_int, []),
+    "bgs_last_error": (ctypes.c_char_p, []),
+    "bgs_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "bgs_connect_arena_bytes": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]),
+    "bgs_connect_create": (
+        ctypes.c_int,
+        [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(c_handle)],
+    ),
+    "bgs_bounce_arena_bytes": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]),
+    "bgs_bounce_create": (
+        ctypes.c_int,
+        [_i8p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(c_handle)],
+    ),
+    "bgs_destroy": (ctypes.c_int, [c_handle]),
+    "bgs_set_stream": (ctypes.c_int, [c_handle, ctypes.c_void_p]),
+    "bgs_set_first_game": (ctypes.c_int, [c_handle, ctypes.c_uint64]),
+    "bgs_synchronize": (ctypes.c_int, [c_handle]),
+    "bgs_info": (
+        ctypes.c_int,
+        [c_handle] + [ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)],
+    ),
+    "bgs_buffer": (ctypes.c_int, [c_handle, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]),
+    "bgs_reset": (ctypes.c_int, [c_handle]),
+    "bgs_step_random": (ctypes.c_int, [c_handle, ctypes.c_uint64]),
+    "bgs_step_actions": (ctypes.c_int, [c_handle, ctypes.c_void_p, ctypes.c_int, _i32p]),
+    "bgs_rollout": (ctypes.c_int, [c_handle, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32]),
+    "bgs_steps": (ctypes.c_int, [c_handle, _u64p]),
+    "bgs_reset_steps": (ctypes.c_int, [c_handle]),
+    "bgs_read_grid": (ctypes.c_int, [c_handle, _i8p]),
+    "bgs_read_player": (ctypes.c_int, [c_handle, _i8p]),
+    "bgs_read_ended": (ctypes.c_int, [c_handle, _u8p]),
+    "bgs_read_winner": (ctypes.c_int, [c_handle, _i8p]),
+    "bgs_read_reward": (ctypes.c_int, [c_handle, _i8p]),
+    "bgs_read_plies": (ctypes.c_int, [c_handle, _i32p]),
+    "bgs_read_legal": (ctypes.c_int, [c_handle, _u8p]),
+    "bgs_read_action_count": (ctypes.c_int, [c_handle, _i32p]),
+    "bgs_bounce_read_targets": (ctypes.c_int, [c_handle, _u64p]),
+    "bgs_export_device": (ctypes.c_int, [c_handle, ctypes.c_int, ctypes.c_void_p]),
+    "bgs_write_state": (ctypes.c_int, [c_handle, _i8p, _i8p, _i8p, _i32p, _i32p]),
+}
+
+_lib = None
+
+
+class BgsError(RuntimeError):
+    """A libbgs call failed (the reference surfaces C++ exceptions as RuntimeError too)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libbgs error {code}: {message}")
+        self.code = code
+
+
+def lib() -> ctypes.CDLL:
+    """Load libbgs.so; fail loudly when it is absent (build it with `python __graft_entry__.py`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+                "Build it with `make -C board-game-simulator-python_amd/csrc` or `python __graft_entry__.py`."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().bgs_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int) -> None:
+    if rc == BGS_OK:
+        return
+    msg = last_error()
+    if rc == BGS_ERR_ARG:
+        raise ValueError(f"libbgs: {msg}")
+    raise BgsError(rc, msg)
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    check(lib().bgs_device_count(ctypes.byref(n)))
+    return n.value

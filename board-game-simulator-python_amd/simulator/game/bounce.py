@@ -1,0 +1,265 @@
+"""``simulator.game.bounce`` -- drop-in for the reference's nanobind module (src/simulator/game/bounce.cpp:19-61).
+
+Same names and semantics as the reference's ``Config`` / ``State`` / ``Action`` (bounce.pyi:5-43).  The move search
+(active row, exact-count walks with bouncing), the transition and the goal / blocked / draw test run in the HIP
+kernels behind libbgs.so on a one-board device batch; nothing here re-implements the rules.  For many boards at a
+time use ``simulator.batch.BounceBatch``.
+
+Coordinates are ``(x, y)`` arrays with ``y = 0`` the bottom row (tests/test_bounce.py:27-35); ``grid[y, x]`` is 0 for
+an empty cell, otherwise the piece's step count.
+"""
+
+from __future__ import annotations
+
+import os
+import threading
+from typing import Any, ClassVar, Dict, List, Tuple
+
+import numpy as np
+
+from ._value import ValueObject
+from ..batch import BounceBatch
+
+_DEVICE = int(os.environ.get("BGS_DEVICE", "0"))
+
+Cell = Tuple[int, int]
+
+
+def _as_cell(value, what: str) -> Cell:
+    a = np.asarray(value)
+    if a.shape != (2,) or not np.issubdtype(a.dtype, np.integer):
+        raise TypeError(f"{what} must be an integer array of shape (2,)")
+    return int(a[0]), int(a[1])
+
+
+class _Engine:
+    """One-board device batch per start grid (shared, locked)."""
+
+    _cache: Dict[Tuple[Tuple[int, int], bytes], "_Engine"] = {}
+    _cache_lock = threading.Lock()
+
+    def __init__(self, grid: np.ndarray):
+        self.batch = BounceBatch(grid, 1, device=_DEVICE, use_torch=False)
+        self.lock = threading.Lock()
+
+    @classmethod
+    def get(cls, grid: np.ndarray) -> "_Engine":
+        key = (grid.shape, grid.tobytes())
+        with cls._cache_lock:
+            eng = cls._cache.get(key)
+            if eng is None:
+                eng = cls._cache[key] = _Engine(grid)
+            return eng
+
+    def _observe(self):
+        b = self.batch
+        grid = b.grid[0]
+        player, winner, plies = int(b.player[0]), int(b.winner[0]), int(b.plies[0])
+        masks = b.targets[0]
+        width = b.width
+        moves: List[Tuple[Cell, Cell]] = []
+        if winner == -1 and int(masks[width]) < b.height:
+            row = int(masks[width])  # the active row, as reported by the device
+            for x in range(width):
+                m = int(masks[x])
+                c = 0
+                while m:
+                    if m & 1:
+                        moves.append(((x, row), (c % width, c // width)))
+                    m >>= 1
+                    c += 1
+        return grid, player, winner, plies, tuple(moves)
+
+    def initial(self):
+        with self.lock:
+            self.batch.reset()
+            return self._observe()
+
+    def _load(self, grid, player, winner, plies):
+        status = self.batch.write_state(
+            grid[None], np.array([player], dtype=np.int8), np.array([winner], dtype=np.int8), np.array([plies], dtype=np.int32)
+        )
+        if status[0] != 0:
+            raise RuntimeError("malformed Bounce state")
+
+    def load(self, grid, player, winner, plies):
+        with self.lock:
+            self._load(grid, player, winner, plies)
+            return self._observe()
+
+    def after(self, grid, player, winner, plies, source: Cell, target: Cell):
+        with self.lock:
+            self._load(grid, player, winner, plies)
+            status = self.batch.step_actions(np.array([[source[0], source[1], target[0], target[1]]], dtype=np.int32))
+            if status[0] != 0:
+                raise RuntimeError(f"illegal action: {source} -> {target}")
+            return self._observe()
+
+
+class Config(ValueObject):
+    """``Config(grid)`` -- any integer 2-D array convertible to int8 (bounce.cpp:26, tensor.hpp:41-66)."""
+
+    __slots__ = ("_grid",)
+    num_players: ClassVar[int] = 2
+    State: ClassVar[type]
+
+    def __init__(self, grid) -> None:
+        a = np.asarray(grid)
+        if a.ndim != 2 or not np.issubdtype(a.dtype, np.integer):
+            raise TypeError("Config(grid: 2-D integer ndarray)")
+        if a.size and (a.min() < -128 or a.max() > 127):
+            raise TypeError("Config grid does not fit int8")
+        g = np.ascontiguousarray(a, dtype=np.int8)
+        g.setflags(write=False)
+        object.__setattr__(self, "_grid", g)
+        h, w = g.shape
+        if h < 3 or w < 1 or (g < 0).any() or g[0].any() or g[-1].any():
+            raise RuntimeError("invalid Bounce grid: need height >= 3, non-negative values and empty goal rows")
+
+    def __setattr__(self, name, value):
+        raise AttributeError("Config is immutable")
+
+    def _key(self):
+        return (self._grid.shape, self._grid.tobytes())
+
+    def __repr__(self):
+        return f"Config({self._grid.tolist()})"
+
+    @property
+    def grid(self) -> np.ndarray:
+        return self._grid.copy()
+
+    def _engine(self) -> _Engine:
+        return _Engine.get(self._grid)
+
+    def sample_initial_state(self) -> "State":
+        return State(self, *self._engine().initial())
+
+    def to_json(self) -> Dict[str, Any]:
+        return {"grid": self._grid.tolist()}
+
+    @staticmethod
+    def from_json(value: Dict[str, Any]) -> "Config":
+        try:
+            return Config(np.array(value["grid"], dtype=np.int64))
+        except (KeyError, TypeError, ValueError) as exc:
+            raise RuntimeError(f"invalid Bounce config JSON: {exc}") from None
+
+
+class State(ValueObject):
+    __slots__ = ("config", "_grid", "_player", "_winner", "_plies", "_moves")
+    Action: ClassVar[type]
+
+    def __init__(self, config: Config, grid, player: int, winner: int, plies: int, moves):
+        object.__setattr__(self, "config", config)
+        g = np.array(grid, dtype=np.int8)
+        g.setflags(write=False)
+        object.__setattr__(self, "_grid", g)
+        object.__setattr__(self, "_player", int(player))
+        object.__setattr__(self, "_winner", int(winner))
+        object.__setattr__(self, "_plies", int(plies))
+        object.__setattr__(self, "_moves", tuple(moves))
+
+    def __setattr__(self, name, value):
+        raise AttributeError("State is immutable")
+
+    def _key(self):
+        return (self.config._key(), self._grid.tobytes(), self._player, self._winner)
+
+    def __repr__(self):
+        return f"State(player={self._player}, winner={self._winner}, grid={self._grid.tolist()})"
+
+    @property
+    def has_ended(self) -> bool:
+        return self._winner != -1
+
+    @property
+    def player(self) -> int:
+        return self._player
+
+    @property
+    def grid(self) -> np.ndarray:
+        return self._grid.copy()
+
+    @property
+    def reward(self) -> np.ndarray:
+        r = np.zeros(2, dtype=np.int8)
+        if self._winner in (0, 1):
+            r[self._winner] = 1
+            r[1 - self._winner] = -1
+        return r
+
+    @property
+    def actions(self) -> List["Action"]:
+        return [Action(self, s, t) for s, t in self._moves]
+
+    def actions_at(self, source) -> List["Action"]:
+        src = _as_cell(source, "source")
+        h, w = self._grid.shape
+        if not (0 <= src[0] < w and 0 <= src[1] < h):
+            raise RuntimeError(f"source {src} is outside the board")
+        return [Action(self, s, t) for s, t in self._moves if s == src]
+
+    def action_at(self, source, target) -> "Action":
+        src, dst = _as_cell(source, "source"), _as_cell(target, "target")
+        if (src, dst) not in self._moves:
+            raise RuntimeError(f"illegal action: {src} -> {dst}")
+        return Action(self, src, dst)
+
+    def to_json(self) -> Dict[str, Any]:
+        return {"grid": self._grid.tolist(), "player": self._player, "winner": self._winner}
+
+    @staticmethod
+    def from_json(value: Dict[str, Any], config: Config) -> "State":
+        try:
+            grid = np.array(value["grid"], dtype=np.int8)
+            player, winner = int(value["player"]), int(value["winner"])
+        except (KeyError, TypeError, ValueError) as exc:
+            raise RuntimeError(f"invalid Bounce state JSON: {exc}") from None
+        if grid.shape != config._grid.shape:
+            raise RuntimeError("state grid does not match the config")
+        return State(config, *config._engine().load(grid, player, winner, player))
+
+
+class Action(ValueObject):
+    __slots__ = ("state", "_source", "_target")
+
+    def __init__(self, state: State, source: Cell, target: Cell):
+        object.__setattr__(self, "state", state)
+        object.__setattr__(self, "_source", (int(source[0]), int(source[1])))
+        object.__setattr__(self, "_target", (int(target[0]), int(target[1])))
+
+    def __setattr__(self, name, value):
+        raise AttributeError("Action is immutable")
+
+    def _key(self):
+        return (self.state._key(), self._source, self._target)
+
+    def __repr__(self):
+        return f"Action(source={self._source}, target={self._target})"
+
+    @property
+    def source(self) -> np.ndarray:
+        return np.array(self._source, dtype=np.int64)
+
+    @property
+    def target(self) -> np.ndarray:
+        return np.array(self._target, dtype=np.int64)
+
+    def sample_next_state(self) -> State:
+        s = self.state
+        return State(s.config, *s.config._engine().after(s._grid, s._player, s._winner, s._plies, self._source, self._target))
+
+    def to_json(self) -> Dict[str, Any]:
+        return {"source": list(self._source), "target": list(self._target)}
+
+    @staticmethod
+    def from_json(value: Dict[str, Any], state: State) -> "Action":
+        try:
+            return state.action_at(np.array(value["source"]), np.array(value["target"]))
+        except (KeyError, TypeError, ValueError) as exc:
+            raise RuntimeError(f"invalid Bounce action JSON: {exc}") from None
+
+
+Config.State = State
+State.Action = Action

@@ -1,0 +1,221 @@
+"""``simulator.game.connect`` -- drop-in for the reference's nanobind module (src/simulator/game/connect.cpp:19-62).
+
+Same names and semantics as the reference's ``Config`` / ``State`` / ``Action`` (connect.pyi:5-43); every rule
+(legal columns, the drop, the k-in-a-row / draw test, the reward) is evaluated by the HIP kernels behind libbgs.so
+on a one-board device batch -- there is no Python or CPU re-implementation of the game here.  For many boards at a
+time use ``simulator.batch.ConnectBatch``.
+
+Cell codes (tests/test_connect.py:24-25): -1 empty, 0 / 1 the players; ``grid[0]`` is the bottom row.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Any, ClassVar, Dict, List, Tuple
+
+import numpy as np
+
+from . import _abi
+from ._value import ValueObject
+from ..batch import ConnectBatch
+
+_DEVICE = int(os.environ.get("BGS_DEVICE", "0"))
+
+
+class _Engine:
+    """One-board device batch that evaluates transitions for the object API (one per geometry, shared, locked:
+    callers do use worker threads -- textual/examples/agent.py:61,71)."""
+
+    _cache: Dict[Tuple[int, int, int], "_Engine"] = {}
+    _cache_lock = threading.Lock()
+
+    def __init__(self, height: int, width: int, count: int):
+        self.batch = ConnectBatch(height, width, count, 1, device=_DEVICE, use_torch=False)
+        self.lock = threading.Lock()
+
+    @classmethod
+    def get(cls, height: int, width: int, count: int) -> "_Engine":
+        key = (height, width, count)
+        with cls._cache_lock:
+            eng = cls._cache.get(key)
+            if eng is None:
+                eng = cls._cache[key] = _Engine(height, width, count)
+            return eng
+
+    def _observe(self):
+        b = self.batch
+        grid = b.grid[0]
+        legal = tuple(int(c) for c in np.flatnonzero(b.legal[0]))
+        return grid, int(b.player[0]), int(b.winner[0]), legal
+
+    def initial(self):
+        with self.lock:
+            self.batch.reset()
+            return self._observe()
+
+    def load(self, grid: np.ndarray, player: int, winner: int):
+        with self.lock:
+            self._load(grid, player, winner)
+            return self._observe()
+
+    def _load(self, grid, player, winner):
+        status = self.batch.write_state(grid[None], np.array([player], dtype=np.int8), np.array([winner], dtype=np.int8))
+        if status[0] != 0:
+            raise RuntimeError("malformed Connect state")
+
+    def after(self, grid: np.ndarray, player: int, winner: int, column: int):
+        with self.lock:
+            self._load(grid, player, winner)
+            status = self.batch.step_actions(np.array([column], dtype=np.int32))
+            if status[0] != 0:
+                raise RuntimeError(f"illegal action: column {column}")
+            return self._observe()
+
+
+class Config(ValueObject):
+    """``Config(height, width, count)`` -- positional ints, as bound at connect.cpp:26."""
+
+    __slots__ = ("height", "width", "count")
+    num_players: ClassVar[int] = 2
+    State: ClassVar[type]
+
+    def __init__(self, height: int, width: int, count: int) -> None:
+        for v in (height, width, count):
+            if isinstance(v, bool) or not isinstance(v, (int, np.integer)):
+                raise TypeError("Config(height: int, width: int, count: int)")
+        object.__setattr__(self, "height", int(height))
+        object.__setattr__(self, "width", int(width))
+        object.__setattr__(self, "count", int(count))
+        # geometry limits are the packed representation's (host-side check, no GPU needed); ValueError if outside
+        nbytes = ctypes.c_size_t()
+        _abi.check(_abi.lib().bgs_connect_arena_bytes(self.height, self.width, self.count, 1, ctypes.byref(nbytes)))
+
+    def __setattr__(self, name, value):
+        raise AttributeError("Config is immutable")
+
+    def _key(self):
+        return (self.height, self.width, self.count)
+
+    def __repr__(self):
+        return f"Config({self.height}, {self.width}, {self.count})"
+
+    def _engine(self) -> _Engine:
+        return _Engine.get(self.height, self.width, self.count)
+
+    def sample_initial_state(self) -> "State":
+        return State(self, *self._engine().initial())
+
+    def to_json(self) -> Dict[str, Any]:
+        return {"height": self.height, "width": self.width, "count": self.count}
+
+    @staticmethod
+    def from_json(value: Dict[str, Any]) -> "Config":
+        try:
+            return Config(value["height"], value["width"], value["count"])
+        except (KeyError, TypeError) as exc:
+            raise RuntimeError(f"invalid Connect config JSON: {exc}") from None
+
+
+class State(ValueObject):
+    __slots__ = ("config", "_grid", "_player", "_winner", "_legal")
+    Action: ClassVar[type]
+
+    def __init__(self, config: Config, grid: np.ndarray, player: int, winner: int, legal: Tuple[int, ...]):
+        object.__setattr__(self, "config", config)
+        g = np.array(grid, dtype=np.int8)
+        g.setflags(write=False)
+        object.__setattr__(self, "_grid", g)
+        object.__setattr__(self, "_player", int(player))
+        object.__setattr__(self, "_winner", int(winner))
+        object.__setattr__(self, "_legal", tuple(legal))
+
+    def __setattr__(self, name, value):
+        raise AttributeError("State is immutable")
+
+    def _key(self):
+        return (self.config._key(), self._grid.tobytes(), self._player, self._winner)
+
+    def __repr__(self):
+        return f"State(player={self._player}, winner={self._winner}, grid={self._grid.tolist()})"
+
+    @property
+    def has_ended(self) -> bool:
+        return self._winner != -1
+
+    @property
+    def player(self) -> int:
+        return self._player
+
+    @property
+    def grid(self) -> np.ndarray:
+        return self._grid.copy()  # the reference hands out a fresh copy per access (tensor.hpp:80-84)
+
+    @property
+    def reward(self) -> np.ndarray:
+        r = np.zeros(2, dtype=np.int8)
+        if self._winner in (0, 1):
+            r[self._winner] = 1
+            r[1 - self._winner] = -1
+        return r
+
+    @property
+    def actions(self) -> List["Action"]:
+        return [Action(self, c) for c in self._legal]
+
+    def action_at(self, column: int) -> "Action":
+        if isinstance(column, bool) or not isinstance(column, (int, np.integer)):
+            raise TypeError("action_at(column: int)")
+        if int(column) not in self._legal:
+            raise RuntimeError(f"illegal action: column {int(column)}")
+        return Action(self, int(column))
+
+    def to_json(self) -> Dict[str, Any]:
+        return {"grid": self._grid.tolist(), "player": self._player, "winner": self._winner}
+
+    @staticmethod
+    def from_json(value: Dict[str, Any], config: Config) -> "State":
+        try:
+            grid = np.array(value["grid"], dtype=np.int8)
+            player, winner = int(value["player"]), int(value["winner"])
+        except (KeyError, TypeError, ValueError) as exc:
+            raise RuntimeError(f"invalid Connect state JSON: {exc}") from None
+        if grid.shape != (config.height, config.width):
+            raise RuntimeError("state grid does not match the config")
+        return State(config, *config._engine().load(grid, player, winner))
+
+
+class Action(ValueObject):
+    __slots__ = ("state", "column")
+
+    def __init__(self, state: State, column: int):
+        object.__setattr__(self, "state", state)
+        object.__setattr__(self, "column", int(column))
+
+    def __setattr__(self, name, value):
+        raise AttributeError("Action is immutable")
+
+    def _key(self):
+        return (self.state._key(), self.column)
+
+    def __repr__(self):
+        return f"Action(column={self.column})"
+
+    def sample_next_state(self) -> State:
+        s = self.state
+        return State(s.config, *s.config._engine().after(s._grid, s._player, s._winner, self.column))
+
+    def to_json(self) -> Dict[str, Any]:
+        return {"column": self.column}
+
+    @staticmethod
+    def from_json(value: Dict[str, Any], state: State) -> "Action":
+        try:
+            return state.action_at(int(value["column"]))
+        except (KeyError, TypeError, ValueError) as exc:
+            raise RuntimeError(f"invalid Connect action JSON: {exc}") from None
+
+
+Config.State = State
+State.Action = Action

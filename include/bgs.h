@@ -1,0 +1,132 @@
+/*
+ * bgs.h -- C ABI of libbgs.so, the MI355X (gfx950) batched board-game rollout engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of jojolebarjos/board-game-simulator-python:
+ *   legal-move enumeration -> uniform action sampling -> sample_next_state transition -> terminal + reward,
+ * for N independent boards per launch.  Every entry point names the reference binding it replaces
+ * (paths relative to the reference tree, src/simulator/game/...).  The reference itself has no batched API,
+ * no RNG and no device; "batch", "seed" and "device" are this library's concepts.
+ *
+ * Conventions
+ *   - plain C types only; no C++ or torch types cross this boundary;
+ *   - every function returns BGS_OK (0) or a negative bgs_status; bgs_last_error() gives a thread-local
+ *     message.  The reference raises C++ exceptions that nanobind turns into RuntimeError
+ *     (textual/connect.py:115-118, textual/bounce.py:119-128): the Python shim maps BGS_ERR_ILLEGAL and
+ *     BGS_ERR_RUNTIME to RuntimeError and BGS_ERR_ARG to TypeError/ValueError;
+ *   - host arrays are C-contiguous, reference layout: grid int8[n][height][width], row 0 = bottom row
+ *     (tensor.hpp:29-34; tests/test_connect.py:24-25); the caller owns every buffer it passes
+ *     (the reference copies both ways too: tensor.hpp:63,80-84);
+ *   - a batch lives on ONE device; all work is enqueued on the batch's HIP stream (default: the null
+ *     stream); functions that fill host memory synchronise that stream before returning;
+ *   - winner codes: -1 running, 0 / 1 that player won, 2 draw.  reward = +1 / -1 per player, 0 / 0 otherwise.
+ *
+ * RNG contract (build-defined): draw(seed, game, ply) = philox4x32-10(key = seed, counter = (game lo, game hi,
+ * ply >> 2, 0))[ply & 3]; sampled action index = (draw * n_actions) >> 32 into the canonical action list
+ * (Connect: legal columns ascending; Bounce: sources by ascending x, targets by ascending (y, x)).
+ * `game` = first_game + index in batch, so results do not depend on sharding or launch geometry.
+ */
+#ifndef BGS_H
+#define BGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bgs_batch bgs_batch; /* opaque: N boards of one game configuration on one device */
+
+typedef enum bgs_status {
+    BGS_OK = 0,
+    BGS_ERR_ARG = -1,         /* bad argument / unsupported geometry */
+    BGS_ERR_ILLEGAL = -2,     /* illegal move (per-board code in status arrays) */
+    BGS_ERR_RUNTIME = -3,     /* HIP runtime error */
+    BGS_ERR_NO_DEVICE = -4    /* no usable GPU: the product path has no CPU fallback */
+} bgs_status;
+
+typedef enum bgs_buffer_id {
+    BGS_BUF_PLANES = 0,  /* uint64 [planes][n]  bit-packed boards, one plane contiguous over the batch */
+    BGS_BUF_STATUS = 1,  /* uint8  [n]          0 running, 1 / 2 player 0 / 1 won, 3 draw */
+    BGS_BUF_PLIES = 2,   /* uint16 [n]          plies played (Bounce only; Connect derives it from the planes) */
+    BGS_BUF_REWARD = 3,  /* int8   [n][2]       reward per player, valid after a board ended (else 0) */
+    BGS_BUF_STEPS = 4,   /* uint64 [1]          env-steps applied since the last reset of the counter */
+    BGS_BUF_STAGING = 5  /* scratch the read/write entry points unpack through */
+} bgs_buffer_id;
+
+/* rollout flags */
+#define BGS_ROLLOUT_DEFAULT 0u
+#define BGS_ROLLOUT_FROM_INITIAL 1u /* ignore the stored boards: every game starts from Config.sample_initial_state() */
+
+/* ---- library ------------------------------------------------------------------------------------ */
+int bgs_version(void);
+const char* bgs_last_error(void);
+int bgs_device_count(int* count);
+
+/* ---- configuration + batch lifetime ------------------------------------------------------------- */
+/* replaces connect::Config(height, width, count) + Config::sample_initial_state (connect.cpp:26,32), N at a time.
+ * arena: optional caller-owned device memory of at least bgs_connect_arena_bytes() bytes (256-byte aligned),
+ * e.g. a torch uint8 tensor; NULL lets the library hipMalloc its own. */
+int bgs_connect_arena_bytes(int height, int width, int count, int64_t n, size_t* bytes);
+int bgs_connect_create(int height, int width, int count, int64_t n, int device, void* arena, size_t arena_bytes,
+                       bgs_batch** out);
+/* replaces bounce::Config(grid) + Config::sample_initial_state (bounce.cpp:26,29); cfg_grid int8[height][width] host */
+int bgs_bounce_arena_bytes(int height, int width, int64_t n, size_t* bytes);
+int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, int device, void* arena,
+                      size_t arena_bytes, bgs_batch** out);
+int bgs_destroy(bgs_batch* b);
+
+int bgs_set_stream(bgs_batch* b, void* hip_stream);      /* hipStream_t; NULL = null stream */
+int bgs_set_first_game(bgs_batch* b, uint64_t first_game); /* global id of board 0 (sharding across GPUs) */
+int bgs_synchronize(bgs_batch* b);
+int bgs_info(const bgs_batch* b, int* game, int* height, int* width, int* count, int64_t* n, int* planes);
+/* device pointer + size of one of the batch's buffers (zero-copy hand-over to torch / RCCL) */
+int bgs_buffer(const bgs_batch* b, int buffer_id, void** device_ptr, size_t* bytes);
+
+/* ---- the hot path --------------------------------------------------------------------------------- */
+/* all boards back to Config::sample_initial_state() (connect.cpp:32, bounce.cpp:29); zeroes the step counter */
+int bgs_reset(bgs_batch* b);
+/* ONE ply on every running board: State::get_actions (connect.cpp:43, bounce.cpp:40) -> uniform choice
+ * (README.md:62 random.choice) -> Action::sample_next_state (connect.cpp:52, bounce.cpp:51) -> has_ended / reward */
+int bgs_step_random(bgs_batch* b, uint64_t seed);
+/* ONE caller-chosen ply: State::get_action_at (connect.cpp:44 / bounce.cpp:42) + Action::sample_next_state.
+ * Connect: actions int32[n] = column; Bounce: int32[n][4] = source x, y, target x, y.  A negative first entry
+ * skips the board.  actions_on_device != 0: `actions` is a device pointer.  status (host int32[n], may be
+ * NULL): BGS_OK or BGS_ERR_ILLEGAL per board; illegal moves leave the board untouched. */
+int bgs_step_actions(bgs_batch* b, const int32_t* actions, int actions_on_device, int32_t* status);
+/* plies until every board ended or holds max_plies plies (README.md:52 `while not state.has_ended`), fused in
+ * one launch with the board in registers */
+int bgs_rollout(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags);
+/* env-steps (transitions applied to running boards) since the last bgs_reset / bgs_reset_steps */
+int bgs_steps(bgs_batch* b, uint64_t* steps);
+int bgs_reset_steps(bgs_batch* b);
+
+/* ---- observation: packed state -> reference layout, into HOST buffers ----------------------------- */
+int bgs_read_grid(bgs_batch* b, int8_t* grid);      /* State::get_grid   (connect.cpp:42, bounce.cpp:39) int8[n][h][w] */
+int bgs_read_player(bgs_batch* b, int8_t* player);  /* State::get_player (connect.cpp:40, bounce.cpp:37) int8[n] */
+int bgs_read_ended(bgs_batch* b, uint8_t* ended);   /* State::has_ended  (connect.cpp:39, bounce.cpp:36) uint8[n] */
+int bgs_read_winner(bgs_batch* b, int8_t* winner);  /* JSON key "winner" (tests/test_connect.py:137) int8[n] */
+int bgs_read_reward(bgs_batch* b, int8_t* reward);  /* State::get_reward (connect.cpp:41, bounce.cpp:38) int8[n][2] */
+int bgs_read_plies(bgs_batch* b, int32_t* plies);   /* plies played, int32[n] */
+/* Connect: State::get_actions as a mask, uint8[n][width] (connect.cpp:43) */
+int bgs_read_legal(bgs_batch* b, uint8_t* legal);
+/* number of legal actions of the side to move, int32[n] (len(state.actions)) */
+int bgs_read_action_count(bgs_batch* b, int32_t* count);
+/* Bounce: State::get_actions_at for every column of the active row (bounce.cpp:41): uint64[n][width + 1]; entry
+ * i < width has bit (y*width + x) set for every legal target of the piece in column i of the active row (0 if
+ * none); entry [width] is the active row's y (all ones when the board has ended or nothing can move) */
+int bgs_bounce_read_targets(bgs_batch* b, uint64_t* targets);
+/* the same observations into DEVICE memory (no synchronisation): what = 'g' grid, 'l' legal, 'r' reward */
+int bgs_export_device(bgs_batch* b, int what, void* device_dst);
+
+/* ---- loading boards (State::from_json, connect.cpp:46 / bounce.cpp:45; policy-driven stepping) ---- */
+/* grid int8[n][h][w]; player int8[n] (Connect: may be NULL, derived from the stone counts); winner int8[n]
+ * (NULL = all running; Connect re-derives wins and draws from the grid when NULL); plies int32[n] (Bounce; NULL =
+ * player parity).  status (host int32[n], may be NULL) reports malformed boards, which are left untouched. */
+int bgs_write_state(bgs_batch* b, const int8_t* grid, const int8_t* player, const int8_t* winner,
+                    const int32_t* plies, int32_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,117 @@
+"""The reference's Bounce tests (tests/test_bounce.py:92-410) replayed through the drop-in
+``simulator.game.bounce`` module, i.e. through libbgs.so and the HIP kernels.  Positions come from
+tests/golden/reference_bounce.json (transcribed data): 16 positions with exhaustive target sets."""
+
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    with open(os.path.join(golden_dir, "reference_bounce.json")) as fh:
+        return json.load(fh)
+
+
+def assert_state(pos, state=None):
+    from simulator.game.bounce import Config
+
+    grid = np.array(pos["grid"], dtype=np.int8)
+    if state is None:
+        assert pos["player"] == 0
+        state = Config(grid).sample_initial_state()
+    np.testing.assert_array_equal(grid, state.grid)
+    assert pos["player"] == state.player
+    selected = None
+    if pos["source"] is not None:
+        actions = {tuple(a.target): a for a in state.actions_at(np.array(pos["source"]))}
+        assert {tuple(t) for t in pos["targets"]} == set(actions)  # exhaustive
+        if pos["chosen"] is not None:
+            selected = actions[tuple(pos["chosen"])]
+    return state, selected
+
+
+def test_reference_games(fx):
+    names = []
+    for test in fx["tests"]:
+        state = None
+        for pos in test["positions"]:
+            state, action = assert_state(pos, state)
+            assert tuple(action.source) == tuple(pos["source"])
+            state = action.sample_next_state()
+        assert state.has_ended == test["final"]["has_ended"], test["name"]
+        assert len(state.actions) == test["final"]["n_actions"]
+        assert state.reward.tolist() == test["final"]["reward"], test["name"]
+        names.append(test["name"])
+    assert names == ["test_small", "test_normal", "test_last_row", "test_larger_values", "test_block_victory", "test_draw"]
+
+
+def test_json(fx):
+    from simulator.game.bounce import Action, Config, State
+
+    j = fx["json"]
+    state, action = assert_state(j["position"])
+    config = state.config
+    assert config.to_json() == j["config"]
+    assert Config.from_json(config.to_json()) == config
+    assert state.to_json() == j["state"]
+    assert State.from_json(state.to_json(), config) == state
+    assert action.to_json() == j["action"]
+    assert Action.from_json(action.to_json(), state) == action
+
+
+def test_surface(fx):
+    from simulator.game.bounce import Action, Config, State
+
+    grid = np.array(fx["tests"][1]["positions"][0]["grid"])  # int64, as textual/bounce.py:66-79 passes it
+    config = Config(grid)
+    assert Config.num_players == 2 and Config.State is State and State.Action is Action
+    assert config.grid.dtype == np.int8 and config.grid.shape == (9, 6)
+    state = config.sample_initial_state()
+    assert state.config is config and state.grid.dtype == np.int8
+    assert state.reward.tolist() == [0, 0]
+    a = state.action_at(np.array([0, 1]), np.array([0, 2]))
+    assert a.source.tolist() == [0, 1] and a.target.tolist() == [0, 2] and a.state is state
+    assert state.actions_at(np.array([0, 7])) == []      # not the active row
+    assert state.actions_at(np.array([3, 4])) == []      # empty cell
+    with pytest.raises(RuntimeError):
+        state.action_at(np.array([0, 1]), np.array([0, 3]))
+    with pytest.raises(RuntimeError):
+        state.actions_at(np.array([6, 1]))               # outside the board
+    with pytest.raises(TypeError):
+        Config(np.zeros(5, dtype=np.int8))               # wrong rank (tensor.hpp:45-59)
+    # canonical order of state.actions: sources by x, targets by (y, x); no duplicates
+    listed = [(tuple(x.source), tuple(x.target)) for x in state.actions]
+    assert listed == sorted(set(listed), key=lambda st: (st[0][0], st[1][1], st[1][0]))
+    nxt = a.sample_next_state()
+    assert state.grid[1, 0] == 1 and nxt.grid[1, 0] == 0 and nxt.grid[2, 0] == 1 and nxt.player == 1
+    assert nxt == state.action_at(np.array([0, 1]), np.array([0, 2])).sample_next_state()
+    assert hash(nxt) == hash(a.sample_next_state()) and nxt != state
+
+
+def test_random_playthrough_matches_oracle(fx):
+    from oracle import oracle
+    from simulator.game.bounce import Config
+
+    grid = np.array(fx["tests"][1]["positions"][0]["grid"], dtype=np.int8)
+    rnd = random.Random(3)
+    for _ in range(2):
+        state = Config(grid).sample_initial_state()
+        orc = oracle.BounceOracle(grid, 1)
+        plies = 0
+        while not state.has_ended and plies < 300:
+            assert state.player == orc.player[0]
+            np.testing.assert_array_equal(state.grid, orc.grid[0])
+            listed = [(tuple(a.source), tuple(a.target)) for a in state.actions]
+            assert listed == orc.actions(0)
+            action = rnd.choice(state.actions)
+            state = action.sample_next_state()
+            orc.step_actions([[*action.source, *action.target]])
+            plies += 1
+        assert bool(orc.ended[0]) == state.has_ended
+        np.testing.assert_array_equal(state.reward, orc.reward[0])

@@ -1,0 +1,124 @@
+"""The reference's Connect tests (tests/test_connect.py:68-145) replayed through the drop-in
+``simulator.game.connect`` module, i.e. through libbgs.so and the HIP kernels.  Positions come from
+tests/golden/reference_connect.json (transcribed data)."""
+
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    with open(os.path.join(golden_dir, "reference_connect.json")) as fh:
+        return json.load(fh)
+
+
+def assert_state(pos, state):
+    np.testing.assert_array_equal(np.array(pos["grid"]), state.grid)
+    if state.has_ended:
+        assert pos["column"] is None
+    else:
+        assert pos["player"] == state.player
+    return state.action_at(pos["column"]) if pos["column"] is not None else None
+
+
+def test_small(fx):
+    from simulator.game.connect import Config
+
+    game = fx["games"][0]
+    config = Config(*game["config"])
+    state = config.sample_initial_state()
+    for pos in game["positions"]:
+        action = assert_state(pos, state)
+        if action is not None:
+            assert action.state is state
+            state = action.sample_next_state()
+    assert state.has_ended
+    np.testing.assert_array_equal(state.reward, game["reward"])
+    assert state.actions == []
+    with pytest.raises(RuntimeError):
+        state.action_at(0)
+
+
+def test_json(fx):
+    from simulator.game.connect import Action, Config, State
+
+    j = fx["json"]
+    config = Config(*j["config_args"])
+    assert config.to_json() == j["config"]
+    assert Config.from_json(config.to_json()) == config
+
+    state = config.sample_initial_state()
+    for col in j["state_after_columns"]:
+        state = state.action_at(col).sample_next_state()
+    assert state.to_json() == j["state"]
+    assert State.from_json(state.to_json(), config) == state
+
+    action = state.action_at(j["action_column"])
+    assert action.to_json() == j["action"]
+    assert Action.from_json(action.to_json(), state) == action
+
+
+def test_surface_and_value_semantics():
+    from simulator.game import ConfigLike, StateLike, ActionLike
+    from simulator.game.connect import Action, Config, State
+
+    config = Config(6, 7, 4)
+    assert Config.num_players == 2 and config.num_players == 2
+    assert (config.height, config.width, config.count) == (6, 7, 4)
+    assert Config.State is State and State.Action is Action
+    state = config.sample_initial_state()
+    assert state.config is config and state.player == 0 and not state.has_ended
+    assert state.grid.shape == (6, 7) and (state.grid == -1).all()
+    assert state.reward.tolist() == [0, 0]
+    assert [a.column for a in state.actions] == list(range(7))
+    assert isinstance(config, ConfigLike) and isinstance(state, StateLike) and isinstance(state.actions[0], ActionLike)
+    # immutability: the old state is untouched by a transition (README.md:67)
+    nxt = state.action_at(3).sample_next_state()
+    assert (state.grid == -1).all() and nxt.grid[0, 3] == 0 and nxt.player == 1
+    # equality, ordering and hashing are by value (helper.hpp:10-25)
+    again = config.sample_initial_state().action_at(3).sample_next_state()
+    assert again == nxt and hash(again) == hash(nxt) and again is not nxt
+    assert nxt != state and (nxt < state) != (state < nxt)
+    assert len({nxt, again, state}) == 2
+    assert state.action_at(2) == state.action_at(2) and state.action_at(2) != state.action_at(3)
+    assert Config(6, 7, 4) == config and Config(6, 7, 5) != config and Config(6, 7, 4) <= config
+    # illegal picks raise RuntimeError, as the UI expects (textual/connect.py:115-118)
+    with pytest.raises(RuntimeError):
+        state.action_at(7)
+    with pytest.raises(RuntimeError):
+        state.action_at(-1)
+    full = state
+    for _ in range(6):
+        full = full.action_at(0).sample_next_state()
+    assert [a.column for a in full.actions] == [1, 2, 3, 4, 5, 6]
+    with pytest.raises(RuntimeError):
+        full.action_at(0)
+
+
+def test_readme_loop_matches_oracle():
+    """README.md:45-72 verbatim loop with random.choice, every state checked against the CPU oracle."""
+    from oracle import oracle
+    from simulator.game.connect import Config
+
+    rnd = random.Random(7)
+    for _ in range(3):
+        config = Config(6, 7, 4)
+        state = config.sample_initial_state()
+        orc = oracle.ConnectOracle(6, 7, 4, 1)
+        while not state.has_ended:
+            assert state.player == orc.player[0]
+            np.testing.assert_array_equal(state.grid, orc.grid[0])
+            actions = state.actions
+            assert [a.column for a in actions] == np.flatnonzero(orc.legal()[0]).tolist()
+            action = rnd.choice(actions)
+            state = action.sample_next_state()
+            orc.step_actions([action.column])
+        assert orc.ended[0]
+        np.testing.assert_array_equal(state.grid, orc.grid[0])
+        np.testing.assert_array_equal(state.reward, orc.reward[0])

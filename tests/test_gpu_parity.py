@@ -1,0 +1,373 @@
+"""HIP path (through the C ABI) against the CPU oracle on the same seeds -- bit-exact, integer work.
+
+Everything here needs a real MI355X: `pytest -m gpu`.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x0123456789ABCDEF
+
+DEFAULT_BOUNCE = np.zeros((9, 6), dtype=np.int8)
+DEFAULT_BOUNCE[1] = DEFAULT_BOUNCE[7] = [1, 2, 3, 3, 2, 1]
+
+
+@pytest.fixture(scope="module")
+def batch_mod():
+    from simulator import batch
+
+    return batch
+
+
+def assert_same(dev, orc, what=""):
+    np.testing.assert_array_equal(dev.grid, orc.grid, err_msg=f"grid {what}")
+    np.testing.assert_array_equal(dev.winner, orc.winner, err_msg=f"winner {what}")
+    np.testing.assert_array_equal(dev.has_ended, orc.ended, err_msg=f"ended {what}")
+    np.testing.assert_array_equal(dev.plies, orc.plies, err_msg=f"plies {what}")
+    np.testing.assert_array_equal(dev.player, orc.player, err_msg=f"player {what}")
+    np.testing.assert_array_equal(dev.reward, orc.reward, err_msg=f"reward {what}")
+
+
+# ------------------------------------------------------------------------------------------------ Connect
+
+CONNECT_GEOMETRIES = [
+    (6, 7, 4),     # static instantiation, 1 word
+    (12, 13, 5),   # static instantiation, 3 words
+    (2, 3, 2),     # the reference's own test board
+    (4, 5, 3),
+    (1, 6, 2),     # single row
+    (5, 1, 3),     # single column
+    (6, 7, 1),     # any stone wins
+    (8, 9, 4),     # 2 words, run-time geometry
+    (15, 12, 5),   # 192 bits, 3 words, run-time geometry
+    (3, 16, 4),    # widest supported
+    (6, 7, 9),     # count larger than the board: draws only
+]
+
+
+@pytest.mark.parametrize("h,w,k", CONNECT_GEOMETRIES)
+def test_connect_step_random_lockstep(batch_mod, h, w, k):
+    n = 1500
+    dev = batch_mod.ConnectBatch(h, w, k, n)
+    orc = oracle.ConnectOracle(h, w, k, n)
+    dev.set_first_game(77)
+    assert_same(dev, orc, "after reset")
+    np.testing.assert_array_equal(dev.legal, orc.legal())
+    total = 0
+    for ply in range(h * w + 1):
+        total += orc.step_random(SEED, first_game=77)
+        dev.step_random(SEED)
+        assert_same(dev, orc, f"ply {ply}")
+        if ply % 5 == 0:
+            np.testing.assert_array_equal(dev.legal, orc.legal())
+            np.testing.assert_array_equal(dev.action_count, orc.legal().sum(axis=1))
+        assert dev.steps == total
+    assert orc.ended.all()
+
+
+@pytest.mark.parametrize("h,w,k", CONNECT_GEOMETRIES)
+@pytest.mark.parametrize("from_initial", [False, True])
+def test_connect_rollout(batch_mod, h, w, k, from_initial):
+    n = 20000 if h * w <= 64 else 6000
+    dev = batch_mod.ConnectBatch(h, w, k, n)
+    orc = oracle.ConnectOracle(h, w, k, n)
+    dev.set_first_game(1 << 33)
+    if from_initial:
+        dev.step_random(SEED)  # dirty the boards: FROM_INITIAL must ignore them
+        dev.reset_steps()
+    dev.rollout(SEED, from_initial=from_initial)
+    total = orc.rollout(SEED, first_game=1 << 33)
+    assert_same(dev, orc)
+    assert dev.steps == total == int(orc.plies.sum())
+    assert dev.has_ended.all()
+    np.testing.assert_array_equal(dev.legal, np.zeros((n, w), dtype=np.uint8))
+
+
+def test_connect_rollout_from_mid_game_and_max_plies(batch_mod):
+    n = 9000
+    dev = batch_mod.ConnectBatch(6, 7, 4, n)
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    for _ in range(9):
+        dev.step_random(SEED ^ 5)
+        orc.step_random(SEED ^ 5)
+    dev.rollout(SEED ^ 5, max_plies=17)
+    orc.rollout(SEED ^ 5, max_plies=17)
+    assert_same(dev, orc, "capped at 17 plies")
+    assert orc.plies.max() == 17 and not orc.ended.all()
+    dev.rollout(SEED ^ 5, max_plies=0)
+    assert_same(dev, orc, "max_plies=0 is a no-op")
+    dev.rollout(SEED ^ 5)
+    orc.rollout(SEED ^ 5)
+    assert_same(dev, orc, "finished")
+
+
+def test_connect_step_actions_legal_illegal_skip(batch_mod):
+    n = 4096
+    rng = np.random.default_rng(3)
+    dev = batch_mod.ConnectBatch(6, 7, 4, n)
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    for _ in range(50):
+        cols = rng.integers(-2, 9, size=n).astype(np.int32)  # negatives skip, 7 and 8 are out of range
+        st_dev = dev.step_actions(cols)
+        st_orc = orc.step_actions(cols)
+        np.testing.assert_array_equal(st_dev, st_orc)
+        assert_same(dev, orc)
+    assert (st_orc == -2).any() and orc.ended.any()
+    assert dev.steps == int(orc.plies.sum())
+
+
+@pytest.mark.parametrize("h,w,k", [(6, 7, 4), (12, 13, 5), (8, 9, 4)])
+def test_connect_write_state_roundtrip(batch_mod, h, w, k):
+    n = 3000
+    orc = oracle.ConnectOracle(h, w, k, n)
+    for i in range(h * w // 2):
+        orc.step_random(SEED + 1)
+    dev = batch_mod.ConnectBatch(h, w, k, n)
+    # winner derived on the device from the grid alone
+    status = dev.write_state(orc.grid)
+    assert (status == 0).all()
+    assert_same(dev, orc, "loaded, winner derived")
+    # winner and player given explicitly
+    dev.reset()
+    assert (dev.write_state(orc.grid, orc.player, orc.winner) == 0).all()
+    assert_same(dev, orc, "loaded with winner")
+    # continue the games from the loaded boards
+    dev.rollout(SEED + 2)
+    orc.rollout(SEED + 2)
+    assert_same(dev, orc, "continued")
+
+
+def test_connect_write_state_rejects_malformed(batch_mod):
+    dev = batch_mod.ConnectBatch(6, 7, 4, 4)
+    before = dev.grid
+    g = np.full((4, 6, 7), -1, dtype=np.int8)
+    g[0, 1, 0] = 0              # floating stone
+    g[1, 0, 0] = 1              # player 1 moved first
+    g[2, 0, 0] = 3              # bad cell code
+    g[3, 0, 0] = 0              # fine
+    status = dev.write_state(g)
+    assert status.tolist() == [-1, -1, -1, 0]
+    got = dev.grid
+    np.testing.assert_array_equal(got[:3], before[:3])
+    np.testing.assert_array_equal(got[3], g[3])
+
+
+def test_connect_sharding_is_invisible(batch_mod):
+    n, shards = 8192, 4
+    whole = batch_mod.ConnectBatch(6, 7, 4, n)
+    whole.rollout(SEED, from_initial=True)
+    grid, reward = whole.grid, whole.reward
+    per = n // shards
+    for r in range(shards):
+        part = batch_mod.ConnectBatch(6, 7, 4, per)
+        part.set_first_game(r * per)
+        part.rollout(SEED, from_initial=True)
+        np.testing.assert_array_equal(part.grid, grid[r * per : (r + 1) * per])
+        np.testing.assert_array_equal(part.reward, reward[r * per : (r + 1) * per])
+
+
+def test_connect_full_size_batch(batch_mod):
+    """BASELINE config 2: Connect4(6,7,4), batch 2^20 -- full comparison with the oracle plus size-free properties."""
+    n = 1 << 20
+    dev = batch_mod.ConnectBatch(6, 7, 4, n)
+    dev.rollout(SEED, from_initial=True)
+    steps = dev.steps
+    grid, reward, winner, plies = dev.grid, dev.reward, dev.winner, dev.plies
+    # properties that hold at any size
+    assert dev.has_ended.all()
+    assert steps == int(plies.sum())
+    assert (reward.sum(axis=1) == 0).all()
+    assert ((winner == 2) == (reward == 0).all(axis=1)).all()
+    stones = (grid >= 0).sum(axis=(1, 2))
+    np.testing.assert_array_equal(stones, plies)
+    assert (((grid == 0).sum(axis=(1, 2)) - (grid == 1).sum(axis=(1, 2))) == (plies & 1)).all()
+    assert plies.min() >= 7 and plies.max() <= 42
+    # determinism + idempotence: same seed twice, and a rollout of finished boards changes nothing
+    dev.rollout(SEED)
+    np.testing.assert_array_equal(dev.grid, grid)
+    assert dev.steps == steps
+    dev.reset()
+    dev.rollout(SEED)
+    np.testing.assert_array_equal(dev.grid, grid)
+    np.testing.assert_array_equal(dev.reward, reward)
+    # and the oracle, all 2^20 games
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    total = orc.rollout(SEED)
+    assert total == steps
+    np.testing.assert_array_equal(grid, orc.grid)
+    np.testing.assert_array_equal(reward, orc.reward)
+    np.testing.assert_array_equal(plies, orc.plies)
+
+
+def test_connect_large_board_full_size(batch_mod):
+    """BASELINE config 3: Connect4(12,13,5), batch 2^18."""
+    n = 1 << 18
+    dev = batch_mod.ConnectBatch(12, 13, 5, n)
+    dev.rollout(SEED, from_initial=True)
+    orc = oracle.ConnectOracle(12, 13, 5, n)
+    total = orc.rollout(SEED)
+    assert dev.steps == total
+    np.testing.assert_array_equal(dev.grid, orc.grid)
+    np.testing.assert_array_equal(dev.reward, orc.reward)
+    np.testing.assert_array_equal(dev.plies, orc.plies)
+
+
+def test_unsupported_geometry_is_an_error(batch_mod):
+    with pytest.raises(ValueError):
+        batch_mod.ConnectBatch(16, 7, 4, 8)
+    with pytest.raises(ValueError):
+        batch_mod.ConnectBatch(15, 13, 4, 8)  # 208 bits
+    with pytest.raises(ValueError):
+        batch_mod.BounceBatch(np.zeros((9, 8), dtype=np.int8), 8)  # 72 cells
+
+
+# ------------------------------------------------------------------------------------------------ Bounce
+
+BOUNCE_GRIDS = {
+    "default": DEFAULT_BOUNCE,
+    "small": np.array([[0, 0, 0], [1, 2, 3], [0, 0, 0], [0, 0, 0], [1, 2, 3], [0, 0, 0]], dtype=np.int8),
+    "big_values": np.array(
+        [[0] * 6, [0, 0, 0, 0, 7, 0], [0] * 6, [0, 5, 0, 0, 0, 0], [0] * 6, [0] * 6, [0] * 6, [1, 0, 0, 15, 0, 0], [0] * 6],
+        dtype=np.int8,
+    ),
+    "crowded": np.array(
+        [[0] * 8, [1, 2, 3, 1, 2, 3, 1, 2], [3, 2, 1, 3, 2, 1, 3, 2], [0] * 8, [2, 2, 2, 2, 2, 2, 2, 2], [1, 1, 1, 3, 3, 1, 1, 1],
+         [1, 2, 3, 4, 4, 3, 2, 1], [0] * 8],
+        dtype=np.int8,
+    ),
+    "narrow": np.array([[0], [1], [0], [2], [0]], dtype=np.int8),
+    "blocked_start": np.array([[0, 0], [2, 2], [2, 2], [0, 0]], dtype=np.int8),
+}
+
+
+def assert_bounce_actions(dev, orc, idx):
+    masks = dev.targets
+    width = dev.width
+    for i in idx:
+        want = orc.actions(int(i))
+        got = []
+        row = int(masks[i, width])
+        for x in range(width):
+            m = int(masks[i, x])
+            got += [((x, row), (c % width, c // width)) for c in range(64) if (m >> c) & 1]
+        assert got == want, f"board {i}"
+
+
+@pytest.mark.parametrize("name", list(BOUNCE_GRIDS))
+def test_bounce_step_random_lockstep(batch_mod, name):
+    grid = BOUNCE_GRIDS[name]
+    n = 700
+    dev = batch_mod.BounceBatch(grid, n)
+    orc = oracle.BounceOracle(grid, n)
+    dev.set_first_game(12345)
+    assert_same(dev, orc, "after reset")
+    total = 0
+    for ply in range(60):
+        np.testing.assert_array_equal(dev.action_count, orc.count_actions(), err_msg=f"action count, ply {ply}")
+        if ply % 7 == 0:
+            assert_bounce_actions(dev, orc, range(0, n, 97))
+        total += orc.step_random(SEED, first_game=12345)
+        dev.step_random(SEED)
+        assert_same(dev, orc, f"ply {ply}")
+        assert dev.steps == total
+        if orc.ended.all():
+            break
+
+
+@pytest.mark.parametrize("name", list(BOUNCE_GRIDS))
+@pytest.mark.parametrize("from_initial", [False, True])
+def test_bounce_rollout(batch_mod, name, from_initial):
+    grid = BOUNCE_GRIDS[name]
+    n = 6000
+    dev = batch_mod.BounceBatch(grid, n)
+    orc = oracle.BounceOracle(grid, n)
+    dev.set_first_game(999)
+    if from_initial:
+        dev.step_random(SEED)
+        dev.reset_steps()
+    dev.rollout(SEED, max_plies=4096, from_initial=from_initial)
+    total = orc.rollout(SEED, first_game=999, max_plies=4096)
+    assert_same(dev, orc)
+    assert dev.steps == total == int(orc.plies.sum())
+
+
+def test_bounce_rollout_max_plies_and_resume(batch_mod):
+    n = 4000
+    dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+    orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+    dev.rollout(SEED, max_plies=11)
+    orc.rollout(SEED, max_plies=11)
+    assert_same(dev, orc, "capped")
+    assert not orc.ended.all()
+    dev.rollout(SEED, max_plies=4096)
+    orc.rollout(SEED, max_plies=4096)
+    assert_same(dev, orc, "resumed")
+
+
+def test_bounce_step_actions(batch_mod):
+    n = 600
+    rng = np.random.default_rng(11)
+    dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+    orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+    for _ in range(25):
+        moves = np.full((n, 4), -1, dtype=np.int32)
+        for i in range(n):
+            acts = orc.actions(i)
+            r = rng.random()
+            if acts and r < 0.7:
+                (sx, sy), (tx, ty) = acts[rng.integers(len(acts))]
+                moves[i] = [sx, sy, tx, ty]
+            elif r < 0.85:
+                moves[i] = rng.integers(0, 9, size=4)  # mostly illegal, sometimes out of range
+        st_dev = dev.step_actions(moves)
+        st_orc = orc.step_actions(moves)
+        np.testing.assert_array_equal(st_dev, st_orc)
+        assert_same(dev, orc)
+    assert (st_orc == -2).any()
+
+
+def test_bounce_write_state_roundtrip(batch_mod):
+    n = 2000
+    orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+    for _ in range(9):
+        orc.step_random(SEED + 9)
+    dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+    assert (dev.write_state(orc.grid, orc.player, orc.winner, orc.plies) == 0).all()
+    assert_same(dev, orc, "loaded")
+    dev.rollout(SEED + 9, max_plies=4096)
+    orc.rollout(SEED + 9, max_plies=4096)
+    assert_same(dev, orc, "continued")
+    # malformed boards are refused and left untouched
+    bad = orc.grid.copy()
+    bad[0, 0, 0] = 3        # piece in a goal row of a running board
+    bad[1, 4, 2] = -1       # negative value
+    winner = orc.winner.copy()
+    winner[:2] = -1
+    status = dev.write_state(bad, orc.player, winner, orc.plies)
+    assert status[0] == -1 and status[1] == -1 and (status[2:] == 0).all()
+
+
+def test_bounce_full_size_batch(batch_mod):
+    """BASELINE config 4: Bounce default grid, batch 2^18, max_plies 4096."""
+    n = 1 << 18
+    dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+    dev.rollout(SEED, max_plies=4096, from_initial=True)
+    steps = dev.steps
+    reward, winner, plies, grid = dev.reward, dev.winner, dev.plies, dev.grid
+    assert steps == int(plies.sum())
+    assert (reward.sum(axis=1) == 0).all()
+    assert (grid.sum(axis=(1, 2)) == int(DEFAULT_BOUNCE.sum())).all()  # pieces are conserved
+    assert ((grid > 0).sum(axis=(1, 2)) == 12).all()
+    in_goal = (grid[:, 0] > 0).any(axis=1) | (grid[:, -1] > 0).any(axis=1)
+    assert (in_goal <= (winner >= 0)).all()
+    assert (dev.action_count[winner >= 0] == 0).all()
+    orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+    total = orc.rollout(SEED, max_plies=4096)
+    assert total == steps
+    np.testing.assert_array_equal(grid, orc.grid)
+    np.testing.assert_array_equal(reward, orc.reward)
+    np.testing.assert_array_equal(plies, orc.plies)

@@ -8,7 +8,9 @@ the thin Python classes in connect.py / bounce.py / ../batch.py.
 from __future__ import annotations
 
 import ctypes
+import importlib.util
 import os
+import sys
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIB_PATH = os.environ.get("BGS_LIBRARY", os.path.join(_PKG_DIR, "libbgs.so"))
@@ -85,10 +87,29 @@ class BgsError(RuntimeError):
         self.code = code
 
 
+def _one_hip_runtime_per_process() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (SONAME libamdhip64.so.7, the name
+    libbgs.so links against).  Two HSA runtimes in one process cannot both open the GPU, so whichever of torch and
+    libbgs loads first must decide for both: if torch is installed but not imported yet, map ITS runtime now (no
+    torch import needed); libbgs.so and a later `import torch` then bind to that same copy."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib() -> ctypes.CDLL:
     """Load libbgs.so; fail loudly when it is absent (build it with `python __graft_entry__.py`)."""
     global _lib
     if _lib is None:
+        _one_hip_runtime_per_process()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "

@@ -39,6 +39,7 @@ HEIGHT, WIDTH, COUNT = 6, 7, 4
 BATCH_PER_GPU = 1 << 20
 BYTES_PER_STEP = 32          # 2 planes x 8 B read + 2 planes x 8 B written per env-step
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+EVENT_STRIDE = 4             # HIP-event pairs bracket every 4th rollout launch of the timed region
 
 
 def cpu_baseline(torch, last_seed, device_reward_head):
@@ -48,8 +49,12 @@ def cpu_baseline(torch, last_seed, device_reward_head):
 
     from oracle import oracle
 
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, int(os.environ.get("BGS_CPU_THREADS", "16")))  # a 1-GPU box's CPU share is 16 cores
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     n = 1 << 20
     reps = 4
     orc = oracle.ConnectOracle(HEIGHT, WIDTH, COUNT, n)
@@ -81,6 +86,9 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="boards per GPU (default 2^20)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight per GPU: step i runs on batch i %% D / HIP stream i %% D, so the drain of one "
+                    "rollout (and, with N > 1, its reward gather) overlaps the start of the next (default 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,10 +115,17 @@ def main() -> int:
     from simulator.batch import ConnectBatch
 
     n = args.batch
-    batch = ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=local_rank, use_torch=True)
-    batch.set_first_game(rank * n)
-    reward = batch.reward_tensor()
-    gathered = torch.empty((world * n, 2), dtype=torch.int8, device=reward.device) if world > 1 else None
+    depth = max(1, args.inflight)
+    os.environ.setdefault("BGS_ROLLOUT_WPS", "2")  # waves per SIMD per launch; `depth` launches share the chip
+    streams = [torch.cuda.Stream(device=local_rank) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
+    batches, gathered = [], []
+    for s in streams:
+        with torch.cuda.stream(s):
+            b = ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=local_rank, use_torch=True)  # binds to stream s
+            b.set_first_game(rank * n)
+            batches.append(b)
+            gathered.append(torch.empty((world * n, 2), dtype=torch.int8, device=f"cuda:{local_rank}") if world > 1 else None)
+    device = batches[0].reward_tensor().device
 
     def barrier():
         torch.cuda.synchronize()
@@ -119,33 +134,40 @@ def main() -> int:
             torch.cuda.synchronize()
 
     def one_step(i, ev=None):
-        if ev is not None:
-            ev[0].record()
-        batch.rollout(SEED + i, from_initial=True)
-        if ev is not None:
-            ev[1].record()
-        if dist is not None:
-            dist.all_gather_into_tensor(gathered, reward)  # the path's only exchange: rewards to one array
+        k = i % depth
+        with torch.cuda.stream(streams[k]):
+            if ev is not None:
+                ev[0].record(streams[k])
+            batches[k].rollout(SEED + i, from_initial=True)
+            if ev is not None:
+                ev[1].record(streams[k])
+            if dist is not None:
+                # the path's only exchange: every rank's int8 rewards into one array (RCCL over xGMI)
+                dist.all_gather_into_tensor(gathered[k], batches[k].reward_tensor())
 
     for i in range(args.warmup):
         one_step(i)
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    batch.reset_steps()
+    for b in batches:
+        b.reset_steps()
 
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_step(args.warmup + i, events[i])
+        # event pairs around every EVENT_STRIDE-th launch: each record is a marker packet on the stream, and
+        # bracketing every launch would cost more than it measures
+        one_step(args.warmup + i, events[i] if i % EVENT_STRIDE == 0 else None)
     barrier()
     elapsed = time.perf_counter() - t0
 
-    steps_local = batch.steps
-    kernel_ms = sum(s.elapsed_time(e) for s, e in events) / max(args.steps, 1)
+    steps_local = sum(b.steps for b in batches)
+    timed = [events[i] for i in range(args.steps) if i % EVENT_STRIDE == 0]
+    kernel_ms = sum(s.elapsed_time(e) for s, e in timed) / max(len(timed), 1)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=reward.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor([steps_local], dtype=torch.int64, device=reward.device)
+        s = torch.tensor([steps_local], dtype=torch.int64, device=device)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         steps_total = int(s.item())
     else:
@@ -180,6 +202,8 @@ def main() -> int:
                 "global_batch": n * world,
                 "env_steps_per_step": steps_total / max(args.steps, 1),
                 "sharding": f"game ids split over {world} rank(s); RCCL all-gather of int8 rewards per step" if world > 1 else "single GPU",
+                "inflight_batches": depth,
+                "waves_per_simd_per_launch": int(os.environ["BGS_ROLLOUT_WPS"]),
             },
             "roofline": {
                 "bound": "hbm",
@@ -191,13 +215,17 @@ def main() -> int:
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": steps_per_launch * BYTES_PER_STEP,
                 "kernel_ms_per_launch": kernel_ms,
+                "launches_in_flight": depth,
                 "note": "algorithmic = 32 B per env-step (SURVEY 8d); the fused rollout keeps boards in registers, "
-                "so real HBM traffic (traffic) is far smaller and the kernel is VALU-issue bound",
+                "so real HBM traffic (traffic) is far smaller and the kernel is VALU-issue bound; with "
+                "launches_in_flight > 1 a launch shares the chip with its neighbours, so its own duration is longer "
+                "than ms_per_step",
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            head = batch.reward[:65536]
-            out["cpu_baseline"] = cpu_baseline(torch, SEED + args.warmup + args.steps - 1, head)
+            last = args.warmup + args.steps - 1
+            head = batches[last % depth].reward[:65536]
+            out["cpu_baseline"] = cpu_baseline(torch, SEED + last, head)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

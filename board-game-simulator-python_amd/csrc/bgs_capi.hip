@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -167,6 +168,19 @@ int to_device(const bgs_batch* b, T* dev, const T* host, size_t count) {
     return BGS_OK;
 }
 
+// device facts the launch geometry of the fused rollout depends on
+int device_facts(bgs_batch* b) {
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
+    b->num_cus = cus > 0 ? cus : 256;
+    b->rollout_wps = 4;  // 4 waves per SIMD: 4 games per lane at 2^20 boards (lane refill needs several)
+    if (const char* env = getenv("BGS_ROLLOUT_WPS")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 8) b->rollout_wps = v;
+    }
+    return BGS_OK;
+}
+
 int reset_impl(bgs_batch* b) {
     HIP_TRY(hipMemsetAsync(b->d_steps, 0, sizeof(unsigned long long), b->stream));
     if (b->game == BGS_GAME_CONNECT) bgs::connect_reset(b);
@@ -225,7 +239,8 @@ int bgs_connect_create(int height, int width, int count, int64_t n, int device, 
     b->n = n;
     b->cg = cg;
     b->planes = 2 * cg.nw;
-    rc = carve(b, arena, arena_bytes, layout_for(b->planes, n, height, width));
+    rc = device_facts(b);
+    if (rc == BGS_OK) rc = carve(b, arena, arena_bytes, layout_for(b->planes, n, height, width));
     if (rc == BGS_OK) rc = reset_impl(b);
     if (rc != BGS_OK) {
         if (b->owns_arena && b->arena) (void)hipFree(b->arena);
@@ -255,7 +270,8 @@ int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, 
     b->n = n;
     b->bg = bg;
     b->planes = 4;
-    rc = carve(b, arena, arena_bytes, layout_for(4, n, height, width));
+    rc = device_facts(b);
+    if (rc == BGS_OK) rc = carve(b, arena, arena_bytes, layout_for(4, n, height, width));
     if (rc == BGS_OK) {
         // a start position whose first player cannot move is already over: let the device settle board 0 once
         // and remember the verdict (the kernels own every rule; the host evaluates none)

@@ -42,6 +42,8 @@ struct bgs_batch {
     ConnectGeom cg;
     BounceGeom bg;
     int planes;              // uint64 planes per board
+    int num_cus;             // compute units of the device
+    int rollout_wps;         // waves per SIMD the fused rollout is sized for
     // device buffers (inside the arena)
     void* arena;
     size_t arena_bytes;

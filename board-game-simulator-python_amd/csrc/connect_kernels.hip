@@ -14,6 +14,8 @@
 //
 // This is integer bit manipulation: no MFMA.  The per-ply kernels are HBM/L2 bound; the fused rollout keeps the
 // board in registers and is VALU-issue bound.
+#include <type_traits>
+
 #include "bgs_common.h"
 #include "bgs_internal.h"
 
@@ -344,39 +346,172 @@ k_connect_step_actions(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__
     add_steps(steps, stepped);
 }
 
-// K2 (first version): one lane plays one board to its end with the board in registers.
-template <class G, bool FROM_INITIAL>
+// ------------------------------------------------------------------------------------------------
+// K2: fused rollout.  A board lives in registers from its first ply to its last; a wave owns a contiguous
+// chunk of games and a lane that finishes its board takes the chunk's next game ("lane refill"), so lanes do
+// not idle while the longest game of the wave is still running.  Refill happens every 4 plies, which keeps all
+// lanes of a wave on the same word of their philox block (one philox4x32-10 per 4 plies per board).
+// Results never depend on the launch geometry: RNG streams are keyed by global game id.
+// ------------------------------------------------------------------------------------------------
+
+// board policy A: any geometry, on top of Lane / play_ply
+template <class G>
+struct GenericGame {
+    static constexpr int NW = G::NW;
+    Lane<NW> l;
+    __device__ __forceinline__ void init(const G&) { l = empty_lane<G>(); }
+    __device__ __forceinline__ void load(const G& g, const Bits<NW>& p0, const Bits<NW>& p1) { l = make_lane(g, p0, p1); }
+    uint32_t st;
+    __device__ __forceinline__ uint32_t plies() const { return l.plies; }
+    // returns true while the board is still running
+    __device__ __forceinline__ bool ply(const G& g, uint32_t draw) {
+        st = play_ply(g, l, draw);
+        return st == BGS_ST_RUNNING;
+    }
+    __device__ __forceinline__ uint32_t status_after_ply() const { return st; }
+    __device__ __forceinline__ void planes(Bits<NW>& p0, Bits<NW>& p1) const { lane_planes(l, p0, p1); }
+};
+
+// board policy B: one-word boards with W <= 8 and H <= 8 (Connect4 6x7).  Column state is one nibble per column,
+// v = (H + 7) - height, so bit 3 of the nibble says "column open"; the i-th open column is found without a loop:
+// a multiply by 0x11111111 turns the open flags into per-nibble prefix counts, and a SWAR compare against the
+// sampled index counts the columns whose prefix count is still <= index.
+template <class G>
+struct NibbleGame {
+    static constexpr int NW = 1;
+    static constexpr uint32_t ONES = 0x11111111u;
+    uint64_t cur, opp;
+    uint32_t hts, open, np;
+    bool won;
+    __device__ __forceinline__ static uint32_t top(const G& g) { return (uint32_t)g.h() + 7u; }
+    __device__ __forceinline__ static uint32_t columns(const G& g) {
+        return g.w() >= 8 ? ONES : (ONES & ((1u << (4 * g.w())) - 1u));
+    }
+    __device__ __forceinline__ void init(const G& g) {
+        cur = 0;
+        opp = 0;
+        hts = top(g) * columns(g);
+        open = columns(g);
+        np = 0;
+    }
+    __device__ __forceinline__ void load(const G& g, const Bits<1>& p0, const Bits<1>& p1) {
+        np = (uint32_t)__popcll(p0.w[0]) + (uint32_t)__popcll(p1.w[0]);
+        const bool second = np & 1u;
+        cur = second ? p1.w[0] : p0.w[0];
+        opp = second ? p0.w[0] : p1.w[0];
+        const uint64_t occ = p0.w[0] | p1.w[0];
+        const int h = g.h(), w = g.w();
+        hts = 0;
+#pragma unroll
+        for (int x = 0; x < G::MAXW; ++x) {
+            if (x < w && x < 8) {
+                const uint32_t hx = (uint32_t)__popcll((occ >> (x * (h + 1))) & ((1ull << (h + 1)) - 1ull));
+                hts |= (top(g) - hx) << (4 * x);
+            }
+        }
+        open = (hts >> 3) & ONES;
+    }
+    __device__ __forceinline__ uint32_t plies() const { return np; }
+    // returns true while the board is still running
+    __device__ __forceinline__ bool ply(const G& g, uint32_t draw) {
+        const uint32_t n = (uint32_t)__popc(open);
+        const uint32_t idx = sample_index(draw, n);
+        const uint32_t prefix = open * ONES;                              // nibble x: open columns among 0..x
+        const uint32_t t = ((idx * ONES) | 0x88888888u) - prefix;         // nibble x: 8 + idx - prefix[x]
+        const uint32_t col = (uint32_t)__popc(t & 0x88888888u);           // columns with prefix[x] <= idx
+        const uint32_t sh = col * 4u;
+        const uint32_t v = (hts >> sh) & 15u;
+        const uint32_t bit = (col * (uint32_t)(g.h() + 1) + top(g)) - v;
+        cur |= 1ull << bit;
+        hts -= 1u << sh;
+        open = (hts >> 3) & ONES;
+        Bits<1> b;
+        b.w[0] = cur;
+        won = has_run(g, b);
+        const uint64_t tmp = cur;
+        cur = opp;
+        opp = tmp;
+        np += 1u;
+        return !won && open != 0u;
+    }
+    // status of the board right after the ply that ended it (the mover of that ply is (np - 1) & 1)
+    __device__ __forceinline__ uint32_t status_after_ply() const {
+        return won ? ((np - 1u) & 1u) + 1u : (open == 0u ? BGS_ST_DRAW : BGS_ST_RUNNING);
+    }
+    __device__ __forceinline__ void planes(Bits<1>& p0, Bits<1>& p1) const {
+        const bool second = np & 1u;
+        p0.w[0] = second ? opp : cur;
+        p1.w[0] = second ? cur : opp;
+    }
+};
+
+template <class G, class Game, bool FROM_INITIAL, bool CAPPED>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                   int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
-                  unsigned long long* __restrict__ steps) {
+                  unsigned long long* __restrict__ steps, uint32_t games_per_wave) {
     constexpr int NW = G::NW;
-    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    // wave-uniform queue of this wave's games: begin + [taken, avail)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
+    const int64_t begin = (int64_t)wave * games_per_wave;
+    const int64_t end = begin + games_per_wave < n ? begin + games_per_wave : n;
+    const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
+    uint32_t taken = 0;
+
+    Game gm;
+    gm.init(g);
+    int64_t game = 0;
+    uint32_t st = BGS_ST_RUNNING, first_ply = 0;
+    bool live = false, finished = false;
     uint32_t stepped = 0;
-    if (i < n) {
-        uint32_t st = FROM_INITIAL ? BGS_ST_RUNNING : (uint32_t)status[i];
-        Lane<NW> l;
-        if (FROM_INITIAL) {
-            l = empty_lane<G>();
-        } else {
+
+    for (;;) {
+        const uint64_t need = __builtin_amdgcn_ballot_w64(!live);
+        if (need && taken < avail) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (!live && taken + rank < avail) {
+                game = begin + taken + rank;
+                if (FROM_INITIAL) {
+                    gm.init(g);
+                    st = BGS_ST_RUNNING;
+                } else {
+                    Bits<NW> p0, p1;
+                    load_planes<NW>(planes, n, game, p0, p1);
+                    gm.load(g, p0, p1);
+                    st = status[game];
+                }
+                first_ply = gm.plies();
+                live = st == BGS_ST_RUNNING && (!CAPPED || first_ply < max_plies);
+                finished = FROM_INITIAL && !live;
+            }
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            taken = avail - taken < wanted ? avail : taken + wanted;
+        }
+        if (__builtin_amdgcn_ballot_w64(live)) {
+            Philox4 blk;
+            if (live) blk = philox4x32_10(seed, first_game + (uint64_t)game, gm.plies() >> 2);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (live && (FROM_INITIAL || (gm.plies() & 3u) == j)) {
+                    const bool running = gm.ply(g, blk.v[j]);
+                    live = running && (!CAPPED || gm.plies() < max_plies);
+                    if (!live) {
+                        finished = true;
+                        st = gm.status_after_ply();
+                    }
+                }
+            }
+        }
+        if (finished) {
             Bits<NW> p0, p1;
-            load_planes<NW>(planes, n, i, p0, p1);
-            l = make_lane(g, p0, p1);
+            gm.planes(p0, p1);
+            store_planes<NW>(planes, n, game, p0, p1);
+            status[game] = (uint8_t)st;
+            reward[game] = reward_pair(st);
+            stepped += gm.plies() - first_ply;
+            finished = false;
         }
-        const uint64_t game = first_game + (uint64_t)i;
-        Philox4 blk = philox4x32_10(seed, game, l.plies >> 2);
-        while (st == BGS_ST_RUNNING && l.plies < max_plies) {
-            st = play_ply(g, l, philox_word(blk, l.plies));
-            ++stepped;
-            if ((l.plies & 3u) == 0u) blk = philox4x32_10(seed, game, l.plies >> 2);
-        }
-        if (FROM_INITIAL || stepped) {
-            Bits<NW> p0, p1;
-            lane_planes(l, p0, p1);
-            store_planes<NW>(planes, n, i, p0, p1);
-            status[i] = (uint8_t)st;
-            reward[i] = reward_pair(st);
-        }
+        if (!__builtin_amdgcn_ballot_w64(live) && taken >= avail) break;
     }
     add_steps(steps, stepped);
 }
@@ -497,6 +632,11 @@ k_connect_pack(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
 // ------------------------------------------------------------------------------------------------
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + BGS_BLOCK - 1) / BGS_BLOCK); }
 
+template <class T>
+struct Tag {
+    using type = T;
+};
+
 template <class F>
 void dispatch(const ConnectGeom& cg, F&& f) {
     if (cg.h == 6 && cg.w == 7 && cg.k == 4) { f(Geo<1, 6, 7, 4>{6, 7, 4}); return; }
@@ -533,16 +673,38 @@ void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t*
 
 void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
     const uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
+    // resident waves: CUs x 4 SIMDs x waves per SIMD; every wave gets an equal contiguous chunk of games
+    const int64_t resident = (int64_t)b->num_cus * 4 * b->rollout_wps;
+    int64_t per_wave = (b->n + resident - 1) / resident;
+    if (per_wave < BGS_WAVE) per_wave = BGS_WAVE;
+    const int64_t waves = (b->n + per_wave - 1) / per_wave;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    const bool nibble_ok = b->cg.nw == 1 && b->cg.w <= 8 && b->cg.h <= 8;
     dispatch(b->cg, [&](auto g) {
         using G = decltype(g);
-        if (flags & 1u)
-            hipLaunchKernelGGL((k_connect_rollout<G, true>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g,
-                               b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
-                               cap, b->d_steps);
-        else
-            hipLaunchKernelGGL((k_connect_rollout<G, false>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g,
-                               b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
-                               cap, b->d_steps);
+        auto launch = [&](auto game_tag, auto initial_tag, auto capped_tag) {
+            using Game = typename decltype(game_tag)::type;
+            constexpr bool INITIAL = decltype(initial_tag)::value;
+            constexpr bool CAPPED = decltype(capped_tag)::value;
+            hipLaunchKernelGGL((k_connect_rollout<G, Game, INITIAL, CAPPED>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream,
+                               g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
+                               b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+        };
+        // a cap of height * width plies or more can never bind: drop the per-ply test
+        const bool capped = cap < (uint32_t)(b->cg.h * b->cg.w);
+        auto with_game = [&](auto game_tag) {
+            if (flags & 1u) {
+                if (capped) launch(game_tag, std::true_type{}, std::true_type{});
+                else launch(game_tag, std::true_type{}, std::false_type{});
+            } else {
+                if (capped) launch(game_tag, std::false_type{}, std::true_type{});
+                else launch(game_tag, std::false_type{}, std::false_type{});
+            }
+        };
+        if constexpr (G::NW == 1) {
+            if (nibble_ok) { with_game(Tag<NibbleGame<G>>{}); return; }
+        }
+        with_game(Tag<GenericGame<G>>{});
     });
 }
 

@@ -46,6 +46,28 @@
 #define OP_PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(x) : "v"(k));
 #define OP_XAD(x) asm volatile("v_xad_u32 %0, %0, %1, %1" : "+v"(x) : "v"(k));
 
+#define DEP(OP) OP(a0) OP(a0) OP(a0) OP(a0) OP(a0) OP(a0) OP(a0) OP(a0)
+#define KERNEL32DEP(NAME, OP)                                                       \
+    __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t seed) {     \
+        uint32_t a0 = threadIdx.x + seed;                                           \
+        uint32_t k = seed | 1u, s = (seed & 7u) + 1u;                               \
+        (void)k; (void)s;                                                           \
+        for (int it = 0; it < ITER; ++it) {                                         \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) { DEP(OP) }               \
+        }                                                                           \
+        out[blockIdx.x * 256 + threadIdx.x] = a0;                                   \
+    }
+#define KERNEL64DEP(NAME, OP)                                                       \
+    __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t seed) {     \
+        uint64_t a0 = threadIdx.x + seed;                                           \
+        uint64_t k = ((uint64_t)seed << 32) | seed | 1u;                            \
+        uint32_t s = (seed & 7u) + 1u;                                              \
+        (void)k; (void)s;                                                           \
+        for (int it = 0; it < ITER; ++it) {                                         \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) { DEP(OP) }               \
+        }                                                                           \
+        out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)a0 ^ (uint32_t)(a0 >> 32); \
+    }
 KERNEL32(k_add, OP_ADD)
 KERNEL32(k_and, OP_AND)
 KERNEL32(k_shr, OP_SHR)
@@ -85,12 +107,20 @@ KERNEL32(k_xad, OP_XAD)
 #define OP_MOV64(x) asm volatile("v_mov_b64 %0, %1" : "+v"(x) : "v"(k));
 #define OP_PKADD(x) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x) : "v"(k));
 
+KERNEL32DEP(kd_add, OP_ADD)
+KERNEL32DEP(kd_and, OP_AND)
+KERNEL32DEP(kd_bcnt, OP_BCNT)
+KERNEL32DEP(kd_mullo, OP_MULLO)
+KERNEL32DEP(kd_bfe, OP_BFE)
+KERNEL32DEP(kd_cmp_cnd, OP_CMP_CND)
 KERNEL64(k_shr64, OP_SHR64)
 KERNEL64(k_shl64v, OP_SHL64V)
 KERNEL64(k_mad64, OP_MAD64)
 KERNEL64(k_lshladd64, OP_LSHLADD64)
 KERNEL64(k_cmp64_cnd, OP_CMP64)
 KERNEL64(k_mov64, OP_MOV64)
+KERNEL64DEP(kd_shr64, OP_SHR64)
+KERNEL64DEP(kd_mad64, OP_MAD64)
 
 // LDS byte look-up with random addresses (the action-select table)
 __global__ void __launch_bounds__(256) k_lds_u8(uint32_t* out, uint32_t seed) {
@@ -123,6 +153,9 @@ int main() {
         {"v_lshrrev_b64 const", k_shr64, 32}, {"v_lshlrev_b64 var", k_shl64v, 32}, {"v_mad_u64_u32", k_mad64, 32},
         {"v_lshl_add_u64", k_lshladd64, 32}, {"v_cmp_lt_u64+v_lshl_add_u64", k_cmp64_cnd, 32}, {"v_mov_b64", k_mov64, 32},
         {"lds u8 lookup (+mad)", k_lds_u8, 32},
+        {"DEP v_add_u32", kd_add, 32}, {"DEP v_and_b32", kd_and, 32}, {"DEP v_bcnt_u32_b32", kd_bcnt, 32},
+        {"DEP v_mul_lo_u32", kd_mullo, 32}, {"DEP v_bfe_u32", kd_bfe, 32}, {"DEP v_cmp+v_cndmask", kd_cmp_cnd, 32},
+        {"DEP v_lshrrev_b64", kd_shr64, 32}, {"DEP v_mad_u64_u32", kd_mad64, 32},
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);

@@ -113,6 +113,7 @@ def main() -> int:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from simulator.batch import ConnectBatch
+    from simulator.sharding import gather_rewards, shard_range, sum_steps
 
     n = args.batch
     depth = max(1, args.inflight)
@@ -122,7 +123,7 @@ def main() -> int:
     for s in streams:
         with torch.cuda.stream(s):
             b = ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=local_rank, use_torch=True)  # binds to stream s
-            b.set_first_game(rank * n)
+            b.set_first_game(shard_range(n * world, rank, world)[0])
             batches.append(b)
             gathered.append(torch.empty((world * n, 2), dtype=torch.int8, device=f"cuda:{local_rank}") if world > 1 else None)
     device = batches[0].reward_tensor().device
@@ -143,7 +144,7 @@ def main() -> int:
                 ev[1].record(streams[k])
             if dist is not None:
                 # the path's only exchange: every rank's int8 rewards into one array (RCCL over xGMI)
-                dist.all_gather_into_tensor(gathered[k], batches[k].reward_tensor())
+                gather_rewards(dist, batches[k].reward_tensor(), gathered[k])
 
     for i in range(args.warmup):
         one_step(i)
@@ -167,9 +168,7 @@ def main() -> int:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor([steps_local], dtype=torch.int64, device=device)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        steps_total = int(s.item())
+        steps_total = sum_steps(dist, steps_local, device)
     else:
         steps_total = steps_local
 

@@ -38,6 +38,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr size_t kAlign = 256;
+constexpr size_t kStepBytes = (size_t)BGS_STEP_SHARDS * BGS_STEP_STRIDE * sizeof(unsigned long long);
 inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
@@ -51,7 +52,7 @@ Layout layout_for(int planes, int64_t n, int h, int w) {
     l.status = off; off += align_up((size_t)n);
     l.plies = off; off += align_up((size_t)n * 2);
     l.reward = off; off += align_up((size_t)n * 2);
-    l.steps = off; off += kAlign;
+    l.steps = off; off += align_up(kStepBytes);
     size_t per_board = (size_t)h * w;
     if (per_board < (size_t)8 * (w + 1)) per_board = (size_t)8 * (w + 1);
     if (per_board < 16) per_board = 16;
@@ -182,7 +183,7 @@ int device_facts(bgs_batch* b) {
 }
 
 int reset_impl(bgs_batch* b) {
-    HIP_TRY(hipMemsetAsync(b->d_steps, 0, sizeof(unsigned long long), b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_steps, 0, kStepBytes, b->stream));
     if (b->game == BGS_GAME_CONNECT) bgs::connect_reset(b);
     else bgs::bounce_reset(b);
     return finish_launch();
@@ -349,7 +350,7 @@ int bgs_buffer(const bgs_batch* b, int buffer_id, void** device_ptr, size_t* byt
         case BGS_BUF_STATUS: p = b->d_status; sz = (size_t)b->n; break;
         case BGS_BUF_PLIES: p = b->d_plies; sz = (size_t)b->n * 2; break;
         case BGS_BUF_REWARD: p = b->d_reward; sz = (size_t)b->n * 2; break;
-        case BGS_BUF_STEPS: p = b->d_steps; sz = 8; break;
+        case BGS_BUF_STEPS: p = b->d_steps; sz = kStepBytes; break;
         case BGS_BUF_STAGING: p = b->d_staging; sz = b->staging_bytes; break;
         default: return fail(BGS_ERR_ARG, "unknown buffer id %d", buffer_id);
     }
@@ -409,8 +410,10 @@ int bgs_steps(bgs_batch* b, uint64_t* steps) {
     int rc = enter(b);
     if (rc) return rc;
     NEED(steps != nullptr, "steps is NULL");
+    static thread_local unsigned long long shards[BGS_STEP_SHARDS * BGS_STEP_STRIDE];
+    rc = to_host(b, shards, b->d_steps, (size_t)BGS_STEP_SHARDS * BGS_STEP_STRIDE);
     unsigned long long v = 0;
-    rc = to_host(b, &v, b->d_steps, 1);
+    for (int i = 0; i < BGS_STEP_SHARDS; ++i) v += shards[i * BGS_STEP_STRIDE];
     *steps = v;
     return rc;
 }
@@ -418,7 +421,7 @@ int bgs_steps(bgs_batch* b, uint64_t* steps) {
 int bgs_reset_steps(bgs_batch* b) {
     int rc = enter(b);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(b->d_steps, 0, sizeof(unsigned long long), b->stream));
+    HIP_TRY(hipMemsetAsync(b->d_steps, 0, kStepBytes, b->stream));
     return BGS_OK;
 }
 

@@ -210,6 +210,7 @@ class _Batch:
         return self._arena_view(_abi.BUF_STATUS)
 
     def steps_tensor(self):
+        """Device view of the sharded env-step counter (int64 words; their SUM is the count)."""
         return self._arena_view(_abi.BUF_STEPS).view(self._torch.int64)
 
     def grid_tensor(self, out=None):

@@ -50,7 +50,7 @@ typedef enum bgs_buffer_id {
     BGS_BUF_STATUS = 1,  /* uint8  [n]          0 running, 1 / 2 player 0 / 1 won, 3 draw */
     BGS_BUF_PLIES = 2,   /* uint16 [n]          plies played (Bounce only; Connect derives it from the planes) */
     BGS_BUF_REWARD = 3,  /* int8   [n][2]       reward per player, valid after a board ended (else 0) */
-    BGS_BUF_STEPS = 4,   /* uint64 [1]          env-steps applied since the last reset of the counter */
+    BGS_BUF_STEPS = 4,   /* uint64 [2048]       sharded env-step counter: the SUM of all words is the count */
     BGS_BUF_STAGING = 5  /* scratch the read/write entry points unpack through */
 } bgs_buffer_id;
 

@@ -105,12 +105,20 @@ def main() -> int:
         print("bench.py: no GPU visible; the rollout engine has no CPU fallback", file=sys.stderr)
         return 2
 
+    # one rank per GPU; BGS_DIST_BACKEND=gloo is a rehearsal mode (ranks may then share a GPU, rewards are gathered
+    # through host copies) used to exercise the N > 1 code path where RCCL cannot run (e.g. a one-GPU box)
+    backend = os.environ.get("BGS_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from simulator.batch import ConnectBatch
     from simulator.sharding import gather_rewards, shard_range, sum_steps
@@ -125,8 +133,8 @@ def main() -> int:
             b = ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=local_rank, use_torch=True)  # binds to stream s
             b.set_first_game(shard_range(n * world, rank, world)[0])
             batches.append(b)
-            gathered.append(torch.empty((world * n, 2), dtype=torch.int8, device=f"cuda:{local_rank}") if world > 1 else None)
-    device = batches[0].reward_tensor().device
+            gathered.append(torch.empty((world * n, 2), dtype=torch.int8, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu") if world > 1 else None)
+    device = batches[0].reward_tensor().device if backend == "nccl" else torch.device("cpu")
 
     def barrier():
         torch.cuda.synchronize()
@@ -144,7 +152,10 @@ def main() -> int:
                 ev[1].record(streams[k])
             if dist is not None:
                 # the path's only exchange: every rank's int8 rewards into one array (RCCL over xGMI)
-                gather_rewards(dist, batches[k].reward_tensor(), gathered[k])
+                if backend == "nccl":
+                    gather_rewards(dist, batches[k].reward_tensor(), gathered[k])
+                else:
+                    gather_rewards(dist, batches[k].reward_tensor().cpu(), gathered[k])
 
     for i in range(args.warmup):
         one_step(i)
@@ -171,6 +182,19 @@ def main() -> int:
         steps_total = sum_steps(dist, steps_local, device)
     else:
         steps_total = steps_local
+
+    gather_ok = None
+    if dist is not None:
+        # the gathered array must hold every rank's rewards in global game order: rank 0 re-plays the first games of
+        # the LAST rank's shard on its own GPU (RNG streams are keyed by global game id) and compares
+        last = args.warmup + args.steps - 1
+        if rank == 0:
+            probe = ConnectBatch(HEIGHT, WIDTH, COUNT, 4096, device=local_rank, use_torch=True)
+            probe.set_first_game((world - 1) * n)
+            probe.rollout(SEED + last, from_initial=True)
+            want = probe.reward
+            got = gathered[last % depth][(world - 1) * n : (world - 1) * n + 4096].cpu().numpy()
+            gather_ok = bool((want == got).all())
 
     if rank == 0:
         value = steps_total / elapsed
@@ -200,7 +224,8 @@ def main() -> int:
                 "batch_per_gpu": n,
                 "global_batch": n * world,
                 "env_steps_per_step": steps_total / max(args.steps, 1),
-                "sharding": f"game ids split over {world} rank(s); RCCL all-gather of int8 rewards per step" if world > 1 else "single GPU",
+                "sharding": f"game ids split over {world} rank(s); {'RCCL' if backend == 'nccl' else backend} all-gather of int8 rewards per step" if world > 1 else "single GPU",
+                "gathered_rewards_verified": gather_ok,
                 "inflight_batches": depth,
                 "waves_per_simd_per_launch": int(os.environ["BGS_ROLLOUT_WPS"]),
             },

@@ -120,21 +120,29 @@ def main() -> int:
         else:
             dist.init_process_group(backend=backend)
 
-    from simulator.batch import ConnectBatch
-    from simulator.sharding import gather_rewards, shard_range, sum_steps
+    from simulator.batch import ConnectBatch, expand_outcomes
+    from simulator.sharding import gather_outcomes, shard_range, sum_steps
 
     n = args.batch
+    if world > 1 and n % 4:
+        print("bench.py: --batch must be a multiple of 4 when sharded (4 outcome codes per byte)", file=sys.stderr)
+        return 2
     depth = max(1, args.inflight)
     os.environ.setdefault("BGS_ROLLOUT_WPS", "2")  # waves per SIMD per launch; `depth` launches share the chip
     streams = [torch.cuda.Stream(device=local_rank) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
-    batches, gathered = [], []
+    # per in-flight batch: the batch, its packed outcome codes (what crosses xGMI: 0.25 B per game), the gathered codes
+    # of all ranks and -- on rank 0, the owner of "the one array" -- the expanded rewards int8[world * n, 2]
+    batches, packed, all_packed, gathered = [], [], [], []
+    gpu = torch.device("cuda", local_rank)
     for s in streams:
         with torch.cuda.stream(s):
             b = ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=local_rank, use_torch=True)  # binds to stream s
             b.set_first_game(shard_range(n * world, rank, world)[0])
             batches.append(b)
-            gathered.append(torch.empty((world * n, 2), dtype=torch.int8, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu") if world > 1 else None)
-    device = batches[0].reward_tensor().device if backend == "nccl" else torch.device("cpu")
+            packed.append(torch.empty((n + 3) // 4, dtype=torch.uint8, device=gpu) if world > 1 else None)
+            all_packed.append(torch.empty(world * ((n + 3) // 4), dtype=torch.uint8, device=gpu) if world > 1 else None)
+            gathered.append(torch.empty((world * n, 2), dtype=torch.int8, device=gpu) if world > 1 and rank == 0 else None)
+    device = gpu if backend == "nccl" else torch.device("cpu")
 
     def barrier():
         torch.cuda.synchronize()
@@ -151,11 +159,15 @@ def main() -> int:
             if ev is not None:
                 ev[1].record(streams[k])
             if dist is not None:
-                # the path's only exchange: every rank's int8 rewards into one array (RCCL over xGMI)
+                # the path's only exchange: every rank's outcomes into one reward array on rank 0 (RCCL over xGMI).
+                # Ranks ship 2-bit outcome codes (a reward pair is a function of the code) and rank 0 expands them.
+                batches[k].outcomes_tensor(packed[k])
                 if backend == "nccl":
-                    gather_rewards(dist, batches[k].reward_tensor(), gathered[k])
+                    gather_outcomes(dist, packed[k], all_packed[k])
                 else:
-                    gather_rewards(dist, batches[k].reward_tensor().cpu(), gathered[k])
+                    all_packed[k].copy_(gather_outcomes(dist, packed[k].cpu()))
+                if rank == 0:
+                    expand_outcomes(all_packed[k], world * n, gathered[k])
 
     for i in range(args.warmup):
         one_step(i)
@@ -224,7 +236,7 @@ def main() -> int:
                 "batch_per_gpu": n,
                 "global_batch": n * world,
                 "env_steps_per_step": steps_total / max(args.steps, 1),
-                "sharding": f"game ids split over {world} rank(s); {'RCCL' if backend == 'nccl' else backend} all-gather of int8 rewards per step" if world > 1 else "single GPU",
+                "sharding": f"game ids split over {world} rank(s); per step {'RCCL' if backend == 'nccl' else backend} all-gather of 2-bit outcome codes ({(n + 3) // 4} B per rank), expanded to int8 rewards [{world * n}, 2] on rank 0" if world > 1 else "single GPU",
                 "gathered_rewards_verified": gather_ok,
                 "inflight_batches": depth,
                 "waves_per_simd_per_launch": int(os.environ["BGS_ROLLOUT_WPS"]),

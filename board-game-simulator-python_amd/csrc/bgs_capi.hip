@@ -182,6 +182,38 @@ int device_facts(bgs_batch* b) {
     return BGS_OK;
 }
 
+// ---- outcome codes for the reward gather: 2 bits per board (0 running, 1 / 2 winner, 3 draw), 4 boards per byte.
+// A reward pair is a function of the status byte, so shipping int8[n][2] over xGMI would move 8x the information.
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_pack_outcomes(const uint8_t* __restrict__ status, int64_t n, uint8_t* __restrict__ packed) {
+    const int64_t t = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    const int64_t first = t * 4;
+    if (first >= n) return;
+    uint32_t four = 0;
+    if (first + 3 < n) {
+        four = *reinterpret_cast<const uint32_t*>(status + first);
+    } else {
+        for (int j = 0; first + j < n; ++j) four |= (uint32_t)status[first + j] << (8 * j);
+    }
+    packed[t] = (uint8_t)((four & 3u) | ((four >> 6) & 0xCu) | ((four >> 12) & 0x30u) | ((four >> 18) & 0xC0u));
+}
+
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_expand_outcomes(const uint8_t* __restrict__ packed, int64_t n, uint16_t* __restrict__ reward) {
+    const int64_t t = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    const int64_t first = t * 4;
+    if (first >= n) return;
+    const uint32_t byte = packed[t];
+    uint64_t four = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) four |= (uint64_t)bgs::reward_pair((byte >> (2 * j)) & 3u) << (16 * j);
+    if (first + 3 < n) {
+        *reinterpret_cast<uint64_t*>(reward + first) = four;
+    } else {
+        for (int j = 0; first + j < n; ++j) reward[first + j] = (uint16_t)(four >> (16 * j));
+    }
+}
+
 int reset_impl(bgs_batch* b) {
     HIP_TRY(hipMemsetAsync(b->d_steps, 0, kStepBytes, b->stream));
     if (b->game == BGS_GAME_CONNECT) bgs::connect_reset(b);
@@ -554,6 +586,30 @@ int bgs_export_device(bgs_batch* b, int what, void* device_dst) {
         default:
             return fail(BGS_ERR_ARG, "unknown export kind '%c'", what);
     }
+    return finish_launch();
+}
+
+int bgs_pack_outcomes(bgs_batch* b, void* device_dst) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(device_dst != nullptr, "destination is NULL");
+    const int64_t bytes = (b->n + 3) / 4;
+    hipLaunchKernelGGL(k_pack_outcomes, dim3((unsigned)((bytes + BGS_BLOCK - 1) / BGS_BLOCK)), dim3(BGS_BLOCK), 0, b->stream,
+                       b->d_status, b->n, static_cast<uint8_t*>(device_dst));
+    return finish_launch();
+}
+
+int bgs_expand_outcomes(int device, void* hip_stream, const void* device_packed, int64_t n, int8_t* device_reward) {
+    NEED(device_packed != nullptr && device_reward != nullptr && n >= 0, "bad argument");
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    NEED(((uintptr_t)device_reward % 8) == 0, "reward buffer must be 8-byte aligned");
+    if (n == 0) return BGS_OK;
+    const int64_t bytes = (n + 3) / 4;
+    hipLaunchKernelGGL(k_expand_outcomes, dim3((unsigned)((bytes + BGS_BLOCK - 1) / BGS_BLOCK)), dim3(BGS_BLOCK), 0,
+                       static_cast<hipStream_t>(hip_stream), static_cast<const uint8_t*>(device_packed), n,
+                       reinterpret_cast<uint16_t*>(device_reward));
     return finish_launch();
 }
 

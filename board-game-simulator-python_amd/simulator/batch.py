@@ -213,6 +213,17 @@ class _Batch:
         """Device view of the sharded env-step counter (int64 words; their SUM is the count)."""
         return self._arena_view(_abi.BUF_STEPS).view(self._torch.int64)
 
+    def outcomes_tensor(self, out=None):
+        """uint8[(n + 3) // 4] on the device: 2-bit outcome codes (0 running, 1 / 2 winner, 3 draw), 4 boards per
+        byte -- the compact form of the rewards that ranks exchange (see simulator.sharding)."""
+        t = self._torch
+        if t is None:
+            raise RuntimeError("outcomes_tensor needs torch with a GPU")
+        if out is None:
+            out = t.empty((self.n + 3) // 4, dtype=t.uint8, device=f"cuda:{self.device}")
+        _abi.check(_abi.lib().bgs_pack_outcomes(self._handle, ctypes.c_void_p(out.data_ptr())))
+        return out
+
     def grid_tensor(self, out=None):
         """Observation tensor int8[n, H, W] on the device (no host round trip), e.g. as policy-network input."""
         t = self._torch
@@ -222,6 +233,23 @@ class _Batch:
             out = t.empty((self.n, self.height, self.width), dtype=t.int8, device=f"cuda:{self.device}")
         _abi.check(_abi.lib().bgs_export_device(self._handle, ord("g"), ctypes.c_void_p(out.data_ptr())))
         return out
+
+
+def expand_outcomes(packed, n: int, out=None):
+    """Packed 2-bit outcome codes (CUDA uint8 tensor) of n boards -> reward int8[n, 2] on the same device."""
+    import torch
+
+    if not packed.is_cuda or packed.dtype != torch.uint8 or not packed.is_contiguous() or packed.numel() < (n + 3) // 4:
+        raise TypeError("packed outcomes must be a contiguous CUDA uint8 tensor of (n + 3) // 4 bytes")
+    if out is None:
+        out = torch.empty((n, 2), dtype=torch.int8, device=packed.device)
+    stream = torch.cuda.current_stream(packed.device).cuda_stream
+    _abi.check(
+        _abi.lib().bgs_expand_outcomes(
+            packed.device.index, ctypes.c_void_p(stream), ctypes.c_void_p(packed.data_ptr()), n, ctypes.c_void_p(out.data_ptr())
+        )
+    )
+    return out
 
 
 class ConnectBatch(_Batch):

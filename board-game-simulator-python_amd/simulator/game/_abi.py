@@ -73,6 +73,8 @@ SIGNATURES = {
     "bgs_read_action_count": (ctypes.c_int, [c_handle, _i32p]),
     "bgs_bounce_read_targets": (ctypes.c_int, [c_handle, _u64p]),
     "bgs_export_device": (ctypes.c_int, [c_handle, ctypes.c_int, ctypes.c_void_p]),
+    "bgs_pack_outcomes": (ctypes.c_int, [c_handle, ctypes.c_void_p]),
+    "bgs_expand_outcomes": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "bgs_write_state": (ctypes.c_int, [c_handle, _i8p, _i8p, _i8p, _i32p, _i32p]),
 }
 

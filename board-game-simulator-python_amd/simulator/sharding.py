@@ -38,6 +38,21 @@ def gather_rewards(dist, local_reward, out=None):
     return out
 
 
+def gather_outcomes(dist, local_packed, out=None):
+    """All-gather the ranks' packed 2-bit outcome codes (uint8[per_rank / 4] each; per_rank must be a multiple of 4)
+    into uint8[world * per_rank / 4], ordered by global game id.  0.25 B per game crosses xGMI instead of the 2 B of
+    an int8[.., 2] reward pair; `simulator.batch.expand_outcomes` turns the result into rewards on the device."""
+    import torch
+
+    world = dist.get_world_size()
+    if out is None:
+        out = torch.empty(world * local_packed.numel(), dtype=local_packed.dtype, device=local_packed.device)
+    if out.numel() != world * local_packed.numel():
+        raise ValueError("gather buffer has the wrong size")
+    dist.all_gather_into_tensor(out, local_packed.contiguous())
+    return out
+
+
 def sum_steps(dist, local_steps: int, device) -> int:
     """Total env-steps over all ranks (one int64 all-reduce, outside any timed region)."""
     import torch

@@ -119,6 +119,14 @@ int bgs_bounce_read_targets(bgs_batch* b, uint64_t* targets);
 /* the same observations into DEVICE memory (no synchronisation): what = 'g' grid, 'l' legal, 'r' reward */
 int bgs_export_device(bgs_batch* b, int what, void* device_dst);
 
+/* ---- compact outcomes for the multi-GPU reward gather ------------------------------------------------ */
+/* 2 bits per board (0 running, 1 / 2 that player won, 3 draw), 4 boards per byte, board 4i in the low bits:
+ * device_dst uint8[(n + 3) / 4].  A reward pair (State::get_reward, connect.cpp:41 / bounce.cpp:38) is a function of
+ * this code, so ranks exchange 0.25 B per game over xGMI instead of 2 B and expand after the gather. */
+int bgs_pack_outcomes(bgs_batch* b, void* device_dst);
+/* inverse, batch-independent: packed codes of n boards -> reward int8[n][2] (8-byte aligned), on `device` / stream */
+int bgs_expand_outcomes(int device, void* hip_stream, const void* device_packed, int64_t n, int8_t* device_reward);
+
 /* ---- loading boards (State::from_json, connect.cpp:46 / bounce.cpp:45; policy-driven stepping) ---- */
 /* grid int8[n][h][w]; player int8[n] (Connect: may be NULL, derived from the stone counts); winner int8[n]
  * (NULL = all running; Connect re-derives wins and draws from the grid when NULL); plies int32[n] (Bounce; NULL =

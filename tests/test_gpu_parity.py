@@ -371,3 +371,64 @@ def test_bounce_full_size_batch(batch_mod):
     np.testing.assert_array_equal(grid, orc.grid)
     np.testing.assert_array_equal(reward, orc.reward)
     np.testing.assert_array_equal(plies, orc.plies)
+
+
+# ------------------------------------------------------------------------------------------------ ragged sizes
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 4097])
+def test_ragged_batch_sizes(batch_mod, n):
+    """Batches that do not fill a wave / workgroup / rollout chunk."""
+    dev = batch_mod.ConnectBatch(6, 7, 4, n)
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    dev.set_first_game(5)
+    for _ in range(3):
+        dev.step_random(SEED)
+        orc.step_random(SEED, first_game=5)
+    assert_same(dev, orc, "stepped")
+    dev.rollout(SEED)
+    orc.rollout(SEED, first_game=5)
+    assert_same(dev, orc, "rolled out")
+    assert dev.steps == int(orc.plies.sum())
+    bd = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+    bo = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+    bd.rollout(SEED, max_plies=300, from_initial=True)
+    bo.rollout(SEED, max_plies=300)
+    assert_same(bd, bo, "bounce")
+
+
+def test_large_batch_2_pow_23(batch_mod):
+    """BASELINE config 5's total size on one GPU: 2^23 boards; rewards of the shards [r*2^20, (r+1)*2^20) must be the
+    slices of the whole (this is what 8 ranks would gather)."""
+    n = 1 << 23
+    dev = batch_mod.ConnectBatch(6, 7, 4, n)
+    dev.rollout(SEED, from_initial=True)
+    reward = dev.reward
+    assert dev.has_ended.all() and dev.steps == int(dev.plies.sum())
+    for r in (0, 3, 7):
+        part = batch_mod.ConnectBatch(6, 7, 4, 1 << 20)
+        part.set_first_game(r << 20)
+        part.rollout(SEED, from_initial=True)
+        np.testing.assert_array_equal(part.reward, reward[r << 20 : (r + 1) << 20])
+    orc = oracle.ConnectOracle(6, 7, 4, 1 << 16)
+    orc.rollout(SEED, first_game=(7 << 20) + 12345)
+    np.testing.assert_array_equal(orc.reward, reward[(7 << 20) + 12345 : (7 << 20) + 12345 + (1 << 16)])
+
+
+def test_outcome_codes_roundtrip(batch_mod):
+    """2-bit outcome codes (what ranks exchange) expand to exactly the reward array."""
+    import torch
+
+    for n in (1, 5, 4096, 100003):
+        dev = batch_mod.ConnectBatch(6, 7, 4, n, use_torch=True)
+        dev.rollout(SEED, max_plies=20, from_initial=True)  # a mix of finished and running boards
+        codes = dev.outcomes_tensor()
+        assert codes.shape == ((n + 3) // 4,)
+        winner = dev.winner
+        want = np.where(winner == -1, 0, np.where(winner == 2, 3, winner + 1)).astype(np.uint8)
+        got = codes.cpu().numpy()
+        unpacked = np.stack([(got >> (2 * j)) & 3 for j in range(4)], axis=1).reshape(-1)[:n]
+        np.testing.assert_array_equal(unpacked, want)
+        reward = batch_mod.expand_outcomes(codes, n)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(reward.cpu().numpy(), dev.reward)

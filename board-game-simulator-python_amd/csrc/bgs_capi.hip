@@ -179,6 +179,7 @@ int device_facts(bgs_batch* b) {
         const int v = atoi(env);
         if (v >= 1 && v <= 8) b->rollout_wps = v;
     }
+    b->rollout_generic = getenv("BGS_ROLLOUT_GENERIC") != nullptr;
     return BGS_OK;
 }
 

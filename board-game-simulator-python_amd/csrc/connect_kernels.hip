@@ -516,6 +516,105 @@ k_connect_rollout(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ stat
     add_steps(steps, stepped);
 }
 
+// K2a: the same rollout for boards that start from the initial state on a one-word geometry (W <= 8, H <= 8),
+// written without per-ply control flow.  Every game starts at a 4-ply boundary, so inside a block the mover of
+// sub-step j is player j & 1: no plane swap, no ply counter.  A lane that is not playing executes the same
+// instructions with `live` = 0 -- the stone it drops is (live << position) = 0 -- so the four plies of a block and
+// the philox call in front of them form ONE basic block for the scheduler; only refill and store are conditional.
+template <class G, bool CAPPED>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
+                          int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
+                          unsigned long long* __restrict__ steps, uint32_t games_per_wave) {
+    constexpr uint32_t ONES = 0x11111111u;
+    const uint32_t top = (uint32_t)g.h() + 7u;
+    const uint32_t columns = g.w() >= 8 ? ONES : (ONES & ((1u << (4 * g.w())) - 1u));
+    const uint32_t stride = (uint32_t)g.h() + 1u;
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
+    const int64_t begin = (int64_t)wave * games_per_wave;
+    const int64_t end = begin + games_per_wave < n ? begin + games_per_wave : n;
+    const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
+    uint32_t taken = 0;
+
+    uint64_t p[2] = {0, 0};      // stones of player 0 / player 1
+    uint32_t hts = 0;            // nibble per column: (H + 7) - height; bit 3 = column open
+    uint32_t blk = 0;            // 4-ply blocks this game has played
+    uint64_t live = 0;           // 1 while this lane's game is running (64-bit: it is shifted into the planes)
+    uint32_t st = 0;             // winner code once somebody won
+    uint32_t game = 0;           // offset of this lane's game in the wave's chunk
+    uint32_t stepped = 0;
+
+    for (;;) {
+        // ---- refill: idle lanes take the next games of the chunk
+        const uint64_t need = __builtin_amdgcn_ballot_w64(live == 0);
+        if (need && taken < avail) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (live == 0 && taken + rank < avail) {
+                game = taken + rank;
+                p[0] = 0;
+                p[1] = 0;
+                hts = top * columns;
+                blk = 0;
+                st = 0;
+                live = (!CAPPED || max_plies > 0u) ? 1u : 0u;
+                if (CAPPED && live == 0) {  // max_plies == 0: the boards still have to be written once
+                    const int64_t i = begin + game;
+                    planes[i] = 0;
+                    planes[n + i] = 0;
+                    status[i] = 0;
+                    reward[i] = 0;
+                }
+            }
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            taken = avail - taken < wanted ? avail : taken + wanted;
+        }
+        if (!__builtin_amdgcn_ballot_w64(live != 0)) {
+            if (taken >= avail) break;
+            continue;
+        }
+
+        // ---- one philox block, four plies, no control flow
+        const uint64_t was_live = live;
+        const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk);
+        uint32_t open = (hts >> 3) & ONES;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t cnt = (uint32_t)__popc(open);
+            const uint32_t idx = sample_index(draws.v[j], cnt);
+            const uint32_t prefix = open * ONES;
+            const uint32_t cmp = ((idx * ONES) | 0x88888888u) - prefix;
+            const uint32_t col = (uint32_t)__popc(cmp & 0x88888888u) & 7u;
+            const uint32_t sh = col * 4u;
+            const uint32_t v = (hts >> sh) & 15u;
+            const uint32_t pos = ((col * stride + top) - v) & 63u;
+            uint64_t& mine = p[j & 1u];
+            mine |= live << pos;
+            hts -= (uint32_t)live << sh;
+            open = (hts >> 3) & ONES;
+            Bits<1> b;
+            b.w[0] = mine;
+            const bool won = has_run(g, b);
+            stepped += (uint32_t)live;
+            st = (live != 0 && won) ? (j & 1u) + 1u : st;
+            live = (won || open == 0u) ? 0 : live;
+            if (CAPPED) live = (4u * blk + j + 1u < max_plies) ? live : 0;
+        }
+        blk += 1u;
+
+        // ---- boards that ended in this block go to memory
+        if (was_live != 0 && live == 0) {
+            const int64_t i = begin + game;
+            const uint32_t code = st ? st : (open == 0u ? BGS_ST_DRAW : BGS_ST_RUNNING);
+            planes[i] = p[0];
+            planes[n + i] = p[1];
+            status[i] = (uint8_t)code;
+            reward[i] = reward_pair(code);
+        }
+    }
+    add_steps(steps, stepped);
+}
+
 // K4: packed planes -> reference layout int8[n][H][W] (row 0 = bottom; -1 empty, 0, 1); 4 output bytes per thread
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_unpack(ConnectGeom cg, const uint64_t* __restrict__ planes, int64_t n, int8_t* __restrict__ grid) {
@@ -702,6 +801,18 @@ void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
             }
         };
         if constexpr (G::NW == 1) {
+            if (nibble_ok && (flags & 1u) && !b->rollout_generic) {
+                // boards from the initial state: the block-aligned, branch-free kernel
+                if (capped)
+                    hipLaunchKernelGGL((k_connect_rollout_aligned<G, true>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, g,
+                                       b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
+                                       b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+                else
+                    hipLaunchKernelGGL((k_connect_rollout_aligned<G, false>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, g,
+                                       b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
+                                       b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+                return;
+            }
             if (nibble_ok) { with_game(Tag<NibbleGame<G>>{}); return; }
         }
         with_game(Tag<GenericGame<G>>{});

@@ -566,6 +566,7 @@ int bgs_export_device(bgs_batch* b, int what, void* device_dst) {
     NEED(device_dst != nullptr, "destination is NULL");
     switch (what) {
         case 'g':
+            NEED(((uintptr_t)device_dst % 16) == 0, "grid destination must be 16-byte aligned");
             if (b->game == BGS_GAME_CONNECT) bgs::connect_unpack_grid(b, static_cast<int8_t*>(device_dst));
             else bgs::bounce_unpack_grid(b, static_cast<int8_t*>(device_dst));
             break;

@@ -75,4 +75,17 @@ __device__ __forceinline__ void add_steps(unsigned long long* counter, uint32_t 
     }
 }
 
+// A workgroup's tile of `bytes` bytes, staged in LDS in its final layout, goes to global memory with 16-byte stores
+// (dst 16-byte aligned).  Used by the layout-conversion kernels: each lane expands one board into LDS, then the
+// whole workgroup streams the tile out coalesced instead of every lane scattering H*W single bytes.
+__device__ __forceinline__ void tile_to_global(const uint8_t* tile, uint8_t* dst, uint32_t bytes) {
+    for (uint32_t o = threadIdx.x * 16u; o < bytes; o += BGS_BLOCK * 16u) {
+        if (o + 16u <= bytes) {
+            *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(tile + o);
+        } else {
+            for (uint32_t k = o; k < bytes; ++k) dst[k] = tile[k];
+        }
+    }
+}
+
 }  // namespace bgs

@@ -216,6 +216,146 @@ k_bounce_play(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__
     add_steps(steps, stepped);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused rollout with lane refill (boards up to 8 columns wide).  Games last from 2 to several hundred plies, so a
+// lane that finishes takes the next game of its wave's chunk at once.  The target masks of the side to move are
+// kept in registers (one uint64 per column of the active row): the enumeration that decides whether the previous
+// move blocked the opponent IS the next ply's action list, so every ply runs the move search once.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxTrackedColumns = 8;
+
+struct Moves {
+    uint64_t t[kMaxTrackedColumns];  // legal landing cells of the piece in column x of the active row (0 if none)
+    uint32_t row_base;               // cell index of column 0 of the active row
+    uint32_t n;                      // number of actions
+};
+
+__device__ __forceinline__ void enumerate(const BounceGeom& g, const Board& b, uint64_t occ, uint32_t player, Moves& m) {
+    const uint64_t src = movable(g, occ, player);
+    const int first = src ? __ffsll((unsigned long long)src) - 1 : 0;
+    const int row = (int)(((uint32_t)first * g.inv_w) >> 16);
+    m.row_base = (uint32_t)(row * g.w);
+    m.n = 0;
+#pragma unroll
+    for (int x = 0; x < kMaxTrackedColumns; ++x) {
+        const int c = (int)m.row_base + x;
+        uint64_t t = 0;
+        if (x < g.w && ((src >> (c & 63)) & 1ull)) t = reach(g, b, occ, player, c);
+        m.t[x] = t;
+        m.n += (uint32_t)__popcll(t);
+    }
+}
+
+// the idx-th action of the canonical list (sources by ascending x, targets by ascending cell index)
+__device__ __forceinline__ void pick_from(const Moves& m, uint32_t idx, int& src_cell, int& dst_cell) {
+    uint64_t chosen = 0;
+    uint32_t column = 0;
+    bool found = false;
+#pragma unroll
+    for (int x = 0; x < kMaxTrackedColumns; ++x) {
+        const uint32_t cnt = (uint32_t)__popcll(m.t[x]);
+        const bool here = !found && idx < cnt;
+        chosen = here ? m.t[x] : chosen;
+        column = here ? (uint32_t)x : column;
+        idx = (found || here) ? idx : idx - cnt;
+        found = found || here;
+    }
+    for (uint32_t j = 0; j < idx; ++j) chosen &= chosen - 1;
+    src_cell = (int)(m.row_base + column);
+    dst_cell = __ffsll((unsigned long long)chosen) - 1;
+}
+
+template <bool FROM_INITIAL>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+                 uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
+                 unsigned long long* __restrict__ steps, uint32_t games_per_wave) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
+    const int64_t begin = (int64_t)wave * games_per_wave;
+    const int64_t end = begin + games_per_wave < n ? begin + games_per_wave : n;
+    const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
+    uint32_t taken = 0;
+
+    Board b;
+    b.v[0] = b.v[1] = b.v[2] = b.v[3] = 0;
+    Moves mv;
+    uint32_t st = 0, plies = 0, first_ply = 0, game = 0, stepped = 0;
+    bool live = false, dirty = false;
+    Philox4 blk;
+    blk.v[0] = blk.v[1] = blk.v[2] = blk.v[3] = 0;
+    bool have_block = false;
+
+    for (;;) {
+        // ---- refill
+        const uint64_t need = __builtin_amdgcn_ballot_w64(!live);
+        if (need && taken < avail) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (!live && taken + rank < avail) {
+                game = taken + rank;
+                const int64_t i = begin + game;
+                if (FROM_INITIAL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b.v[j] = g.init[j];
+                    st = g.init_status;
+                    plies = 0;
+                } else {
+                    b = load_board(planes, n, i);
+                    st = status[i];
+                    plies = plies_buf[i];
+                }
+                first_ply = plies;
+                dirty = FROM_INITIAL;
+                have_block = false;
+                if (st == BGS_ST_RUNNING) {
+                    enumerate(g, b, occupancy(b), plies & 1u, mv);
+                    if (mv.n == 0) {  // a running board whose side to move is blocked: settle it now
+                        st = settle_blocked(g, b, plies & 1u);
+                        dirty = true;
+                    }
+                }
+                live = st == BGS_ST_RUNNING && plies < max_plies;
+            }
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            taken = avail - taken < wanted ? avail : taken + wanted;
+        }
+
+        // ---- one ply on every live lane
+        if (live) {
+            if (!have_block || (plies & 3u) == 0u) {
+                blk = philox4x32_10(seed, first_game + (uint64_t)(begin + game), plies >> 2);
+                have_block = true;
+            }
+            const uint32_t mover = plies & 1u;
+            int s, t;
+            pick_from(mv, sample_index(philox_word(blk, plies), mv.n), s, t);
+            move_piece(b, s, t);
+            ++plies;
+            dirty = true;
+            if ((1ull << t) & (g.goal_top | g.goal_bottom)) {
+                st = mover + 1u;
+            } else {
+                const uint64_t occ = occupancy(b);
+                enumerate(g, b, occ, 1u - mover, mv);
+                if (mv.n == 0) st = count_actions(g, b, occ, mover) ? mover + 1u : BGS_ST_DRAW;
+            }
+            live = st == BGS_ST_RUNNING && plies < max_plies;
+        }
+
+        // ---- boards that stopped go to memory
+        if (!live && dirty) {
+            const int64_t i = begin + game;
+            store_board(planes, n, i, b);
+            status[i] = (uint8_t)st;
+            plies_buf[i] = (uint16_t)plies;
+            reward[i] = reward_pair(st);
+            stepped += plies - first_ply;
+            dirty = false;
+        }
+        if (!__builtin_amdgcn_ballot_w64(live) && taken >= avail) break;
+    }
+    add_steps(steps, stepped);
+}
+
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_step_actions(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
                       uint16_t* __restrict__ plies_buf, uint16_t* __restrict__ reward, int64_t n,
@@ -256,31 +396,22 @@ k_bounce_step_actions(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
     add_steps(steps, stepped);
 }
 
-// packed planes -> reference layout int8[n][H][W]; 4 output bytes per thread
+// packed planes -> reference layout int8[n][H][W]: one lane expands one board into the workgroup's LDS tile, the
+// workgroup streams the tile out with 16-byte stores
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_unpack(BounceGeom g, const uint64_t* __restrict__ planes, int64_t n, int8_t* __restrict__ grid) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
     const int hw = g.h * g.w;
-    const int64_t total = n * hw;
-    const int64_t f = ((int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x) * 4;
-    if (f >= total) return;
-    uint32_t packed = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t idx = f + j;
-        uint32_t v = 0;
-        if (idx < total) {
-            const int64_t bi = idx / hw;
-            const int c = (int)(idx - bi * hw);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) v |= (uint32_t)((planes[(int64_t)p * n + bi] >> c) & 1ull) << p;
-        }
-        packed |= v << (8 * j);
+    const int64_t base = (int64_t)blockIdx.x * BGS_BLOCK;
+    const int64_t i = base + threadIdx.x;
+    if (i < n) {
+        const Board b = load_board(planes, n, i);
+        uint8_t* mine = tile + threadIdx.x * hw;
+        for (int c = 0; c < hw; ++c) mine[c] = (uint8_t)value_at(b, c);
     }
-    if (f + 3 < total) {
-        *reinterpret_cast<uint32_t*>(grid + f) = packed;
-    } else {
-        for (int j = 0; j < 4 && f + j < total; ++j) grid[f + j] = (int8_t)(packed >> (8 * j));
-    }
+    __syncthreads();
+    const int64_t boards = n - base < BGS_BLOCK ? n - base : BGS_BLOCK;
+    tile_to_global(tile, reinterpret_cast<uint8_t*>(grid) + base * hw, (uint32_t)(boards * hw));
 }
 
 __global__ void __launch_bounds__(BGS_BLOCK)
@@ -376,6 +507,23 @@ void bounce_step_random(const bgs_batch* b, uint64_t seed) {
 void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
     uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
     if (cap > 65535u) cap = 65535u;  // plies are stored as uint16
+    if (b->bg.w <= kMaxTrackedColumns && !b->rollout_generic) {
+        const int64_t resident = (int64_t)b->num_cus * 4 * b->rollout_wps;
+        int64_t per_wave = (b->n + resident - 1) / resident;
+        if (per_wave < BGS_WAVE) per_wave = BGS_WAVE;
+        const int64_t waves = (b->n + per_wave - 1) / per_wave;
+        const unsigned blocks = (unsigned)((waves + 3) / 4);
+        if (flags & 1u)
+            hipLaunchKernelGGL((k_bounce_rollout<true>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
+                               b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
+                               cap, b->d_steps, (uint32_t)per_wave);
+        else
+            hipLaunchKernelGGL((k_bounce_rollout<false>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
+                               b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
+                               cap, b->d_steps, (uint32_t)per_wave);
+        return;
+    }
+    // wider boards: one lane per board, two-pass enumeration
     if (flags & 1u)
         hipLaunchKernelGGL((k_bounce_play<false, true>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg,
                            b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
@@ -393,8 +541,8 @@ void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_
 }
 
 void bounce_unpack_grid(const bgs_batch* b, int8_t* d_grid) {
-    const int64_t quads = (b->n * b->bg.h * b->bg.w + 3) / 4;
-    hipLaunchKernelGGL(k_bounce_unpack, dim3(grid_for(quads)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->n,
+    const size_t lds = (size_t)BGS_BLOCK * b->bg.h * b->bg.w;
+    hipLaunchKernelGGL(k_bounce_unpack, dim3(grid_for(b->n)), dim3(BGS_BLOCK), lds, b->stream, b->bg, b->d_planes, b->n,
                        d_grid);
 }
 

@@ -283,34 +283,6 @@ __global__ void __launch_bounds__(BGS_BLOCK) k_connect_reset(uint64_t* __restric
     reward[i] = 0;
 }
 
-// K1: one uniformly sampled ply per running board.  Algorithmic traffic per env-step: both planes in, the
-// mover's plane out, status in/out.
-template <class G>
-__global__ void __launch_bounds__(BGS_BLOCK)
-k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
-                      int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps) {
-    constexpr int NW = G::NW;
-    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
-    uint32_t stepped = 0;
-    if (i < n && status[i] == BGS_ST_RUNNING) {
-        Bits<NW> p0, p1;
-        load_planes<NW>(planes, n, i, p0, p1);
-        Lane<NW> l = make_lane(g, p0, p1);
-        const uint32_t mover = l.plies & 1u;
-        const Philox4 blk = philox4x32_10(seed, first_game + (uint64_t)i, l.plies >> 2);
-        const uint32_t st = play_ply(g, l, philox_word(blk, l.plies));
-        // after the swap the mover's stones are in l.opp; only that plane changed
-#pragma unroll
-        for (int j = 0; j < NW; ++j) planes[(int64_t)(mover * NW + j) * n + i] = l.opp.w[j];
-        if (st != BGS_ST_RUNNING) {
-            status[i] = (uint8_t)st;
-            reward[i] = reward_pair(st);
-        }
-        stepped = 1;
-    }
-    add_steps(steps, stepped);
-}
-
 template <class G>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_step_actions(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
@@ -516,6 +488,42 @@ k_connect_rollout(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ stat
     add_steps(steps, stepped);
 }
 
+// K1: one uniformly sampled ply per running board.  Algorithmic traffic per env-step: both planes + status in, the
+// mover's plane out (+ status / reward when the board ends).  All loads are issued before the first use: with a
+// dependent status -> planes chain every wave paid two memory latencies and the kernel was latency-, not
+// bandwidth-bound.
+template <class G, class Game>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
+                      int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps) {
+    constexpr int NW = G::NW;
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    uint32_t stepped = 0;
+    if (i < n) {
+        Bits<NW> p0, p1;
+        const uint32_t st0 = status[i];
+        load_planes<NW>(planes, n, i, p0, p1);
+        if (st0 == BGS_ST_RUNNING) {
+            Game gm;
+            gm.load(g, p0, p1);
+            const uint32_t ply = gm.plies();
+            const Philox4 blk = philox4x32_10(seed, first_game + (uint64_t)i, ply >> 2);
+            const bool running = gm.ply(g, philox_word(blk, ply));
+            gm.planes(p0, p1);
+            const uint32_t mover = ply & 1u;  // only the mover's plane changed
+#pragma unroll
+            for (int j = 0; j < NW; ++j) planes[(int64_t)(mover * NW + j) * n + i] = mover ? p1.w[j] : p0.w[j];
+            if (!running) {
+                const uint32_t st = gm.status_after_ply();
+                status[i] = (uint8_t)st;
+                reward[i] = reward_pair(st);
+            }
+            stepped = 1;
+        }
+    }
+    add_steps(steps, stepped);
+}
+
 // K2a: the same rollout for boards that start from the initial state on a one-word geometry (W <= 8, H <= 8),
 // written without per-ply control flow.  Every game starts at a 4-ply boundary, so inside a block the mover of
 // sub-step j is player j & 1: no plane swap, no ply counter.  A lane that is not playing executes the same
@@ -615,35 +623,31 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
     add_steps(steps, stepped);
 }
 
-// K4: packed planes -> reference layout int8[n][H][W] (row 0 = bottom; -1 empty, 0, 1); 4 output bytes per thread
+// K4: packed planes -> reference layout int8[n][H][W] (row 0 = bottom; -1 empty, 0, 1).  One lane expands one board
+// into the workgroup's LDS tile (256 boards x H*W bytes, already in output order); the workgroup then streams the
+// tile to HBM with 16-byte stores.
+template <class G>
 __global__ void __launch_bounds__(BGS_BLOCK)
-k_connect_unpack(ConnectGeom cg, const uint64_t* __restrict__ planes, int64_t n, int8_t* __restrict__ grid) {
-    const int64_t total = n * cg.h * cg.w;
-    const int64_t f = ((int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x) * 4;
-    if (f >= total) return;
-    const int hw = cg.h * cg.w;
-    uint32_t packed = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t idx = f + j;
-        int8_t v = 0;
-        if (idx < total) {
-            const int64_t b = idx / hw;
-            const int cell = (int)(idx - b * hw);
-            const int y = cell / cg.w, x = cell - y * cg.w;
-            const int bit = x * (cg.h + 1) + y;
-            const uint64_t m = 1ull << (bit & 63);
-            const uint64_t w0 = planes[(int64_t)(bit >> 6) * n + b];
-            const uint64_t w1 = planes[(int64_t)(cg.nw + (bit >> 6)) * n + b];
-            v = (w1 & m) ? 1 : ((w0 & m) ? 0 : -1);
-        }
-        packed |= (uint32_t)(uint8_t)v << (8 * j);
+k_connect_unpack(G g, const uint64_t* __restrict__ planes, int64_t n, int8_t* __restrict__ grid) {
+    constexpr int NW = G::NW;
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    const int h = g.h(), w = g.w(), hw = h * w;
+    const int64_t base = (int64_t)blockIdx.x * BGS_BLOCK;
+    const int64_t i = base + threadIdx.x;
+    if (i < n) {
+        Bits<NW> p0, p1;
+        load_planes<NW>(planes, n, i, p0, p1);
+        uint8_t* mine = tile + threadIdx.x * hw;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const int bit = x * (h + 1) + y;
+                const uint32_t b0 = test_bit(p0, bit), b1 = test_bit(p1, bit);
+                mine[y * w + x] = (uint8_t)(b0 + 2u * b1 - 1u);  // 0xFF empty, 0 player 0, 1 player 1
+            }
     }
-    if (f + 3 < total) {
-        *reinterpret_cast<uint32_t*>(grid + f) = packed;
-    } else {
-        for (int j = 0; j < 4 && f + j < total; ++j) grid[f + j] = (int8_t)(packed >> (8 * j));
-    }
+    __syncthreads();
+    const int64_t boards = n - base < BGS_BLOCK ? n - base : BGS_BLOCK;
+    tile_to_global(tile, reinterpret_cast<uint8_t*>(grid) + base * hw, (uint32_t)(boards * hw));
 }
 
 __global__ void __launch_bounds__(BGS_BLOCK)
@@ -754,11 +758,26 @@ void connect_reset(const bgs_batch* b) {
                        reinterpret_cast<uint16_t*>(b->d_reward), b->n, b->planes);
 }
 
-void connect_step_random(const bgs_batch* b, uint64_t seed) {
-    dispatch(b->cg, [&](auto g) {
+// geometry + board policy: nibble column state where it applies (one word, W <= 8, H <= 8), generic otherwise
+template <class F>
+void dispatch_game(const ConnectGeom& cg, F&& f) {
+    const bool nibble_ok = cg.nw == 1 && cg.w <= 8 && cg.h <= 8;
+    dispatch(cg, [&](auto g) {
         using G = decltype(g);
-        hipLaunchKernelGGL((k_connect_step_random<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g, b->d_planes,
-                           b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, b->d_steps);
+        if constexpr (G::NW == 1) {
+            if (nibble_ok) { f(g, Tag<NibbleGame<G>>{}); return; }
+        }
+        f(g, Tag<GenericGame<G>>{});
+    });
+}
+
+void connect_step_random(const bgs_batch* b, uint64_t seed) {
+    dispatch_game(b->cg, [&](auto g, auto game_tag) {
+        using G = decltype(g);
+        using Game = typename decltype(game_tag)::type;
+        hipLaunchKernelGGL((k_connect_step_random<G, Game>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g,
+                           b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
+                           b->d_steps);
     });
 }
 
@@ -820,9 +839,12 @@ void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
 }
 
 void connect_unpack_grid(const bgs_batch* b, int8_t* d_grid) {
-    const int64_t quads = (b->n * b->cg.h * b->cg.w + 3) / 4;
-    hipLaunchKernelGGL(k_connect_unpack, dim3(grid_for(quads)), dim3(BGS_BLOCK), 0, b->stream, b->cg, b->d_planes, b->n,
-                       d_grid);
+    const size_t lds = (size_t)BGS_BLOCK * b->cg.h * b->cg.w;
+    dispatch(b->cg, [&](auto g) {
+        using G = decltype(g);
+        hipLaunchKernelGGL((k_connect_unpack<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), lds, b->stream, g, b->d_planes,
+                           b->n, d_grid);
+    });
 }
 
 void connect_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies) {

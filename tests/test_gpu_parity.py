@@ -240,6 +240,7 @@ BOUNCE_GRIDS = {
         dtype=np.int8,
     ),
     "narrow": np.array([[0], [1], [0], [2], [0]], dtype=np.int8),
+    "wide": np.array([[0] * 12, [1, 2, 0, 3, 1, 0, 2, 2, 0, 1, 3, 1], [0] * 12, [2, 1, 3, 0, 0, 2, 1, 0, 3, 1, 0, 2], [0] * 12], dtype=np.int8),
     "blocked_start": np.array([[0, 0], [2, 2], [2, 2], [0, 0]], dtype=np.int8),
 }
 

@@ -156,11 +156,41 @@ int finish_launch() {
     return BGS_OK;
 }
 
-template <class T>
-int to_host(const bgs_batch* b, T* host, const T* dev, size_t count) {
-    HIP_TRY(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+// Device -> caller's (pageable) host memory.  A direct hipMemcpy into pageable memory runs at a few GB/s; large
+// copies go through two pinned bounce buffers instead: chunk k+1 crosses PCIe while the CPU moves chunk k.
+constexpr size_t kPinnedChunk = 4u << 20;
+
+int copy_to_host(bgs_batch* b, void* host, const void* dev, size_t bytes) {
+    if (bytes <= (256u << 10)) {
+        HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        return BGS_OK;
+    }
+    if (!b->pinned[0]) {
+        HIP_TRY(hipHostMalloc(&b->pinned[0], kPinnedChunk, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&b->pinned[1], kPinnedChunk, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&b->pinned_done[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b->pinned_done[1], hipEventDisableTiming));
+    }
+    const size_t chunks = (bytes + kPinnedChunk - 1) / kPinnedChunk;
+    auto issue = [&](size_t k) -> hipError_t {
+        const size_t off = k * kPinnedChunk, len = bytes - off < kPinnedChunk ? bytes - off : kPinnedChunk;
+        hipError_t e = hipMemcpyAsync(b->pinned[k & 1], static_cast<const uint8_t*>(dev) + off, len, hipMemcpyDeviceToHost, b->stream);
+        return e != hipSuccess ? e : hipEventRecord(b->pinned_done[k & 1], b->stream);
+    };
+    HIP_TRY(issue(0));
+    for (size_t k = 0; k < chunks; ++k) {
+        if (k + 1 < chunks) HIP_TRY(issue(k + 1));
+        HIP_TRY(hipEventSynchronize(b->pinned_done[k & 1]));
+        const size_t off = k * kPinnedChunk, len = bytes - off < kPinnedChunk ? bytes - off : kPinnedChunk;
+        memcpy(static_cast<uint8_t*>(host) + off, b->pinned[k & 1], len);
+    }
     return BGS_OK;
+}
+
+template <class T>
+int to_host(bgs_batch* b, T* host, const T* dev, size_t count) {
+    return copy_to_host(b, host, dev, count * sizeof(T));
 }
 
 template <class T>
@@ -339,6 +369,10 @@ int bgs_destroy(bgs_batch* b) {
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
     if (b->owns_arena && b->arena) (void)hipFree(b->arena);
+    for (int k = 0; k < 2; ++k) {
+        if (b->pinned[k]) (void)hipHostFree(b->pinned[k]);
+        if (b->pinned_done[k]) (void)hipEventDestroy(b->pinned_done[k]);
+    }
     delete b;
     return BGS_OK;
 }

@@ -56,6 +56,9 @@ struct bgs_batch {
     unsigned long long* d_steps;
     uint8_t* d_staging;
     size_t staging_bytes;
+    // pinned bounce buffers for large device -> host copies (allocated on first use)
+    void* pinned[2];
+    hipEvent_t pinned_done[2];
 };
 
 namespace bgs {

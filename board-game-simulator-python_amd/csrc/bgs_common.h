@@ -21,15 +21,27 @@ struct Philox4 {
     uint32_t v[4];
 };
 
-__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t game, uint32_t block) {
+// a ^ b ^ c in one VALU instruction: v_bitop3_b32 with truth table 0x96 (gfx950 has no v_xor3_b32; hipcc emits two
+// v_xor_b32 here)
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+#else
+    return a ^ b ^ c;
+#endif
+}
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t game, uint32_t block) {
     uint32_t c0 = (uint32_t)game, c1 = (uint32_t)(game >> 32), c2 = block, c3 = 0u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);  // wave-uniform: the key schedule stays in SGPRs
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -42,7 +54,7 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_
     return out;
 }
 
-__host__ __device__ __forceinline__ uint32_t philox_word(const Philox4& p, uint32_t ply) {
+__device__ __forceinline__ uint32_t philox_word(const Philox4& p, uint32_t ply) {
     const uint32_t j = ply & 3u;
     const uint32_t lo = (j & 1u) ? p.v[1] : p.v[0];
     const uint32_t hi = (j & 1u) ? p.v[3] : p.v[2];

@@ -524,6 +524,37 @@ k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
     add_steps(steps, stepped);
 }
 
+// (a & b) | c in one VALU instruction (v_bitop3_b32, truth table 0xEA)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// four in a row on a one-word board, written for instruction count (every VALU instruction costs about one issue
+// quad here, whatever its width): per direction two 64-bit shifts, two ANDs for the pairs, and the quads are
+// accumulated with the fused (pairs & shifted pairs) | acc
+__device__ __forceinline__ bool four_in_a_row(uint64_t b, int h) {
+    const int dirs[4] = {1, h + 1, h + 2, h};
+    uint32_t acc_lo = 0, acc_hi = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint64_t s1 = b >> dirs[d];
+        const uint32_t pl = (uint32_t)b & (uint32_t)s1, ph = (uint32_t)(b >> 32) & (uint32_t)(s1 >> 32);
+        const uint64_t pairs = ((uint64_t)ph << 32) | pl;
+        uint64_t s2;  // one v_lshrrev_b64 (hipcc would split this shift of two halves into alignbit + shift)
+        asm("v_lshrrev_b64 %0, %1, %2" : "=v"(s2) : "s"(2 * dirs[d]), "v"(pairs));
+        if (d == 0) {
+            acc_lo = pl & (uint32_t)s2;
+            acc_hi = ph & (uint32_t)(s2 >> 32);
+        } else {
+            acc_lo = and_or(pl, (uint32_t)s2, acc_lo);
+            acc_hi = and_or(ph, (uint32_t)(s2 >> 32), acc_hi);
+        }
+    }
+    return (acc_lo | acc_hi) != 0u;
+}
+
 // K2a: the same rollout for boards that start from the initial state on a one-word geometry (W <= 8, H <= 8),
 // written without per-ply control flow.  Every game starts at a 4-ply boundary, so inside a block the mover of
 // sub-step j is player j & 1: no plane swap, no ply counter.  A lane that is not playing executes the same
@@ -538,6 +569,7 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
     const uint32_t top = (uint32_t)g.h() + 7u;
     const uint32_t columns = g.w() >= 8 ? ONES : (ONES & ((1u << (4 * g.w())) - 1u));
     const uint32_t stride = (uint32_t)g.h() + 1u;
+    const uint32_t column_top = 8u * columns;  // bit 3 of the nibbles of real columns only: the count stays <= W
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
     const int64_t begin = (int64_t)wave * games_per_wave;
@@ -590,19 +622,28 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t cnt = (uint32_t)__popc(open);
             const uint32_t idx = sample_index(draws.v[j], cnt);
-            const uint32_t prefix = open * ONES;
-            const uint32_t cmp = ((idx * ONES) | 0x88888888u) - prefix;
-            const uint32_t col = (uint32_t)__popc(cmp & 0x88888888u) & 7u;
+            // nibble x of cmp = 8 + idx - (open columns among 0..x): (idx - open) * ONES is idx * ONES - open * ONES
+            const uint32_t cmp = (uint32_t)((uint64_t)(idx - open) * ONES + 0x88888888ull);  // one v_mad_u64_u32
+            uint32_t col = (uint32_t)__popc(cmp & column_top);  // columns whose prefix count is still <= idx
+            if (g.w() >= 8) col &= 7u;                         // (a full 8-wide board would give 8)
             const uint32_t sh = col * 4u;
             const uint32_t v = (hts >> sh) & 15u;
-            const uint32_t pos = ((col * stride + top) - v) & 63u;
+            uint32_t base = col * stride + top;
+            asm("" : "+v"(base));  // keep (col * stride + top) one multiply-add; then one subtract
+            uint32_t pos = base - v;
+            if ((uint32_t)g.w() * stride + top > 63u) pos &= 63u;  // only a lane that is not playing can exceed 63
             uint64_t& mine = p[j & 1u];
             mine |= live << pos;
             hts -= (uint32_t)live << sh;
             open = (hts >> 3) & ONES;
-            Bits<1> b;
-            b.w[0] = mine;
-            const bool won = has_run(g, b);
+            bool won;
+            if (g.k() == 4) {
+                won = four_in_a_row(mine, g.h());
+            } else {
+                Bits<1> b;
+                b.w[0] = mine;
+                won = has_run(g, b);
+            }
             stepped += (uint32_t)live;
             st = (live != 0 && won) ? (j & 1u) + 1u : st;
             live = (won || open == 0u) ? 0 : live;

@@ -585,7 +585,8 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
     uint32_t game = 0;           // offset of this lane's game in the wave's chunk
     uint32_t stepped = 0;
 
-    for (;;) {
+    if (avail == 0u) return;  // (whole wave: the chunk is empty; nothing was counted)
+    do {
         // ---- refill: idle lanes take the next games of the chunk
         const uint64_t need = __builtin_amdgcn_ballot_w64(live == 0);
         if (need && taken < avail) {
@@ -608,10 +609,6 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
             }
             const uint32_t wanted = (uint32_t)__popcll(need);
             taken = avail - taken < wanted ? avail : taken + wanted;
-        }
-        if (!__builtin_amdgcn_ballot_w64(live != 0)) {
-            if (taken >= avail) break;
-            continue;
         }
 
         // ---- one philox block, four plies, no control flow
@@ -660,7 +657,7 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
             status[i] = (uint8_t)code;
             reward[i] = reward_pair(code);
         }
-    }
+    } while (__builtin_amdgcn_ballot_w64(live != 0) || taken < avail);
     add_steps(steps, stepped);
 }
 

@@ -212,11 +212,21 @@ def main() -> int:
         value = steps_total / elapsed
         steps_per_launch = steps_local / max(args.steps, 1)
         achieved = steps_per_launch * BYTES_PER_STEP / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, valu = None, None
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             with open(traffic_file) as fh:
-                traffic = json.load(fh).get("k_connect_rollout", {}).get("hbm_bytes_per_launch")
+                counters = json.load(fh).get("k_connect_rollout", {})
+            traffic = counters.get("hbm_bytes_per_launch")
+            if counters.get("valu_wave_instructions_per_launch") and n == BATCH_PER_GPU:
+                # the resource that actually binds: one wave64 VALU instruction per 4 cycles per SIMD (measured,
+                # tools/ubench.hip + SQ_ACTIVE_INST_VALU); instruction count per launch from the committed PMC pass
+                instr = counters["valu_wave_instructions_per_launch"]
+                peak = 256 * 4 * 2.4e9 / 4 / 1e9
+                rate = instr / (elapsed / max(args.steps, 1)) / 1e9
+                valu = {"wave_instr_per_launch": instr, "achieved_Ginstr_per_s": rate, "peak_Ginstr_per_s": peak,
+                        "frac": rate / peak, "basis": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; "
+                        "launches overlap, so the rate uses ms_per_step"}
         out = {
             "metric": "env-steps/sec, Connect4(6,7,4) random rollout, batch=2^20 per GPU",
             "value": value,
@@ -252,6 +262,7 @@ def main() -> int:
                 "algorithmic_bytes_per_launch": steps_per_launch * BYTES_PER_STEP,
                 "kernel_ms_per_launch": kernel_ms,
                 "launches_in_flight": depth,
+                "valu_issue": valu,
                 "note": "algorithmic = 32 B per env-step (SURVEY 8d); the fused rollout keeps boards in registers, "
                 "so real HBM traffic (traffic) is far smaller and the kernel is VALU-issue bound; with "
                 "launches_in_flight > 1 a launch shares the chip with its neighbours, so its own duration is longer "

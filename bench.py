@@ -11,12 +11,17 @@ transitions applied to running boards (masked no-ops are not counted); they are 
         bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU, rank r owns global game ids [r * 2^20, (r+1) * 2^20) (RNG streams are keyed by global
-game id, so the shards reproduce the unsharded run); the only collective is the reward gather (RCCL all-gather of
-int8[2^20, 2] per rank) plus one all-reduce of the step counters after the timed region.  Weak scaling.
+game id, so the shards reproduce the unsharded run); the only collective per step is the reward gather (RCCL
+all-gather of 2-bit outcome codes, 256 KiB per rank, expanded to int8[N * 2^20, 2] rewards on rank 0) plus one
+all-reduce of the step counters after the timed region.  Weak scaling.
+
+Steps run on `--inflight` (default 2) batches / HIP streams in rotation: a rollout is bound by VALU instruction
+issue, and its drain (the last game of every lane) leaves SIMDs idle that the next launch fills.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     : algorithmic HBM bytes (32 B per env-step: both 8-byte planes in and out) over the
-                 rollout kernel's mean launch duration (HIP events on the launch stream) against 8 TB/s;
+                 rollout kernel's mean launch duration (HIP events on the launch stream) against 8 TB/s, plus
+                 `valu_issue`, the resource that actually binds (see DESIGN.md section 6);
   cpu_baseline : the CPU oracle (plain C restatement, OpenMP) timed on this host on a bounded sample of the same
                  workload -- a reported baseline, not the target.
 """

@@ -69,7 +69,9 @@ int orc_reward(int64_t n, const int8_t* winner, int8_t* reward) {
 
 static int connect_cfg_ok(int h, int w, int k) { return h >= 1 && w >= 1 && k >= 1 && h <= 64 && w <= 64; }
 
-/* number of stones of `who` in a row through (x, y) along (dx, dy), counting (x, y) itself */
+/* number of stones of `who` in a row through (x, y) along (dx, dy), counting (x, y) itself.
+ * Follows: reference tests/test_connect.py:107-115 (horizontal pair wins at count = 2); other directions are the
+ * standard Connect-k rule [UNPINNED]. */
 static int connect_run(int h, int w, const int8_t* g, int x, int y, int dx, int dy, int who) {
     int count = 1;
     for (int s = 1;; ++s) {
@@ -85,6 +87,8 @@ static int connect_run(int h, int w, const int8_t* g, int x, int y, int dx, int 
     return count;
 }
 
+/* State.actions (reference src/simulator/game/connect.cpp:43): one action per column whose top cell is empty, ascending
+ * [order UNPINNED], none once the game has ended (by analogy with tests/test_bounce.py:151). */
 static int connect_legal_one(int h, int w, const int8_t* g, int winner, int* cols) {
     int n = 0;
     if (winner != -1) return 0;
@@ -93,7 +97,10 @@ static int connect_legal_one(int h, int w, const int8_t* g, int winner, int* col
     return n;
 }
 
-/* drop + terminal test on one board; returns ORC_ERR_ILLEGAL for a full column / ended board */
+/* State.action_at + Action.sample_next_state (reference connect.cpp:44,52): the stone lands in the lowest empty cell of
+ * the column, the other player is to move (tests/test_connect.py:86-104, :130-138), a k-run ends the game with reward
+ * [1,-1] for the mover (:107-115); a full board without a run is a draw [UNPINNED].  Illegal: full column, column out
+ * of range, ended board (RuntimeError in the reference, textual/connect.py:115-118). */
 static int connect_apply_one(int h, int w, int k, int8_t* g, int8_t* player, int8_t* winner, int32_t* plies, int col) {
     if (*winner != -1 || col < 0 || col >= w) return ORC_ERR_ILLEGAL;
     int y = 0;
@@ -113,6 +120,8 @@ static int connect_apply_one(int h, int w, int k, int8_t* g, int8_t* player, int
     return ORC_OK;
 }
 
+/* Config.sample_initial_state (reference connect.cpp:32): empty board (-1), player 0 to move, winner -1
+ * (tests/test_connect.py:75-83, :131-138). */
 int orc_connect_reset(int h, int w, int64_t n, int8_t* grid, int8_t* player, int8_t* winner, int32_t* plies) {
     if (!connect_cfg_ok(h, w, 1) || n < 0) return ORC_ERR_ARG;
     memset(grid, 0xFF, (size_t)n * h * w);
@@ -141,6 +150,7 @@ int orc_connect_step_actions(int h, int w, int k, int64_t n, int8_t* grid, int8_
     return ORC_OK;
 }
 
+/* the caller loop of reference README.md:52-69 with random.choice replaced by the RNG contract of bgs_oracle.h */
 static uint64_t connect_play(int h, int w, int k, int8_t* g, int8_t* player, int8_t* winner, int32_t* plies,
                              uint64_t seed, uint64_t game, int32_t max_plies, int single_ply) {
     int cols[64];
@@ -196,6 +206,7 @@ typedef struct {
 
 static int bounce_cfg_ok(int h, int w) { return h >= 3 && w >= 1 && h <= 64 && w <= 64; }
 
+/* Config(grid) (reference bounce.cpp:26): pieces only strictly between the first and last row (tests/test_bounce.py:30) */
 int orc_bounce_validate(int h, int w, const int8_t* cfg) {
     if (!bounce_cfg_ok(h, w) || !cfg) return ORC_ERR_ARG;
     for (int y = 0; y < h; ++y)
@@ -234,7 +245,8 @@ static void bounce_walk(bounce_search* s, int x, int y, int remaining, int lastd
     }
 }
 
-/* active row (Appendix B rule 3): nearest non-empty non-goal row on the mover's side, or -1 */
+/* active row (Appendix B rule 3; reference tests/test_bounce.py:44-48 infers the player from it and every scripted
+ * selection obeys it): nearest non-empty non-goal row on the mover's side, or -1 */
 static int bounce_active_row(int h, int w, const int8_t* g, int player) {
     if (player == 0) {
         for (int y = 1; y < h - 1; ++y)
@@ -248,6 +260,8 @@ static int bounce_active_row(int h, int w, const int8_t* g, int player) {
     return -1;
 }
 
+/* State.actions_at(source) (reference bounce.cpp:41): the exhaustive target set the reference tests compare with
+ * (tests/test_bounce.py:80-83) */
 static int bounce_targets_one(int h, int w, const int8_t* g, int player, int sx, int sy, uint8_t* targets) {
     memset(targets, 0, (size_t)h * w);
     if (sx < 0 || sx >= w || sy < 0 || sy >= h) return ORC_ERR_ARG;
@@ -272,6 +286,8 @@ int orc_bounce_targets(int h, int w, const int8_t* grid, int player, int winner,
     return bounce_targets_one(h, w, grid, player, sx, sy, targets);
 }
 
+/* State.actions (reference bounce.cpp:40): all (source, target) pairs; canonical order and no duplicates are
+ * build-defined [UNPINNED]; empty once ended (tests/test_bounce.py:151,277,298,319,340,361) */
 int orc_bounce_actions(int h, int w, const int8_t* g, int player, int winner, int cap, int32_t* src_xy, int32_t* dst_xy) {
     if (!bounce_cfg_ok(h, w) || !g) return ORC_ERR_ARG;
     if (winner != -1) return 0;
@@ -312,6 +328,8 @@ static void bounce_settle(int h, int w, const int8_t* g, int mover, int ty, int8
     *winner = (int8_t)(orc_bounce_actions(h, w, g, mover, -1, 0, NULL, NULL) > 0 ? mover : 2);
 }
 
+/* State.action_at(source, target) + Action.sample_next_state (reference bounce.cpp:42,51): the piece moves from source
+ * to target, the other player is to move (tests/test_bounce.py:106-148) */
 static int bounce_apply_one(int h, int w, int8_t* g, int8_t* player, int8_t* winner, int32_t* plies, int sx, int sy,
                             int tx, int ty) {
     if (*winner != -1) return ORC_ERR_ILLEGAL;
@@ -330,6 +348,8 @@ static int bounce_apply_one(int h, int w, int8_t* g, int8_t* player, int8_t* win
     return ORC_OK;
 }
 
+/* Config.sample_initial_state (reference bounce.cpp:29): a copy of the config grid, player 0 to move
+ * (tests/test_bounce.py:53-60, :392-403) */
 int orc_bounce_reset(int h, int w, const int8_t* cfg, int64_t n, int8_t* grid, int8_t* player, int8_t* winner,
                      int32_t* plies) {
     if (orc_bounce_validate(h, w, cfg) != ORC_OK || n < 0) return ORC_ERR_ARG;

@@ -155,9 +155,21 @@ def main() -> int:
             dist.barrier()
             torch.cuda.synchronize()
 
+    pending = [None] * depth  # the in-flight reward gather of each batch slot
+
+    def finish_gather(k):
+        """Slot k's gather is due: make stream k wait for it and, on rank 0, expand the codes into THE reward array."""
+        if pending[k] is not None:
+            pending[k].wait()
+            pending[k] = None
+            if rank == 0:
+                expand_outcomes(all_packed[k], world * n, gathered[k])
+
     def one_step(i, ev=None):
         k = i % depth
         with torch.cuda.stream(streams[k]):
+            if dist is not None:
+                finish_gather(k)  # of step i - depth: it has had `depth` rollouts of time to cross xGMI
             if ev is not None:
                 ev[0].record(streams[k])
             batches[k].rollout(SEED + i, from_initial=True)
@@ -165,17 +177,24 @@ def main() -> int:
                 ev[1].record(streams[k])
             if dist is not None:
                 # the path's only exchange: every rank's outcomes into one reward array on rank 0 (RCCL over xGMI).
-                # Ranks ship 2-bit outcome codes (a reward pair is a function of the code) and rank 0 expands them.
+                # Ranks ship 2-bit outcome codes (a reward pair is a function of the code); the collective is
+                # asynchronous, so the stream goes straight on to its next rollout.
                 batches[k].outcomes_tensor(packed[k])
                 if backend == "nccl":
-                    gather_outcomes(dist, packed[k], all_packed[k])
+                    _, pending[k] = gather_outcomes(dist, packed[k], all_packed[k], async_op=True)
                 else:
                     all_packed[k].copy_(gather_outcomes(dist, packed[k].cpu()))
-                if rank == 0:
-                    expand_outcomes(all_packed[k], world * n, gathered[k])
+                    if rank == 0:
+                        expand_outcomes(all_packed[k], world * n, gathered[k])
+
+    def drain():
+        for k in range(depth):
+            with torch.cuda.stream(streams[k]):
+                finish_gather(k)
 
     for i in range(args.warmup):
         one_step(i)
+    drain()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for b in batches:
         b.reset_steps()
@@ -186,6 +205,7 @@ def main() -> int:
         # event pairs around every EVENT_STRIDE-th launch: each record is a marker packet on the stream, and
         # bracketing every launch would cost more than it measures
         one_step(args.warmup + i, events[i] if i % EVENT_STRIDE == 0 else None)
+    drain()  # every step's rewards are in rank 0's array before the clock stops
     barrier()
     elapsed = time.perf_counter() - t0
 

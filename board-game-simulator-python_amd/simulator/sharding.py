@@ -38,10 +38,13 @@ def gather_rewards(dist, local_reward, out=None):
     return out
 
 
-def gather_outcomes(dist, local_packed, out=None):
+def gather_outcomes(dist, local_packed, out=None, async_op: bool = False):
     """All-gather the ranks' packed 2-bit outcome codes (uint8[per_rank / 4] each; per_rank must be a multiple of 4)
     into uint8[world * per_rank / 4], ordered by global game id.  0.25 B per game crosses xGMI instead of the 2 B of
-    an int8[.., 2] reward pair; `simulator.batch.expand_outcomes` turns the result into rewards on the device."""
+    an int8[.., 2] reward pair; `simulator.batch.expand_outcomes` turns the result into rewards on the device.
+
+    async_op=True returns (out, work): the collective then runs beside whatever the caller enqueues next, and
+    `work.wait()` (which only makes the CURRENT stream wait) is due before `out` is read."""
     import torch
 
     world = dist.get_world_size()
@@ -49,8 +52,8 @@ def gather_outcomes(dist, local_packed, out=None):
         out = torch.empty(world * local_packed.numel(), dtype=local_packed.dtype, device=local_packed.device)
     if out.numel() != world * local_packed.numel():
         raise ValueError("gather buffer has the wrong size")
-    dist.all_gather_into_tensor(out, local_packed.contiguous())
-    return out
+    work = dist.all_gather_into_tensor(out, local_packed.contiguous(), async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def sum_steps(dist, local_steps: int, device) -> int:

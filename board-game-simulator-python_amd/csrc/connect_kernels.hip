@@ -202,14 +202,11 @@ __device__ __forceinline__ Lane<G::NW> make_lane(const G& g, const Bits<G::NW>& 
     return l;
 }
 
-// one ply: pick the i-th legal column (ascending), drop, test for a win of the mover, then for a draw.
-// returns the new status byte (0 running, 1 / 2 winner, 3 draw)
+// drop the mover's stone into column `col` (not full), test for a win of the mover, then for a draw, hand the move
+// to the other side; returns the new status byte (0 running, 1 / 2 winner, 3 draw)
 template <class G>
-__device__ __forceinline__ uint32_t play_ply(const G& g, Lane<G::NW>& l, uint32_t draw) {
+__device__ __forceinline__ uint32_t drop_stone(const G& g, Lane<G::NW>& l, int col) {
     const int h = g.h();
-    const uint32_t legal = ~l.full & g.all_columns();
-    const uint32_t n = (uint32_t)__popc(legal);
-    const int col = select_bit(legal, sample_index(draw, n), G::MAXW);
     const uint32_t hx = (uint32_t)(l.hts >> (4 * col)) & 15u;
     set_bit(l.cur, col * (h + 1) + (int)hx);
     l.hts += 1ull << (4 * col);
@@ -224,22 +221,19 @@ __device__ __forceinline__ uint32_t play_ply(const G& g, Lane<G::NW>& l, uint32_
     return st;
 }
 
+// one uniformly sampled ply: the i-th legal column in ascending order
+template <class G>
+__device__ __forceinline__ uint32_t play_ply(const G& g, Lane<G::NW>& l, uint32_t draw) {
+    const uint32_t legal = ~l.full & g.all_columns();
+    const uint32_t n = (uint32_t)__popc(legal);
+    return drop_stone(g, l, select_bit(legal, sample_index(draw, n), G::MAXW));
+}
+
 // a caller-chosen column; returns false (board untouched) when the column is full or out of range
 template <class G>
 __device__ __forceinline__ bool play_column(const G& g, Lane<G::NW>& l, int col, uint32_t& st) {
     if (col < 0 || col >= g.w() || ((l.full >> col) & 1u)) return false;
-    const int h = g.h();
-    const uint32_t hx = (uint32_t)(l.hts >> (4 * col)) & 15u;
-    set_bit(l.cur, col * (h + 1) + (int)hx);
-    l.hts += 1ull << (4 * col);
-    l.full |= (hx + 1u == (uint32_t)h) ? (1u << col) : 0u;
-    const uint32_t mover = l.plies & 1u;
-    const bool won = has_run(g, l.cur);
-    st = won ? mover + 1u : (l.full == g.all_columns() ? BGS_ST_DRAW : BGS_ST_RUNNING);
-    const Bits<G::NW> t = l.cur;
-    l.cur = l.opp;
-    l.opp = t;
-    l.plies += 1u;
+    st = drop_stone(g, l, col);
     return true;
 }
 

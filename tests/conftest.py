@@ -17,6 +17,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once, exactly as the driver does.
+    # The product itself never builds or falls back on its own -- a missing libbgs.so is an ImportError there.
+    if not (os.path.exists(os.path.join(PKG, "libbgs.so")) and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))):
+        import __graft_entry__
+
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")

@@ -338,6 +338,37 @@ struct GenericGame {
     __device__ __forceinline__ void planes(Bits<NW>& p0, Bits<NW>& p1) const { lane_planes(l, p0, p1); }
 };
 
+// (a & b) | c in one VALU instruction (v_bitop3_b32, truth table 0xEA)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// four in a row on a one-word board, written for instruction count (every VALU instruction costs about one issue
+// quad here, whatever its width): per direction two 64-bit shifts, two ANDs for the pairs, and the quads are
+// accumulated with the fused (pairs & shifted pairs) | acc
+__device__ __forceinline__ bool four_in_a_row(uint64_t b, int h) {
+    const int dirs[4] = {1, h + 1, h + 2, h};
+    uint32_t acc_lo = 0, acc_hi = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint64_t s1 = b >> dirs[d];
+        const uint32_t pl = (uint32_t)b & (uint32_t)s1, ph = (uint32_t)(b >> 32) & (uint32_t)(s1 >> 32);
+        const uint64_t pairs = ((uint64_t)ph << 32) | pl;
+        uint64_t s2;  // one v_lshrrev_b64 (hipcc would split this shift of two halves into alignbit + shift)
+        asm("v_lshrrev_b64 %0, %1, %2" : "=v"(s2) : "s"(2 * dirs[d]), "v"(pairs));
+        if (d == 0) {
+            acc_lo = pl & (uint32_t)s2;
+            acc_hi = ph & (uint32_t)(s2 >> 32);
+        } else {
+            acc_lo = and_or(pl, (uint32_t)s2, acc_lo);
+            acc_hi = and_or(ph, (uint32_t)(s2 >> 32), acc_hi);
+        }
+    }
+    return (acc_lo | acc_hi) != 0u;
+}
+
 // board policy B: one-word boards with W <= 8 and H <= 8 (Connect4 6x7).  Column state is one nibble per column,
 // v = (H + 7) - height, so bit 3 of the nibble says "column open"; the i-th open column is found without a loop:
 // a multiply by 0x11111111 turns the open flags into per-nibble prefix counts, and a SWAR compare against the
@@ -382,18 +413,22 @@ struct NibbleGame {
     __device__ __forceinline__ bool ply(const G& g, uint32_t draw) {
         const uint32_t n = (uint32_t)__popc(open);
         const uint32_t idx = sample_index(draw, n);
-        const uint32_t prefix = open * ONES;                              // nibble x: open columns among 0..x
-        const uint32_t t = ((idx * ONES) | 0x88888888u) - prefix;         // nibble x: 8 + idx - prefix[x]
-        const uint32_t col = (uint32_t)__popc(t & 0x88888888u);           // columns with prefix[x] <= idx
+        // nibble x of t: 8 + idx - (open columns among 0..x); (idx - open) * ONES = idx * ONES - open * ONES (mod 2^32)
+        const uint32_t t = (idx - open) * ONES + 0x88888888u;
+        const uint32_t col = (uint32_t)__popc(t & 0x88888888u);           // columns whose prefix count is <= idx
         const uint32_t sh = col * 4u;
         const uint32_t v = (hts >> sh) & 15u;
         const uint32_t bit = (col * (uint32_t)(g.h() + 1) + top(g)) - v;
         cur |= 1ull << bit;
         hts -= 1u << sh;
         open = (hts >> 3) & ONES;
-        Bits<1> b;
-        b.w[0] = cur;
-        won = has_run(g, b);
+        if (g.k() == 4) {
+            won = four_in_a_row(cur, g.h());
+        } else {
+            Bits<1> b;
+            b.w[0] = cur;
+            won = has_run(g, b);
+        }
         const uint64_t tmp = cur;
         cur = opp;
         opp = tmp;
@@ -516,37 +551,6 @@ k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
         }
     }
     add_steps(steps, stepped);
-}
-
-// (a & b) | c in one VALU instruction (v_bitop3_b32, truth table 0xEA)
-__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// four in a row on a one-word board, written for instruction count (every VALU instruction costs about one issue
-// quad here, whatever its width): per direction two 64-bit shifts, two ANDs for the pairs, and the quads are
-// accumulated with the fused (pairs & shifted pairs) | acc
-__device__ __forceinline__ bool four_in_a_row(uint64_t b, int h) {
-    const int dirs[4] = {1, h + 1, h + 2, h};
-    uint32_t acc_lo = 0, acc_hi = 0;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const uint64_t s1 = b >> dirs[d];
-        const uint32_t pl = (uint32_t)b & (uint32_t)s1, ph = (uint32_t)(b >> 32) & (uint32_t)(s1 >> 32);
-        const uint64_t pairs = ((uint64_t)ph << 32) | pl;
-        uint64_t s2;  // one v_lshrrev_b64 (hipcc would split this shift of two halves into alignbit + shift)
-        asm("v_lshrrev_b64 %0, %1, %2" : "=v"(s2) : "s"(2 * dirs[d]), "v"(pairs));
-        if (d == 0) {
-            acc_lo = pl & (uint32_t)s2;
-            acc_hi = ph & (uint32_t)(s2 >> 32);
-        } else {
-            acc_lo = and_or(pl, (uint32_t)s2, acc_lo);
-            acc_hi = and_or(ph, (uint32_t)(s2 >> 32), acc_hi);
-        }
-    }
-    return (acc_lo | acc_hi) != 0u;
 }
 
 // K2a: the same rollout for boards that start from the initial state on a one-word geometry (W <= 8, H <= 8),

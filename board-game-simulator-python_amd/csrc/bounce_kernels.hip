@@ -34,10 +34,15 @@ __device__ __forceinline__ uint32_t value_at(const Board& b, int c) {
            ((uint32_t)((b.v[2] >> c) & 1ull) << 2) | ((uint32_t)((b.v[3] >> c) & 1ull) << 3);
 }
 
-// every legal landing cell of the piece on cell `src` for `player` (SURVEY Appendix B rules 4-5)
+// every legal landing cell of the piece on cell `src` for `player` (SURVEY Appendix B rules 4-5).
+// Walkers only ever stand on interior cells (the start piece, empty interior cells), so a forward step never leaves
+// the board and needs no mask; forward is "<< w" for player 0 and ">> w" for player 1, written as two shifts one of
+// which is by 0, so there is no per-lane select in the step.
 __device__ __forceinline__ uint64_t reach(const BounceGeom& g, const Board& b, uint64_t occ, uint32_t player, int src) {
     const uint64_t empty_interior = ~occ & g.interior;
     const uint64_t landing = empty_interior | (player ? g.goal_bottom : g.goal_top);
+    const uint64_t bounce_on = occ & g.interior;
+    const uint32_t up = player ? 0u : (uint32_t)g.w, down = player ? (uint32_t)g.w : 0u;
     uint64_t pending = 1ull << src, done = 0, targets = 0;
     while (pending) {
         const int c = __ffsll((unsigned long long)pending) - 1;
@@ -46,10 +51,10 @@ __device__ __forceinline__ uint64_t reach(const BounceGeom& g, const Board& b, u
         const uint32_t v = value_at(b, c);
         uint64_t a0 = 1ull << c, al = 0, ar = 0, land = 0;
         for (uint32_t s = 1; s <= v; ++s) {
-            const uint64_t from_any = a0 | al | ar;
-            const uint64_t nf = (player ? (from_any >> g.w) : (from_any << g.w)) & g.all;
-            const uint64_t nl = ((a0 | al) & g.not_col0) >> 1;
-            const uint64_t nr = ((a0 | ar) & g.not_collast) << 1;
+            const uint64_t via_left = a0 | al, via_right = a0 | ar;  // who may go on left / right (no reversal)
+            const uint64_t nf = ((via_left | ar) << up) >> down;
+            const uint64_t nl = (via_left & g.not_col0) >> 1;
+            const uint64_t nr = (via_right & g.not_collast) << 1;
             if (s < v) {
                 a0 = nf & empty_interior;
                 al = nl & empty_interior;
@@ -60,7 +65,7 @@ __device__ __forceinline__ uint64_t reach(const BounceGeom& g, const Board& b, u
             }
         }
         targets |= land & landing;
-        pending |= land & occ & g.interior & ~done;
+        pending |= land & bounce_on & ~done;
     }
     return targets;
 }

@@ -116,7 +116,9 @@ int bgs_read_action_count(bgs_batch* b, int32_t* count);
  * i < width has bit (y*width + x) set for every legal target of the piece in column i of the active row (0 if
  * none); entry [width] is the active row's y (all ones when the board has ended or nothing can move) */
 int bgs_bounce_read_targets(bgs_batch* b, uint64_t* targets);
-/* the same observations into DEVICE memory (no synchronisation): what = 'g' grid, 'l' legal, 'r' reward */
+/* the same observations into DEVICE memory, enqueued on the batch's stream (no synchronisation): what =
+ * 'g' grid int8[n][h][w] (16-byte aligned destination), 'l' Connect legal mask uint8[n][w], 'c' action count int32[n],
+ * 't' Bounce target masks uint64[n][w + 1], 'r' reward int8[n][2] */
 int bgs_export_device(bgs_batch* b, int what, void* device_dst);
 
 /* ---- compact outcomes for the multi-GPU reward gather ------------------------------------------------ */

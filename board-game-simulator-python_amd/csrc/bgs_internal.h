@@ -44,6 +44,7 @@ struct bgs_batch {
     int planes;              // uint64 planes per board
     int num_cus;             // compute units of the device
     int rollout_wps;         // waves per SIMD the fused rollout is sized for
+    int bounce_group;        // lanes per board in the fused Bounce rollout: 8 (default) or 1 (BGS_BOUNCE_GROUP)
     int rollout_generic;     // 1: never take the block-aligned from-initial kernel (A/B timing, BGS_ROLLOUT_GENERIC)
     // device buffers (inside the arena)
     void* arena;

@@ -17,6 +17,8 @@
 // +-1 under an edge mask, "no immediate left<->right reversal" is the rule that a left frontier only feeds forward
 // and left.  Landing on a piece queues that cell; every queued cell is expanded once (its continuation does not
 // depend on how it was reached), which is the closure the recursive search computes.
+#include <type_traits>
+
 #include "bgs_common.h"
 #include "bgs_internal.h"
 
@@ -251,6 +253,29 @@ __device__ __forceinline__ void enumerate(const BounceGeom& g, const Board& b, u
     }
 }
 
+// The same list computed by the 8 lanes that share one board (lane-group mode): lane `sub` of the group searches the
+// piece in column `sub` of the active row, then every lane collects all eight masks (ds_bpermute within the group).
+// The move search of a board is a handful of independent walks; one lane runs them one after the other, eight
+// lanes run them side by side -- a ply then costs one walk, which is what the latency-bound end of a batch needs.
+__device__ __forceinline__ void enumerate_group(const BounceGeom& g, const Board& b, uint64_t occ, uint32_t player, Moves& m) {
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, leader = lane & ~7u;
+    const uint64_t src = movable(g, occ, player);
+    const int first = src ? __ffsll((unsigned long long)src) - 1 : 0;
+    const int row = (int)(((uint32_t)first * g.inv_w) >> 16);
+    m.row_base = (uint32_t)(row * g.w);
+    const int c = (int)(m.row_base + sub) & 63;
+    uint64_t mine = 0;
+    if (sub < (uint32_t)g.w && ((src >> c) & 1ull)) mine = reach(g, b, occ, player, c);
+    m.n = 0;
+#pragma unroll
+    for (int x = 0; x < kMaxTrackedColumns; ++x) {
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, (int)(leader + x), BGS_WAVE);
+        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), (int)(leader + x), BGS_WAVE);
+        m.t[x] = ((uint64_t)hi << 32) | lo;
+        m.n += (uint32_t)__popcll(m.t[x]);
+    }
+}
+
 // the idx-th action of the canonical list (sources by ascending x, targets by ascending cell index)
 __device__ __forceinline__ void pick_from(const Moves& m, uint32_t idx, int& src_cell, int& dst_cell) {
     uint64_t chosen = 0;
@@ -270,7 +295,9 @@ __device__ __forceinline__ void pick_from(const Moves& m, uint32_t idx, int& src
     dst_cell = __ffsll((unsigned long long)chosen) - 1;
 }
 
-template <bool FROM_INITIAL>
+// GL = lanes per board: 1 (a lane owns a board) or 8 (a lane group shares a board; all eight lanes hold the same
+// state and take the same decisions, lane 0 of the group stores)
+template <bool FROM_INITIAL, int GL>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                  uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
@@ -280,6 +307,9 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
     const int64_t end = begin + games_per_wave < n ? begin + games_per_wave : n;
     const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
     uint32_t taken = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool stores = GL == 1 || (lane & (GL - 1)) == 0;           // the lane that owns the board in memory
+    const uint64_t below_group = (1ull << (lane & ~(uint32_t)(GL - 1))) - 1ull;  // lanes below this lane's group
 
     Board b;
     b.v[0] = b.v[1] = b.v[2] = b.v[3] = 0;
@@ -292,9 +322,9 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
 
     for (;;) {
         // ---- refill
-        const uint64_t need = __builtin_amdgcn_ballot_w64(!live);
+        const uint64_t need = __builtin_amdgcn_ballot_w64(!live && stores);  // one bit per idle board slot
         if (need && taken < avail) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t rank = (uint32_t)__popcll(need & below_group);  // the same in every lane of a group
             if (!live && taken + rank < avail) {
                 game = taken + rank;
                 const int64_t i = begin + game;
@@ -312,7 +342,8 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
                 dirty = FROM_INITIAL;
                 have_block = false;
                 if (st == BGS_ST_RUNNING) {
-                    enumerate(g, b, occupancy(b), plies & 1u, mv);
+                    if (GL == 1) enumerate(g, b, occupancy(b), plies & 1u, mv);
+                    else enumerate_group(g, b, occupancy(b), plies & 1u, mv);
                     if (mv.n == 0) {  // a running board whose side to move is blocked: settle it now
                         st = settle_blocked(g, b, plies & 1u);
                         dirty = true;
@@ -340,7 +371,8 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
                 st = mover + 1u;
             } else {
                 const uint64_t occ = occupancy(b);
-                enumerate(g, b, occ, 1u - mover, mv);
+                if (GL == 1) enumerate(g, b, occ, 1u - mover, mv);
+                else enumerate_group(g, b, occ, 1u - mover, mv);
                 if (mv.n == 0) st = count_actions(g, b, occ, mover) ? mover + 1u : BGS_ST_DRAW;
             }
             live = st == BGS_ST_RUNNING && plies < max_plies;
@@ -348,12 +380,14 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
 
         // ---- boards that stopped go to memory
         if (!live && dirty) {
-            const int64_t i = begin + game;
-            store_board(planes, n, i, b);
-            status[i] = (uint8_t)st;
-            plies_buf[i] = (uint16_t)plies;
-            reward[i] = reward_pair(st);
-            stepped += plies - first_ply;
+            if (stores) {
+                const int64_t i = begin + game;
+                store_board(planes, n, i, b);
+                status[i] = (uint8_t)st;
+                plies_buf[i] = (uint16_t)plies;
+                reward[i] = reward_pair(st);
+                stepped += plies - first_ply;
+            }
             dirty = false;
         }
         if (!__builtin_amdgcn_ballot_w64(live) && taken >= avail) break;
@@ -513,19 +547,27 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
     uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
     if (cap > 65535u) cap = 65535u;  // plies are stored as uint16
     if (b->bg.w <= kMaxTrackedColumns && !b->rollout_generic) {
-        const int64_t resident = (int64_t)b->num_cus * 4 * b->rollout_wps;
+        // lane-group mode (8 lanes per board) unless BGS_BOUNCE_GROUP=1 asks for one lane per board
+        const int group = b->bounce_group;
+        const int64_t slots_per_wave = BGS_WAVE / group;
+        const int64_t resident = (int64_t)b->num_cus * 4 * (group == 1 ? b->rollout_wps : 8);
         int64_t per_wave = (b->n + resident - 1) / resident;
-        if (per_wave < BGS_WAVE) per_wave = BGS_WAVE;
+        if (per_wave < slots_per_wave) per_wave = slots_per_wave;
         const int64_t waves = (b->n + per_wave - 1) / per_wave;
         const unsigned blocks = (unsigned)((waves + 3) / 4);
-        if (flags & 1u)
-            hipLaunchKernelGGL((k_bounce_rollout<true>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
-                               b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
-                               cap, b->d_steps, (uint32_t)per_wave);
-        else
-            hipLaunchKernelGGL((k_bounce_rollout<false>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
-                               b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
-                               cap, b->d_steps, (uint32_t)per_wave);
+        auto launch = [&](auto initial_tag, auto group_tag) {
+            constexpr bool INITIAL = decltype(initial_tag)::value;
+            constexpr int GL = decltype(group_tag)::value;
+            hipLaunchKernelGGL((k_bounce_rollout<INITIAL, GL>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, b->bg,
+                               b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
+                               b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+        };
+        auto with_group = [&](auto initial_tag) {
+            if (group == 1) launch(initial_tag, std::integral_constant<int, 1>{});
+            else launch(initial_tag, std::integral_constant<int, 8>{});
+        };
+        if (flags & 1u) with_group(std::true_type{});
+        else with_group(std::false_type{});
         return;
     }
     // wider boards: one lane per board, two-pass enumeration

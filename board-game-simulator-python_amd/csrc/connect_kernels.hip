@@ -574,6 +574,11 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
     const int64_t end = begin + games_per_wave < n ? begin + games_per_wave : n;
     const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
     uint32_t taken = 0;
+    // the chunk's slices of the batch arrays (wave-uniform bases; lanes index them with their 32-bit game offset)
+    uint64_t* __restrict__ const plane0 = planes + begin;
+    uint64_t* __restrict__ const plane1 = planes + n + begin;
+    uint8_t* __restrict__ const status_out = status + begin;
+    uint16_t* __restrict__ const reward_out = reward + begin;
 
     uint64_t p[2] = {0, 0};      // stones of player 0 / player 1
     uint32_t hts = 0;            // nibble per column: (H + 7) - height; bit 3 = column open
@@ -598,11 +603,10 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
                 st = 0;
                 live = (!CAPPED || max_plies > 0u) ? 1u : 0u;
                 if (CAPPED && live == 0) {  // max_plies == 0: the boards still have to be written once
-                    const int64_t i = begin + game;
-                    planes[i] = 0;
-                    planes[n + i] = 0;
-                    status[i] = 0;
-                    reward[i] = 0;
+                    plane0[game] = 0;
+                    plane1[game] = 0;
+                    status_out[game] = 0;
+                    reward_out[game] = 0;
                 }
             }
             const uint32_t wanted = (uint32_t)__popcll(need);
@@ -648,12 +652,12 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
 
         // ---- boards that ended in this block go to memory
         if (was_live != 0 && live == 0) {
-            const int64_t i = begin + game;
             const uint32_t code = st ? st : (open == 0u ? BGS_ST_DRAW : BGS_ST_RUNNING);
-            planes[i] = p[0];
-            planes[n + i] = p[1];
-            status[i] = (uint8_t)code;
-            reward[i] = reward_pair(code);
+            // scalar base + 32-bit byte offset: the addressing mode that needs no 64-bit VALU arithmetic per lane
+            *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane0) + (game * 8u)) = p[0];
+            *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane1) + (game * 8u)) = p[1];
+            *(reinterpret_cast<uint8_t*>(status_out) + game) = (uint8_t)code;
+            *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(reward_out) + (game * 2u)) = reward_pair(code);
         }
     } while (__builtin_amdgcn_ballot_w64(live != 0) || taken < avail);
     add_steps(steps, stepped);

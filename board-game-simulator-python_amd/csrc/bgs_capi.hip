@@ -204,7 +204,17 @@ int device_facts(bgs_batch* b) {
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
     b->num_cus = cus > 0 ? cus : 256;
-    b->rollout_wps = 4;  // 4 waves per SIMD: 4 games per lane at 2^20 boards (lane refill needs several)
+    // Waves per SIMD of the fused rollout.  Instruction issue is the bound, so what matters is games per lane (lane
+    // refill wastes about half a game per lane at the end of a launch): aim for >= 4 games per lane, between 1 and 4
+    // waves per SIMD; one-word boards have short games and keep at least 2 waves for latency hiding.
+    {
+        const int64_t lanes_per_wps = (int64_t)b->num_cus * 4 * BGS_WAVE;
+        int64_t wps = b->n / (lanes_per_wps * 4);
+        const int64_t floor_wps = (b->game == BGS_GAME_CONNECT && b->cg.nw == 1) ? 2 : 1;
+        if (wps < floor_wps) wps = floor_wps;
+        if (wps > 4) wps = 4;
+        b->rollout_wps = (int)wps;
+    }
     if (const char* env = getenv("BGS_ROLLOUT_WPS")) {
         const int v = atoi(env);
         if (v >= 1 && v <= 8) b->rollout_wps = v;

@@ -663,6 +663,98 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
     add_steps(steps, stepped);
 }
 
+// K2b: the block-aligned, branch-free rollout for every other geometry (multi-word planes, up to 16 columns, up to 15
+// rows).  Same structure as K2a; column state is a nibble of height per column (64 bits) plus "column open" flags
+// kept nibble-spread in two 32-bit halves (columns 0-7 and 8-15), so the idx-th open column is one SWAR select inside
+// the half that holds it.
+template <class G, bool CAPPED>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_rollout_aligned_wide(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
+                               uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game,
+                               uint32_t max_plies, unsigned long long* __restrict__ steps, uint32_t games_per_wave) {
+    constexpr int NW = G::NW;
+    constexpr uint32_t ONES = 0x11111111u;
+    const int h = g.h(), w = g.w();
+    const uint32_t open_lo0 = w >= 8 ? ONES : (ONES & ((1u << (4 * w)) - 1u));
+    const uint32_t open_hi0 = w <= 8 ? 0u : (w >= 16 ? ONES : (ONES & ((1u << (4 * (w - 8))) - 1u)));
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
+    const int64_t begin = (int64_t)wave * games_per_wave;
+    const int64_t end = begin + games_per_wave < n ? begin + games_per_wave : n;
+    const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
+    uint32_t taken = 0;
+
+    Bits<NW> p[2] = {zero_bits<NW>(), zero_bits<NW>()};  // stones of player 0 / player 1
+    uint64_t hts = 0;                                      // nibble per column: its height
+    uint32_t open_lo = 0, open_hi = 0;                     // nibble-spread "column open" flags
+    uint32_t blk = 0, st = 0, game = 0, stepped = 0;
+    uint64_t live = 0;
+
+    if (avail == 0u) return;
+    do {
+        const uint64_t need = __builtin_amdgcn_ballot_w64(live == 0);
+        if (need && taken < avail) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (live == 0 && taken + rank < avail) {
+                game = taken + rank;
+                p[0] = zero_bits<NW>();
+                p[1] = zero_bits<NW>();
+                hts = 0;
+                open_lo = open_lo0;
+                open_hi = open_hi0;
+                blk = 0;
+                st = 0;
+                live = (!CAPPED || max_plies > 0u) ? 1u : 0u;
+                if (CAPPED && live == 0) {
+                    store_planes<NW>(planes, n, begin + game, p[0], p[1]);
+                    status[begin + game] = 0;
+                    reward[begin + game] = 0;
+                }
+            }
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            taken = avail - taken < wanted ? avail : taken + wanted;
+        }
+
+        const uint64_t was_live = live;
+        const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t count_lo = (uint32_t)__popc(open_lo);
+            const uint32_t idx = sample_index(draws.v[j], count_lo + (uint32_t)__popc(open_hi));
+            const bool in_lo = idx < count_lo;
+            const uint32_t part = in_lo ? open_lo : open_hi;
+            const uint32_t rank_in_part = in_lo ? idx : idx - count_lo;
+            const uint32_t cmp = (rank_in_part - part) * ONES + 0x88888888u;  // nibble x: 8 + rank - (open among 0..x)
+            const uint32_t col = ((uint32_t)__popc(cmp & 0x88888888u) & 7u) + (in_lo ? 0u : 8u);
+            const uint32_t v = (uint32_t)(hts >> (4u * col)) & 15u;
+            const uint32_t pos = col * (uint32_t)(h + 1) + v;
+            Bits<NW>& mine = p[j & 1u];
+            const uint64_t stone = live << (pos & 63u);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) mine.w[i] |= ((pos >> 6) == (uint32_t)i) ? stone : 0ull;
+            hts += live << (4u * col);
+            const uint32_t filled = (live != 0 && v + 1u == (uint32_t)h) ? (1u << (4u * (col & 7u))) : 0u;
+            open_lo &= ~(in_lo ? filled : 0u);
+            open_hi &= ~(in_lo ? 0u : filled);
+            const bool won = has_run(g, mine);
+            stepped += (uint32_t)live;
+            st = (live != 0 && won) ? (j & 1u) + 1u : st;
+            live = (won || (open_lo | open_hi) == 0u) ? 0 : live;
+            if (CAPPED) live = (4u * blk + j + 1u < max_plies) ? live : 0;
+        }
+        blk += 1u;
+
+        if (was_live != 0 && live == 0) {
+            const int64_t i = begin + game;
+            const uint32_t code = st ? st : ((open_lo | open_hi) == 0u ? BGS_ST_DRAW : BGS_ST_RUNNING);
+            store_planes<NW>(planes, n, i, p[0], p[1]);
+            status[i] = (uint8_t)code;
+            reward[i] = reward_pair(code);
+        }
+    } while (__builtin_amdgcn_ballot_w64(live != 0) || taken < avail);
+    add_steps(steps, stepped);
+}
+
 // K4: packed planes -> reference layout int8[n][H][W] (row 0 = bottom; -1 empty, 0, 1).  One lane expands one board
 // into the workgroup's LDS tile (256 boards x H*W bytes, already in output order); the workgroup then streams the
 // tile to HBM with 16-byte stores.
@@ -873,6 +965,17 @@ void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
                 return;
             }
             if (nibble_ok) { with_game(Tag<NibbleGame<G>>{}); return; }
+        }
+        if ((flags & 1u) && !b->rollout_generic) {
+            if (capped)
+                hipLaunchKernelGGL((k_connect_rollout_aligned_wide<G, true>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream,
+                                   g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
+                                   b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+            else
+                hipLaunchKernelGGL((k_connect_rollout_aligned_wide<G, false>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream,
+                                   g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
+                                   b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+            return;
         }
         with_game(Tag<GenericGame<G>>{});
     });

@@ -1,1 +1,5 @@
-from .protocol import ConfigLike, StateLike, ActionLike  # noqa: F401
+"""Game modules of the drop-in package: `connect`, `bounce` (HIP-backed), and the structural types they satisfy."""
+
+from .protocol import ActionLike, ConfigLike, StateLike
+
+__all__ = ["ActionLike", "ConfigLike", "StateLike"]

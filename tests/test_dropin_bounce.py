@@ -115,3 +115,22 @@ def test_random_playthrough_matches_oracle(fx):
             plies += 1
         assert bool(orc.ended[0]) == state.has_ended
         np.testing.assert_array_equal(state.reward, orc.reward[0])
+
+
+def test_json_of_terminal_states(fx):
+    from simulator.game.bounce import Action, Config, State
+
+    test = fx["tests"][0]  # test_small: player 1 reaches the bottom row
+    state = None
+    for pos in test["positions"]:
+        state, action = assert_state(pos, state)
+        state = action.sample_next_state()
+    assert state.has_ended and state.reward.tolist() == [-1, 1]
+    j = state.to_json()
+    assert j["winner"] == 1
+    back = State.from_json(j, state.config)
+    assert back == state and back.has_ended and back.actions == [] and back.reward.tolist() == [-1, 1]
+    with pytest.raises(RuntimeError):
+        Action.from_json({"source": [0, 1], "target": [0, 2]}, back)
+    with pytest.raises(RuntimeError):
+        State.from_json({"grid": [[0, 0, 0]], "player": 0, "winner": -1}, state.config)

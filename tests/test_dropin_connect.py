@@ -122,3 +122,36 @@ def test_readme_loop_matches_oracle():
         assert orc.ended[0]
         np.testing.assert_array_equal(state.grid, orc.grid[0])
         np.testing.assert_array_equal(state.reward, orc.reward[0])
+
+
+def test_json_of_terminal_and_illegal_inputs():
+    from simulator.game.connect import Action, Config, State
+
+    config = Config(2, 2, 3)  # can only be drawn
+    state = config.sample_initial_state()
+    for col in (0, 0, 1, 1):
+        state = state.action_at(col).sample_next_state()
+    assert state.has_ended and state.reward.tolist() == [0, 0] and state.actions == []
+    j = state.to_json()
+    assert j["winner"] == 2 and j["player"] == 0
+    again = State.from_json(j, config)
+    assert again == state and again.has_ended and again.actions == []
+    # a finished game: winner survives the round trip, further moves are refused
+    config = Config(6, 7, 4)
+    state = config.sample_initial_state()
+    for col in (0, 1, 0, 1, 0, 1, 0):
+        state = state.action_at(col).sample_next_state()
+    assert state.has_ended and state.reward.tolist() == [1, -1]
+    back = State.from_json(state.to_json(), config)
+    assert back == state and back.reward.tolist() == [1, -1]
+    with pytest.raises(RuntimeError):
+        Action.from_json({"column": 3}, back)
+    # malformed states are refused by the device-side validation
+    bad = state.to_json()
+    bad["grid"][5][6] = 0  # floating stone
+    with pytest.raises(RuntimeError):
+        State.from_json(bad, config)
+    with pytest.raises(RuntimeError):
+        State.from_json({"grid": [[0]], "player": 0, "winner": -1}, config)
+    with pytest.raises(RuntimeError):
+        Action.from_json({"col": 1}, config.sample_initial_state())

@@ -56,7 +56,9 @@ Layout layout_for(int planes, int64_t n, int h, int w) {
     size_t per_board = (size_t)h * w;
     if (per_board < (size_t)8 * (w + 1)) per_board = (size_t)8 * (w + 1);
     if (per_board < 16) per_board = 16;
-    l.staging_bytes = (size_t)n * (per_board + 16) + 8 * kAlign;
+    // unpack / pack scratch for every board, plus bgs_transition's in-block and out-block (object API: <= 4096 boards)
+    const size_t small = n < 4096 ? (size_t)n : 4096;
+    l.staging_bytes = (size_t)n * (per_board + 16) + small * (2 * per_board + 80) + 8 * kAlign;
     l.staging = off; off += align_up(l.staging_bytes);
     l.total = off;
     return l;
@@ -685,6 +687,95 @@ int bgs_write_state(bgs_batch* b, const int8_t* grid, const int8_t* player, cons
     if (rc) return rc;
     if (status) return to_host(b, status, dr, (size_t)b->n);
     HIP_TRY(hipStreamSynchronize(b->stream));
+    return BGS_OK;
+}
+
+int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const int8_t* winner, const int32_t* plies,
+                   const int32_t* actions, int32_t* status, int8_t* grid_out, int8_t* player_out, int8_t* winner_out,
+                   int32_t* plies_out, void* legal_out) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(status && grid_out && player_out && winner_out && plies_out && legal_out, "output pointer is NULL");
+    NEED(b->n <= 4096, "bgs_transition serves the object API: batches of at most 4096 boards");
+    const bool connect = b->game == BGS_GAME_CONNECT;
+    const size_t n = (size_t)b->n;
+    const size_t hw = connect ? (size_t)b->cg.h * b->cg.w : (size_t)b->bg.h * b->bg.w;
+    const size_t per_action = connect ? 1 : 4;
+    const size_t legal_bytes = connect ? n * b->cg.w : n * 8 * ((size_t)b->bg.w + 1);
+    auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+    // in-block: [grid][player][winner][plies][actions]; out-block: [load status][step status][grid][player][winner][plies][legal]
+    const size_t in_grid = 0, in_player = up8(n * hw), in_winner = in_player + up8(n), in_plies = in_winner + up8(n),
+                 in_actions = in_plies + 4 * n, in_bytes = in_actions + 4 * n * per_action;
+    const size_t out_load = 0, out_step = 4 * n, out_legal = up8(out_step + 4 * n),
+                 out_grid = (out_legal + legal_bytes + 15) & ~(size_t)15,  // the unpack tile store needs 16-byte alignment
+                
+                 out_player = up8(out_grid + n * hw), out_winner = out_player + up8(n), out_plies = out_winner + up8(n),
+                 out_bytes = out_plies + 4 * n;
+    Stage st(b);
+    uint8_t* d_in = st.take<uint8_t>(in_bytes);
+    uint8_t* d_out = st.take<uint8_t>(out_bytes);
+    NEED(d_in && d_out, "staging buffer too small");
+    if (!b->pinned[0]) {
+        HIP_TRY(hipHostMalloc(&b->pinned[0], kPinnedChunk, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&b->pinned[1], kPinnedChunk, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&b->pinned_done[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b->pinned_done[1], hipEventDisableTiming));
+    }
+    NEED(in_bytes <= kPinnedChunk && out_bytes <= kPinnedChunk, "batch too large for bgs_transition");
+    uint8_t* h_in = static_cast<uint8_t*>(b->pinned[0]);
+    uint8_t* h_out = static_cast<uint8_t*>(b->pinned[1]);
+    const bool load = grid != nullptr;
+    if (load) {
+        NEED(player != nullptr && winner != nullptr, "player and winner are required with a grid");
+        memcpy(h_in + in_grid, grid, n * hw);
+        memcpy(h_in + in_player, player, n);
+        memcpy(h_in + in_winner, winner, n);
+        if (plies) memcpy(h_in + in_plies, plies, 4 * n);
+    }
+    if (actions) memcpy(h_in + in_actions, actions, 4 * n * per_action);
+    if (load || actions) HIP_TRY(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, b->stream));
+    int32_t* d_load = reinterpret_cast<int32_t*>(d_out + out_load);
+    int32_t* d_step = reinterpret_cast<int32_t*>(d_out + out_step);
+    HIP_TRY(hipMemsetAsync(d_out, 0, 8 * n, b->stream));
+    if (load) {
+        const int8_t* dg = reinterpret_cast<const int8_t*>(d_in + in_grid);
+        const int8_t* dp = reinterpret_cast<const int8_t*>(d_in + in_player);
+        const int8_t* dw = reinterpret_cast<const int8_t*>(d_in + in_winner);
+        const int32_t* dl = plies ? reinterpret_cast<const int32_t*>(d_in + in_plies) : nullptr;
+        if (connect) bgs::connect_pack(b, dg, dp, dw, d_load);
+        else bgs::bounce_pack(b, dg, dp, dw, dl, d_load);
+    }
+    if (actions) {
+        const int32_t* da = reinterpret_cast<const int32_t*>(d_in + in_actions);
+        if (connect) bgs::connect_step_actions(b, da, d_step);
+        else bgs::bounce_step_actions(b, da, d_step);
+    }
+    int8_t* og = reinterpret_cast<int8_t*>(d_out + out_grid);
+    int8_t* op = reinterpret_cast<int8_t*>(d_out + out_player);
+    int8_t* ow = reinterpret_cast<int8_t*>(d_out + out_winner);
+    int32_t* ol = reinterpret_cast<int32_t*>(d_out + out_plies);
+    if (connect) {
+        bgs::connect_unpack_grid(b, og);
+        bgs::connect_meta(b, op, nullptr, ow, ol);
+        bgs::connect_legal(b, d_out + out_legal, nullptr);
+    } else {
+        bgs::bounce_unpack_grid(b, og);
+        bgs::bounce_meta(b, op, nullptr, ow, ol);
+        bgs::bounce_targets(b, reinterpret_cast<uint64_t*>(d_out + out_legal), nullptr);
+    }
+    rc = finish_launch();
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    // a malformed board was left untouched and an illegal move changed nothing: report the first problem per board
+    const int32_t* load_status = reinterpret_cast<const int32_t*>(h_out + out_load);
+    const int32_t* step_status = reinterpret_cast<const int32_t*>(h_out + out_step);
+    for (size_t i = 0; i < n; ++i) status[i] = load_status[i] ? load_status[i] : step_status[i];
+    memcpy(grid_out, h_out + out_grid, n * hw);
+    memcpy(player_out, h_out + out_player, n);
+    memcpy(winner_out, h_out + out_winner, n);
+    memcpy(plies_out, h_out + out_plies, 4 * n);
+    memcpy(legal_out, h_out + out_legal, legal_bytes);
     return BGS_OK;
 }
 

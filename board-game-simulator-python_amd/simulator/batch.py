@@ -187,6 +187,48 @@ class _Batch:
         )
         return status
 
+    def transition(self, grid=None, player=None, winner=None, plies=None, actions=None):
+        """One round trip for the object API: optionally load boards, optionally apply one chosen move per board, then
+        observe.  Returns (status int32[n], grid, player, winner, plies, legal) with `legal` the Connect mask
+        uint8[n, W] or the Bounce target masks uint64[n, W + 1]."""
+        n = self.n
+        i8 = ctypes.c_int8
+        g = p = w = l = a = None
+        if grid is not None:
+            g = np.ascontiguousarray(grid, dtype=np.int8)
+            if g.shape != (n, self.height, self.width):
+                raise TypeError(f"grid must have shape {(n, self.height, self.width)}, got {g.shape}")
+            p = np.ascontiguousarray(player, dtype=np.int8)
+            w = np.ascontiguousarray(winner, dtype=np.int8)
+            l = None if plies is None else np.ascontiguousarray(plies, dtype=np.int32)
+        if actions is not None:
+            a = np.ascontiguousarray(actions, dtype=np.int32)
+            if a.size != n * self._action_width:
+                raise TypeError(f"expected {n * self._action_width} action entries, got {a.size}")
+        status = np.zeros(n, dtype=np.int32)
+        grid_out = np.empty((n, self.height, self.width), dtype=np.int8)
+        player_out = np.empty(n, dtype=np.int8)
+        winner_out = np.empty(n, dtype=np.int8)
+        plies_out = np.empty(n, dtype=np.int32)
+        legal_out = self._empty_legal()
+        _abi.check(
+            _abi.lib().bgs_transition(
+                self._handle,
+                None if g is None else _ptr(g, i8),
+                None if p is None else _ptr(p, i8),
+                None if w is None else _ptr(w, i8),
+                None if l is None else _ptr(l, ctypes.c_int32),
+                None if a is None else _ptr(a, ctypes.c_int32),
+                _ptr(status, ctypes.c_int32),
+                _ptr(grid_out, i8),
+                _ptr(player_out, i8),
+                _ptr(winner_out, i8),
+                _ptr(plies_out, ctypes.c_int32),
+                ctypes.c_void_p(legal_out.ctypes.data),
+            )
+        )
+        return status, grid_out, player_out, winner_out, plies_out, legal_out
+
     # ---- device-side hand-over (torch / RCCL plumbing) -----------------------------------------------
     def buffer(self, buffer_id: int):
         """(device pointer, bytes) of one of the batch's buffers (see bgs_buffer_id in include/bgs.h)."""
@@ -256,6 +298,10 @@ class ConnectBatch(_Batch):
     """N Connect-k boards: ``Config(height, width, count)`` (reference connect.cpp:26) times n."""
 
     game = _abi.GAME_CONNECT
+    _action_width = 1
+
+    def _empty_legal(self):
+        return np.empty((self.n, self.width), dtype=np.uint8)
 
     def __init__(self, height: int, width: int, count: int, n: int, device: int = 0, use_torch: Optional[bool] = None):
         super().__init__(n, height, width, device, use_torch)
@@ -294,6 +340,10 @@ class BounceBatch(_Batch):
     """N Bounce boards sharing one start grid: ``Config(grid)`` (reference bounce.cpp:26) times n."""
 
     game = _abi.GAME_BOUNCE
+    _action_width = 4
+
+    def _empty_legal(self):
+        return np.empty((self.n, self.width + 1), dtype=np.uint64)
 
     def __init__(self, grid, n: int, device: int = 0, use_torch: Optional[bool] = None):
         cfg = np.ascontiguousarray(grid)

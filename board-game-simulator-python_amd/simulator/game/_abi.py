@@ -75,6 +75,10 @@ SIGNATURES = {
     "bgs_export_device": (ctypes.c_int, [c_handle, ctypes.c_int, ctypes.c_void_p]),
     "bgs_pack_outcomes": (ctypes.c_int, [c_handle, ctypes.c_void_p]),
     "bgs_expand_outcomes": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "bgs_transition": (
+        ctypes.c_int,
+        [c_handle, _i8p, _i8p, _i8p, _i32p, _i32p, _i32p, _i8p, _i8p, _i8p, _i32p, ctypes.c_void_p],
+    ),
     "bgs_write_state": (ctypes.c_int, [c_handle, _i8p, _i8p, _i8p, _i32p, _i32p]),
 }
 

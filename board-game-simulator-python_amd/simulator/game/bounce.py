@@ -17,6 +17,7 @@ from typing import Any, ClassVar, Dict, List, Tuple
 
 import numpy as np
 
+from . import _abi
 from ._value import ValueObject
 from ..batch import BounceBatch
 
@@ -51,49 +52,47 @@ class _Engine:
                 eng = cls._cache[key] = _Engine(grid)
             return eng
 
-    def _observe(self):
+    def _round_trip(self, grid=None, player=0, winner=-1, plies=0, move=None):
+        """One fused call (bgs_transition): optional load, optional move, then the observations a State needs."""
         b = self.batch
-        grid = b.grid[0]
-        player, winner, plies = int(b.player[0]), int(b.winner[0]), int(b.plies[0])
-        masks = b.targets[0]
+        status, g, p, w, l, masks = b.transition(
+            None if grid is None else grid[None],
+            None if grid is None else np.array([player], dtype=np.int8),
+            None if grid is None else np.array([winner], dtype=np.int8),
+            None if grid is None else np.array([plies], dtype=np.int32),
+            None if move is None else np.array([move], dtype=np.int32),
+        )
+        if status[0] == _abi.BGS_ERR_ILLEGAL:
+            raise RuntimeError(f"illegal action: {tuple(move[:2])} -> {tuple(move[2:])}")
+        if status[0] != 0:
+            raise RuntimeError("malformed Bounce state")
+        grid_out, player_out, winner_out, plies_out = g[0], int(p[0]), int(w[0]), int(l[0])
         width = b.width
         moves: List[Tuple[Cell, Cell]] = []
-        if winner == -1 and int(masks[width]) < b.height:
-            row = int(masks[width])  # the active row, as reported by the device
+        row = int(masks[0, width])
+        if winner_out == -1 and row < b.height:  # the active row, as reported by the device
             for x in range(width):
-                m = int(masks[x])
+                m = int(masks[0, x])
                 c = 0
                 while m:
                     if m & 1:
                         moves.append(((x, row), (c % width, c // width)))
                     m >>= 1
                     c += 1
-        return grid, player, winner, plies, tuple(moves)
+        return grid_out, player_out, winner_out, plies_out, tuple(moves)
 
     def initial(self):
         with self.lock:
             self.batch.reset()
-            return self._observe()
-
-    def _load(self, grid, player, winner, plies):
-        status = self.batch.write_state(
-            grid[None], np.array([player], dtype=np.int8), np.array([winner], dtype=np.int8), np.array([plies], dtype=np.int32)
-        )
-        if status[0] != 0:
-            raise RuntimeError("malformed Bounce state")
+            return self._round_trip()
 
     def load(self, grid, player, winner, plies):
         with self.lock:
-            self._load(grid, player, winner, plies)
-            return self._observe()
+            return self._round_trip(grid, player, winner, plies)
 
     def after(self, grid, player, winner, plies, source: Cell, target: Cell):
         with self.lock:
-            self._load(grid, player, winner, plies)
-            status = self.batch.step_actions(np.array([[source[0], source[1], target[0], target[1]]], dtype=np.int32))
-            if status[0] != 0:
-                raise RuntimeError(f"illegal action: {source} -> {target}")
-            return self._observe()
+            return self._round_trip(grid, player, winner, plies, (source[0], source[1], target[0], target[1]))
 
 
 class Config(ValueObject):

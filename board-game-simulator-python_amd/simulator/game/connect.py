@@ -44,34 +44,34 @@ class _Engine:
                 eng = cls._cache[key] = _Engine(height, width, count)
             return eng
 
-    def _observe(self):
+    def _round_trip(self, grid=None, player=0, winner=-1, column=None):
+        """One fused call (bgs_transition): optional load, optional move, then the observations a State needs."""
         b = self.batch
-        grid = b.grid[0]
-        legal = tuple(int(c) for c in np.flatnonzero(b.legal[0]))
-        return grid, int(b.player[0]), int(b.winner[0]), legal
+        status, g, p, w, _, legal = b.transition(
+            None if grid is None else grid[None],
+            None if grid is None else np.array([player], dtype=np.int8),
+            None if grid is None else np.array([winner], dtype=np.int8),
+            None,
+            None if column is None else np.array([column], dtype=np.int32),
+        )
+        if status[0] == _abi.BGS_ERR_ILLEGAL:
+            raise RuntimeError(f"illegal action: column {column}")
+        if status[0] != 0:
+            raise RuntimeError("malformed Connect state")
+        return g[0], int(p[0]), int(w[0]), tuple(int(c) for c in np.flatnonzero(legal[0]))
 
     def initial(self):
         with self.lock:
             self.batch.reset()
-            return self._observe()
+            return self._round_trip()
 
     def load(self, grid: np.ndarray, player: int, winner: int):
         with self.lock:
-            self._load(grid, player, winner)
-            return self._observe()
-
-    def _load(self, grid, player, winner):
-        status = self.batch.write_state(grid[None], np.array([player], dtype=np.int8), np.array([winner], dtype=np.int8))
-        if status[0] != 0:
-            raise RuntimeError("malformed Connect state")
+            return self._round_trip(grid, player, winner)
 
     def after(self, grid: np.ndarray, player: int, winner: int, column: int):
         with self.lock:
-            self._load(grid, player, winner)
-            status = self.batch.step_actions(np.array([column], dtype=np.int32))
-            if status[0] != 0:
-                raise RuntimeError(f"illegal action: column {column}")
-            return self._observe()
+            return self._round_trip(grid, player, winner, column)
 
 
 class Config(ValueObject):

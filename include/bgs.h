@@ -136,6 +136,18 @@ int bgs_expand_outcomes(int device, void* hip_stream, const void* device_packed,
 int bgs_write_state(bgs_batch* b, const int8_t* grid, const int8_t* player, const int8_t* winner,
                     const int32_t* plies, int32_t* status);
 
+/* ---- one round trip for the object API -------------------------------------------------------------- */
+/* What one `State` / `Action` operation of the reference needs (connect.cpp:39-46,52; bounce.cpp:36-45,51), fused
+ * into one upload, one launch sequence, one download and one synchronisation (batches of at most 4096 boards):
+ *   grid != NULL     load the boards first (as bgs_write_state; player and winner required, plies optional);
+ *   actions != NULL  then apply one caller-chosen move per board (as bgs_step_actions; negative first entry skips);
+ *   then observe: grid int8[n][h][w], player int8[n], winner int8[n], plies int32[n] and the legal moves of the side
+ *   to move -- Connect: uint8[n][width] mask, Bounce: uint64[n][width + 1] target masks (bgs_bounce_read_targets).
+ * status int32[n]: 0, BGS_ERR_ARG (malformed board: nothing loaded) or BGS_ERR_ILLEGAL (move refused). */
+int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const int8_t* winner, const int32_t* plies,
+                   const int32_t* actions, int32_t* status, int8_t* grid_out, int8_t* player_out, int8_t* winner_out,
+                   int32_t* plies_out, void* legal_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -433,3 +433,47 @@ def test_outcome_codes_roundtrip(batch_mod):
         reward = batch_mod.expand_outcomes(codes, n)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(reward.cpu().numpy(), dev.reward)
+
+
+def test_transition_round_trip_matches_separate_calls(batch_mod):
+    """bgs_transition (load + move + observe in one round trip) against the oracle, Connect and Bounce."""
+    rng = np.random.default_rng(21)
+    n = 700
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    for _ in range(11):
+        orc.step_random(SEED)
+    dev = batch_mod.ConnectBatch(6, 7, 4, n)
+    cols = rng.integers(-1, 8, size=n).astype(np.int32)
+    status, grid, player, winner, plies, legal = dev.transition(orc.grid, orc.player, orc.winner, None, cols)
+    np.testing.assert_array_equal(status, orc.step_actions(cols))
+    np.testing.assert_array_equal(grid, orc.grid)
+    np.testing.assert_array_equal(player, orc.player)
+    np.testing.assert_array_equal(winner, orc.winner)
+    np.testing.assert_array_equal(plies, orc.plies)
+    np.testing.assert_array_equal(legal, orc.legal())
+    # malformed boards are reported and leave the previous board in place
+    bad = orc.grid.copy()
+    bad[0, 5, 0] = 1 if bad[0, 4, 0] == -1 else bad[0, 5, 0]
+    bad[1, 0, 0] = 7
+    status2, grid2, *_ = dev.transition(bad, orc.player, orc.winner)
+    assert status2[1] == -1 and (status2[2:] == 0).all()
+    np.testing.assert_array_equal(grid2[1], orc.grid[1])
+
+    bo = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+    for _ in range(5):
+        bo.step_random(SEED)
+    bd = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+    moves = np.full((n, 4), -1, dtype=np.int32)
+    for i in range(n):
+        acts = bo.actions(i)
+        if acts and rng.random() < 0.8:
+            (sx, sy), (tx, ty) = acts[rng.integers(len(acts))]
+            moves[i] = [sx, sy, tx, ty]
+        elif rng.random() < 0.5:
+            moves[i] = rng.integers(0, 9, size=4)
+    status, grid, player, winner, plies, masks = bd.transition(bo.grid, bo.player, bo.winner, bo.plies, moves)
+    np.testing.assert_array_equal(status, bo.step_actions(moves))
+    np.testing.assert_array_equal(grid, bo.grid)
+    np.testing.assert_array_equal(winner, bo.winner)
+    np.testing.assert_array_equal(plies, bo.plies)
+    np.testing.assert_array_equal(masks, bd.targets)

@@ -6,7 +6,7 @@ Config.sample_initial_state() to its terminal state with uniformly sampled actio
 transition -> k-in-a-row / draw -> reward), fused in one HIP launch (k_connect_rollout).  env-steps are the
 transitions applied to running boards (masked no-ops are not counted); they are counted on the device.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -88,8 +88,8 @@ def cpu_baseline(torch, last_seed, device_reward_head):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="boards per GPU (default 2^20)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches in flight per GPU: step i runs on batch i %% D / HIP stream i %% D, so the drain of one "

@@ -294,9 +294,24 @@ def main() -> int:
                 "than ms_per_step",
             },
         }
-        if not args.no_cpu_baseline and world == 1:
-            last = args.warmup + args.steps - 1
-            head = batches[last % depth].reward[:65536]
+        last = args.warmup + args.steps - 1
+        head = batches[last % depth].reward[:65536] if (world == 1 and not args.no_cpu_baseline) else None
+        if world == 1 and depth > 1:
+            # for comparison, outside the timed region above: the same launches strictly one after the other on one
+            # stream (what a caller sees who waits for each batch before starting the next)
+            solo = batches[0]
+            reps = min(args.steps, 40)
+            solo.reset_steps()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            with torch.cuda.stream(streams[0]):
+                for i in range(reps):
+                    solo.rollout(SEED + 5000 + i, from_initial=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            out["one_launch_at_a_time"] = {"value": solo.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / reps * 1e3,
+                                           "steps": reps}
+        if head is not None:
             out["cpu_baseline"] = cpu_baseline(torch, SEED + last, head)
         print(json.dumps(out), flush=True)
 

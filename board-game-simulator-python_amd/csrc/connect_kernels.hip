@@ -558,7 +558,7 @@ k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
 // sub-step j is player j & 1: no plane swap, no ply counter.  A lane that is not playing executes the same
 // instructions with `live` = 0 -- the stone it drops is (live << position) = 0 -- so the four plies of a block and
 // the philox call in front of them form ONE basic block for the scheduler; only refill and store are conditional.
-template <class G, bool CAPPED>
+template <class G, bool CAPPED, bool FROM_INITIAL>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                           int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
@@ -586,6 +586,7 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
     uint64_t live = 0;           // 1 while this lane's game is running (64-bit: it is shifted into the planes)
     uint32_t st = 0;             // winner code once somebody won
     uint32_t game = 0;           // offset of this lane's game in the wave's chunk
+    uint32_t skip = 0;           // loaded boards: sub-steps to sit out in the first block (= plies already in it)
     uint32_t stepped = 0;
 
     if (avail == 0u) return;  // (whole wave: the chunk is empty; nothing was counted)
@@ -596,17 +597,38 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (live == 0 && taken + rank < avail) {
                 game = taken + rank;
-                p[0] = 0;
-                p[1] = 0;
-                hts = top * columns;
-                blk = 0;
                 st = 0;
-                live = (!CAPPED || max_plies > 0u) ? 1u : 0u;
-                if (CAPPED && live == 0) {  // max_plies == 0: the boards still have to be written once
-                    plane0[game] = 0;
-                    plane1[game] = 0;
-                    status_out[game] = 0;
-                    reward_out[game] = 0;
+                if (FROM_INITIAL) {
+                    p[0] = 0;
+                    p[1] = 0;
+                    hts = top * columns;
+                    blk = 0;
+                    live = (!CAPPED || max_plies > 0u) ? 1u : 0u;
+                    if (CAPPED && live == 0) {  // max_plies == 0: the boards still have to be written once
+                        plane0[game] = 0;
+                        plane1[game] = 0;
+                        status_out[game] = 0;
+                        reward_out[game] = 0;
+                    }
+                } else {
+                    // a board from memory joins at its own ply: ply p is sub-step p & 3 of block p >> 2, so the lane
+                    // sits out the first (p & 3) sub-steps of its first block and the mover of sub-step j is still
+                    // player j & 1
+                    p[0] = plane0[game];
+                    p[1] = plane1[game];
+                    const uint32_t ply0 = (uint32_t)__popcll(p[0]) + (uint32_t)__popcll(p[1]);
+                    const uint64_t occ = p[0] | p[1];
+                    hts = 0;
+#pragma unroll
+                    for (int x = 0; x < G::MAXW; ++x) {
+                        if (x < g.w() && x < 8) {
+                            const uint32_t hx = (uint32_t)__popcll((occ >> (x * (int)stride)) & ((1ull << stride) - 1ull));
+                            hts |= (top - hx) << (4 * x);
+                        }
+                    }
+                    blk = ply0 >> 2;
+                    skip = ply0 & 3u;
+                    live = (status_out[game] == BGS_ST_RUNNING && (!CAPPED || ply0 < max_plies)) ? 1u : 0u;
                 }
             }
             const uint32_t wanted = (uint32_t)__popcll(need);
@@ -631,9 +653,10 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
             asm("" : "+v"(base));  // keep (col * stride + top) one multiply-add; then one subtract
             uint32_t pos = base - v;
             if ((uint32_t)g.w() * stride + top > 63u) pos &= 63u;  // only a lane that is not playing can exceed 63
+            const uint64_t act = (FROM_INITIAL || j >= skip) ? live : 0;  // this lane plays this sub-step
             uint64_t& mine = p[j & 1u];
-            mine |= live << pos;
-            hts -= (uint32_t)live << sh;
+            mine |= act << pos;
+            hts -= (uint32_t)act << sh;
             open = (hts >> 3) & ONES;
             bool won;
             if (g.k() == 4) {
@@ -643,12 +666,13 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
                 b.w[0] = mine;
                 won = has_run(g, b);
             }
-            stepped += (uint32_t)live;
-            st = (live != 0 && won) ? (j & 1u) + 1u : st;
+            stepped += (uint32_t)act;
+            st = (act != 0 && won) ? (j & 1u) + 1u : st;
             live = (won || open == 0u) ? 0 : live;
             if (CAPPED) live = (4u * blk + j + 1u < max_plies) ? live : 0;
         }
         blk += 1u;
+        skip = 0;
 
         // ---- boards that ended in this block go to memory
         if (was_live != 0 && live == 0) {
@@ -952,16 +976,22 @@ void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
             }
         };
         if constexpr (G::NW == 1) {
-            if (nibble_ok && (flags & 1u) && !b->rollout_generic) {
-                // boards from the initial state: the block-aligned, branch-free kernel
-                if (capped)
-                    hipLaunchKernelGGL((k_connect_rollout_aligned<G, true>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, g,
-                                       b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
-                                       b->first_game, cap, b->d_steps, (uint32_t)per_wave);
-                else
-                    hipLaunchKernelGGL((k_connect_rollout_aligned<G, false>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, g,
-                                       b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
-                                       b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+            if (nibble_ok && !b->rollout_generic) {
+                // one-word boards: the block-aligned, branch-free kernel (from the initial state or from memory)
+                auto launch_aligned = [&](auto capped_tag, auto initial_tag) {
+                    constexpr bool CAPPED = decltype(capped_tag)::value;
+                    constexpr bool INITIAL = decltype(initial_tag)::value;
+                    hipLaunchKernelGGL((k_connect_rollout_aligned<G, CAPPED, INITIAL>), dim3(blocks), dim3(BGS_BLOCK), 0,
+                                       b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
+                                       seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+                };
+                if (flags & 1u) {
+                    if (capped) launch_aligned(std::true_type{}, std::true_type{});
+                    else launch_aligned(std::false_type{}, std::true_type{});
+                } else {
+                    if (capped) launch_aligned(std::true_type{}, std::false_type{});
+                    else launch_aligned(std::false_type{}, std::false_type{});
+                }
                 return;
             }
             if (nibble_ok) { with_game(Tag<NibbleGame<G>>{}); return; }

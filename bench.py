@@ -95,6 +95,10 @@ def main() -> int:
                     help="batches in flight per GPU: step i runs on batch i %% D / HIP stream i %% D, so the drain of one "
                     "rollout (and, with N > 1, its reward gather) overlaps the start of the next (default 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-compare", action="store_true",
+                    help="after the timed region, also time the same launches one at a time on one stream and report it "
+                    "as `one_launch_at_a_time` (off by default so that a profile of this command sees only the timed "
+                    "region's launches)")
     args = ap.parse_args()
 
     import torch
@@ -296,7 +300,7 @@ def main() -> int:
         }
         last = args.warmup + args.steps - 1
         head = batches[last % depth].reward[:65536] if (world == 1 and not args.no_cpu_baseline) else None
-        if world == 1 and depth > 1:
+        if world == 1 and depth > 1 and args.serial_compare:
             # for comparison, outside the timed region above: the same launches strictly one after the other on one
             # stream (what a caller sees who waits for each batch before starting the next)
             solo = batches[0]

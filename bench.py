@@ -257,7 +257,8 @@ def main() -> int:
                         "frac": rate / peak, "basis": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; "
                         "launches overlap, so the rate uses ms_per_step"}
         out = {
-            "metric": "env-steps/sec, Connect4(6,7,4) random rollout, batch=2^20 per GPU",
+            "metric": "env-steps/sec, Connect4(6,7,4) random rollout, batch="
+            + ("2^20" if n == BATCH_PER_GPU else str(n)) + " per GPU",
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,

@@ -1,0 +1,46 @@
+"""bench.py's output contract, checked on the committed round-1 bench line (CPU only), and its loud failure
+without a GPU."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_every_contract_field():
+    with open(os.path.join(ROOT, "profiles", "r01_bench.json")) as fh:
+        line = [ln for ln in fh.read().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "u64" and d["n_gpus"] == 1
+    assert "Connect4(6,7,4)" in d["metric"] and "workload" in d["config"] and "model" not in d["config"]
+    roof = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    cpu = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1
+    assert cpu["parity_with_device_rewards"] is True
+    assert d["value"] > 1e9  # the north star's floor was 1e9 env-steps/s on EIGHT GPUs
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    sys.path[:0] = [os.path.join(ROOT, "board-game-simulator-python_amd")]
+    from simulator.game import _abi
+
+    if _abi.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                          capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 2
+    assert "no GPU" in proc.stderr and not proc.stdout.strip()

@@ -8,7 +8,11 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
+import os
+
 SEED = 0x0123456789ABCDEF
+# BGS_FUZZ_CASES=N widens the sweep (default: 24 Connect + 32 Bounce cases)
+EXTRA = int(os.environ.get("BGS_FUZZ_CASES", "0"))
 
 
 def same(dev, orc, what):
@@ -28,7 +32,7 @@ def random_connect_geometries(rng, count):
     return out
 
 
-@pytest.mark.parametrize("case", range(24))
+@pytest.mark.parametrize("case", range(max(24, EXTRA)))
 def test_connect_random_geometry(case):
     from simulator.batch import ConnectBatch
 
@@ -84,7 +88,7 @@ def random_bounce_grid(rng):
     return grid
 
 
-@pytest.mark.parametrize("case", range(32))
+@pytest.mark.parametrize("case", range(max(32, EXTRA)))
 def test_bounce_random_grid(case):
     from simulator.batch import BounceBatch
 

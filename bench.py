@@ -44,7 +44,7 @@ HEIGHT, WIDTH, COUNT = 6, 7, 4
 BATCH_PER_GPU = 1 << 20
 BYTES_PER_STEP = 32          # 2 planes x 8 B read + 2 planes x 8 B written per env-step
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-EVENT_STRIDE = 4             # HIP-event pairs bracket every 4th rollout launch of the timed region
+EVENT_STRIDE = 10            # HIP-event pairs bracket every 10th rollout launch of the timed region
 
 
 def cpu_baseline(torch, last_seed, device_reward_head):

@@ -74,10 +74,25 @@ def cpu_baseline(torch, last_seed, device_reward_head):
         elapsed += time.perf_counter() - t0
         if r == 0 and device_reward_head is not None:
             parity = bool(np.array_equal(orc.reward[: device_reward_head.shape[0]], device_reward_head))
+    # the same oracle on ONE thread (the reference's own loop is single-threaded under the GIL)
+    single = None
+    try:
+        import ctypes
+
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        small = oracle.ConnectOracle(HEIGHT, WIDTH, COUNT, 1 << 18)
+        t0 = time.perf_counter()
+        steps1 = small.rollout(SEED + 77)
+        single = steps1 / (time.perf_counter() - t0)
+        gomp.omp_set_num_threads(cores)
+    except OSError:
+        pass
     return {
         "value": total / elapsed,
         "unit": "env-steps/s",
         "cores": cores,
+        "single_thread_value": single,
         "kind": "port",
         "sample": f"{reps} x 2^20 Connect4(6,7,4) games from the initial state ({total} env-steps), CPU oracle "
         f"(oracle/bgs_oracle.c, OpenMP, {cores} threads); the reference's own core is not buildable offline",

@@ -10,13 +10,19 @@
 #include <cstring>
 #include <new>
 
+#include "bgs_capi_util.h"
 #include "bgs_common.h"
 #include "bgs_internal.h"
 
+#ifndef BGS_BUILD_ID
+#define BGS_BUILD_ID "unknown"
+#endif
+
 namespace {
-
 thread_local char g_error[512] = "";
+}
 
+namespace bgs {
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -24,18 +30,11 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+}  // namespace bgs
 
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(BGS_ERR_RUNTIME, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+namespace {
 
-#define NEED(cond, ...)                               \
-    do {                                              \
-        if (!(cond)) return fail(BGS_ERR_ARG, __VA_ARGS__); \
-    } while (0)
+using bgs::fail;
 
 constexpr size_t kAlign = 256;
 constexpr size_t kStepBytes = (size_t)BGS_STEP_SHARDS * BGS_STEP_STRIDE * sizeof(unsigned long long);
@@ -58,7 +57,7 @@ Layout layout_for(int planes, int64_t n, int h, int w) {
     if (per_board < 16) per_board = 16;
     // unpack / pack scratch for every board, plus bgs_transition's in-block and out-block (object API: <= 4096 boards)
     const size_t small = n < 4096 ? (size_t)n : 4096;
-    l.staging_bytes = (size_t)n * (per_board + 16) + small * (2 * per_board + 80) + 8 * kAlign;
+    l.staging_bytes = (size_t)n * (per_board + 16) + small * (2 * per_board + 96) + 8 * kAlign;
     l.staging = off; off += align_up(l.staging_bytes);
     l.total = off;
     return l;
@@ -259,6 +258,18 @@ k_expand_outcomes(const uint8_t* __restrict__ packed, int64_t n, uint16_t* __res
     }
 }
 
+int make_order_event(bgs_batch* b) {
+    HIP_TRY(hipEventCreateWithFlags(&b->order_event, hipEventDisableTiming));
+    return BGS_OK;
+}
+
+// a batch whose construction failed half-way
+void discard(bgs_batch* b) {
+    if (b->owns_arena && b->arena) (void)hipFree(b->arena);
+    if (b->order_event) (void)hipEventDestroy(b->order_event);
+    delete b;
+}
+
 int reset_impl(bgs_batch* b) {
     HIP_TRY(hipMemsetAsync(b->d_steps, 0, kStepBytes, b->stream));
     if (b->game == BGS_GAME_CONNECT) bgs::connect_reset(b);
@@ -268,9 +279,19 @@ int reset_impl(bgs_batch* b) {
 
 }  // namespace
 
+namespace bgs {
+void pack_outcomes(const bgs_batch* b, uint8_t* d_packed) {
+    const int64_t bytes = (b->n + 3) / 4;
+    hipLaunchKernelGGL(k_pack_outcomes, dim3((unsigned)((bytes + BGS_BLOCK - 1) / BGS_BLOCK)), dim3(BGS_BLOCK), 0, b->stream,
+                       b->d_status, b->n, d_packed);
+}
+}  // namespace bgs
+
 extern "C" {
 
-int bgs_version(void) { return 100; }
+int bgs_version(void) { return 200; }
+
+const char* bgs_build_id(void) { return BGS_BUILD_ID; }
 
 const char* bgs_last_error(void) { return g_error; }
 
@@ -319,10 +340,10 @@ int bgs_connect_create(int height, int width, int count, int64_t n, int device, 
     b->planes = 2 * cg.nw;
     rc = device_facts(b);
     if (rc == BGS_OK) rc = carve(b, arena, arena_bytes, layout_for(b->planes, n, height, width));
+    if (rc == BGS_OK) rc = make_order_event(b);
     if (rc == BGS_OK) rc = reset_impl(b);
     if (rc != BGS_OK) {
-        if (b->owns_arena && b->arena) (void)hipFree(b->arena);
-        delete b;
+        discard(b);
         return rc;
     }
     *out = b;
@@ -350,12 +371,14 @@ int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, 
     b->planes = 4;
     rc = device_facts(b);
     if (rc == BGS_OK) rc = carve(b, arena, arena_bytes, layout_for(4, n, height, width));
+    if (rc == BGS_OK) rc = make_order_event(b);
     if (rc == BGS_OK) {
         // a start position whose first player cannot move is already over: let the device settle board 0 once
         // and remember the verdict (the kernels own every rule; the host evaluates none)
         rc = [&]() -> int {
             Stage st(b);
             int8_t* d_grid = st.take<int8_t>((size_t)height * width);
+            NEED(d_grid != nullptr, "staging buffer too small");
             bgs_batch one = *b;
             one.n = 1;
             HIP_TRY(hipMemcpyAsync(d_grid, cfg_grid, (size_t)height * width, hipMemcpyHostToDevice, b->stream));
@@ -370,8 +393,7 @@ int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, 
     }
     if (rc == BGS_OK) rc = reset_impl(b);
     if (rc != BGS_OK) {
-        if (b->owns_arena && b->arena) (void)hipFree(b->arena);
-        delete b;
+        discard(b);
         return rc;
     }
     *out = b;
@@ -387,13 +409,22 @@ int bgs_destroy(bgs_batch* b) {
         if (b->pinned[k]) (void)hipHostFree(b->pinned[k]);
         if (b->pinned_done[k]) (void)hipEventDestroy(b->pinned_done[k]);
     }
+    if (b->order_event) (void)hipEventDestroy(b->order_event);
     delete b;
     return BGS_OK;
 }
 
 int bgs_set_stream(bgs_batch* b, void* hip_stream) {
-    NEED(b != nullptr, "batch handle is NULL");
-    b->stream = static_cast<hipStream_t>(hip_stream);
+    int rc = enter(b);
+    if (rc) return rc;
+    hipStream_t next = static_cast<hipStream_t>(hip_stream);
+    if (next != b->stream) {
+        // whatever the batch has enqueued so far (its reset included) happens before anything the new stream runs:
+        // torch's pool streams are non-blocking and do not synchronise with the null stream by themselves
+        HIP_TRY(hipEventRecord(b->order_event, b->stream));
+        HIP_TRY(hipStreamWaitEvent(next, b->order_event, 0));
+        b->stream = next;
+    }
     return BGS_OK;
 }
 
@@ -461,6 +492,7 @@ int bgs_step_actions(bgs_batch* b, const int32_t* actions, int actions_on_device
     const size_t per = b->game == BGS_GAME_CONNECT ? 1 : 4;
     Stage st(b);
     int32_t* d_result = status ? st.take<int32_t>((size_t)b->n) : nullptr;
+    NEED(!status || d_result != nullptr, "staging buffer too small");
     const int32_t* d_actions = actions;
     if (!actions_on_device) {
         int32_t* tmp = st.take<int32_t>((size_t)b->n * per);
@@ -514,6 +546,7 @@ int bgs_read_grid(bgs_batch* b, int8_t* grid) {
     const size_t cells = (size_t)b->n * (connect ? b->cg.h * b->cg.w : b->bg.h * b->bg.w);
     Stage st(b);
     int8_t* d = st.take<int8_t>(cells);
+    NEED(d != nullptr, "staging buffer too small");
     if (connect) bgs::connect_unpack_grid(b, d);
     else bgs::bounce_unpack_grid(b, d);
     rc = finish_launch();
@@ -529,6 +562,7 @@ static int read_meta(bgs_batch* b, int8_t* player, uint8_t* ended, int8_t* winne
     uint8_t* de = ended ? st.take<uint8_t>((size_t)b->n) : nullptr;
     int8_t* dw = winner ? st.take<int8_t>((size_t)b->n) : nullptr;
     int32_t* dl = plies ? st.take<int32_t>((size_t)b->n) : nullptr;
+    NEED((!player || dp) && (!ended || de) && (!winner || dw) && (!plies || dl), "staging buffer too small");
     if (b->game == BGS_GAME_CONNECT) bgs::connect_meta(b, dp, de, dw, dl);
     else bgs::bounce_meta(b, dp, de, dw, dl);
     rc = finish_launch();
@@ -575,6 +609,7 @@ int bgs_read_legal(bgs_batch* b, uint8_t* legal) {
     NEED(b->game == BGS_GAME_CONNECT, "bgs_read_legal is a Connect entry point; use bgs_bounce_read_targets");
     Stage st(b);
     uint8_t* d = st.take<uint8_t>((size_t)b->n * b->cg.w);
+    NEED(d != nullptr, "staging buffer too small");
     bgs::connect_legal(b, d, nullptr);
     rc = finish_launch();
     if (rc) return rc;
@@ -587,6 +622,7 @@ int bgs_read_action_count(bgs_batch* b, int32_t* count) {
     NEED(count != nullptr, "count is NULL");
     Stage st(b);
     int32_t* d = st.take<int32_t>((size_t)b->n);
+    NEED(d != nullptr, "staging buffer too small");
     if (b->game == BGS_GAME_CONNECT) bgs::connect_legal(b, nullptr, d);
     else bgs::bounce_targets(b, nullptr, d);
     rc = finish_launch();
@@ -643,9 +679,7 @@ int bgs_pack_outcomes(bgs_batch* b, void* device_dst) {
     int rc = enter(b);
     if (rc) return rc;
     NEED(device_dst != nullptr, "destination is NULL");
-    const int64_t bytes = (b->n + 3) / 4;
-    hipLaunchKernelGGL(k_pack_outcomes, dim3((unsigned)((bytes + BGS_BLOCK - 1) / BGS_BLOCK)), dim3(BGS_BLOCK), 0, b->stream,
-                       b->d_status, b->n, static_cast<uint8_t*>(device_dst));
+    bgs::pack_outcomes(b, static_cast<uint8_t*>(device_dst));
     return finish_launch();
 }
 
@@ -676,7 +710,8 @@ int bgs_write_state(bgs_batch* b, const int8_t* grid, const int8_t* player, cons
     int8_t* dw = winner ? st.take<int8_t>((size_t)b->n) : nullptr;
     int32_t* dl = (plies && !connect) ? st.take<int32_t>((size_t)b->n) : nullptr;
     int32_t* dr = st.take<int32_t>((size_t)b->n);
-    NEED(dr != nullptr, "staging buffer too small");
+    NEED(dg != nullptr && dr != nullptr && (!player || dp) && (!winner || dw) && (!(plies && !connect) || dl),
+         "staging buffer too small");
     if ((rc = to_device(b, dg, grid, cells))) return rc;
     if (player && (rc = to_device(b, dp, player, (size_t)b->n))) return rc;
     if (winner && (rc = to_device(b, dw, winner, (size_t)b->n))) return rc;
@@ -692,7 +727,7 @@ int bgs_write_state(bgs_batch* b, const int8_t* grid, const int8_t* player, cons
 
 int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const int8_t* winner, const int32_t* plies,
                    const int32_t* actions, int32_t* status, int8_t* grid_out, int8_t* player_out, int8_t* winner_out,
-                   int32_t* plies_out, void* legal_out) {
+                   int32_t* plies_out, void* legal_out, int8_t* reward_out) {
     int rc = enter(b);
     if (rc) return rc;
     NEED(status && grid_out && player_out && winner_out && plies_out && legal_out, "output pointer is NULL");
@@ -710,7 +745,7 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
                  out_grid = (out_legal + legal_bytes + 15) & ~(size_t)15,  // the unpack tile store needs 16-byte alignment
                 
                  out_player = up8(out_grid + n * hw), out_winner = out_player + up8(n), out_plies = out_winner + up8(n),
-                 out_bytes = out_plies + 4 * n;
+                 out_reward = out_plies + 4 * n, out_bytes = out_reward + 2 * n;
     Stage st(b);
     uint8_t* d_in = st.take<uint8_t>(in_bytes);
     uint8_t* d_out = st.take<uint8_t>(out_bytes);
@@ -763,6 +798,8 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
         bgs::bounce_meta(b, op, nullptr, ow, ol);
         bgs::bounce_targets(b, reinterpret_cast<uint64_t*>(d_out + out_legal), nullptr);
     }
+    // the reward pairs as the kernels wrote them (State::get_reward): no host-side rule
+    HIP_TRY(hipMemcpyAsync(d_out + out_reward, b->d_reward, 2 * n, hipMemcpyDeviceToDevice, b->stream));
     rc = finish_launch();
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, b->stream));
@@ -776,6 +813,7 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
     memcpy(winner_out, h_out + out_winner, n);
     memcpy(plies_out, h_out + out_plies, 4 * n);
     memcpy(legal_out, h_out + out_legal, legal_bytes);
+    if (reward_out) memcpy(reward_out, h_out + out_reward, 2 * n);
     return BGS_OK;
 }
 

@@ -1,0 +1,346 @@
+// bgs_host.hip -- the asynchronous hand-over of results to HOST memory (include/bgs.h, "asynchronous hand-over").
+//
+// The reference returns `reward` as a host ndarray on every call (State::get_reward, src/simulator/game/connect.cpp:41,
+// bounce.cpp:38, through the copying caster tensor.hpp:69-87).  For a batch that hand-over is part of the path and has
+// to keep up with the rollout kernel (one batch of 2^20 games every ~50 us), so it is
+//   device:  status bytes -> 2-bit outcome codes (k_pack_outcomes, 0.25 B per game)
+//   PCIe:    one hipMemcpyAsync of the codes into a page-locked slot (256 KiB per 2^20 games)
+//   host:    worker threads expand codes -> int8[n][2] reward pairs in the caller's array (table look-up)
+// all of it enqueued behind the rollout on the batch's stream and overlapped with the next batches' kernels.
+// No game rule lives here: a reward pair is a fixed function of the outcome code (bgs_common.h reward_pair).
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "bgs_capi_util.h"
+#include "bgs_common.h"
+#include "bgs_internal.h"
+
+struct bgs_event {
+    int device;
+    hipEvent_t ev;
+};
+
+namespace {
+
+using bgs::fail;
+
+// code byte (4 games x 2 bits) -> 8 bytes (4 reward pairs), little endian
+struct ExpandTable {
+    uint64_t pairs[256];
+    ExpandTable() {
+        for (int byte = 0; byte < 256; ++byte) {
+            uint64_t four = 0;
+            for (int j = 0; j < 4; ++j) four |= (uint64_t)bgs::reward_pair((uint32_t)(byte >> (2 * j)) & 3u) << (16 * j);
+            pairs[byte] = four;
+        }
+    }
+};
+const ExpandTable g_expand;
+
+void expand_range(const uint8_t* packed, int64_t first, int64_t count, int8_t* reward) {
+    // whole code bytes through the table, 8 bytes per look-up; a ragged tail pair by pair
+    const int64_t whole = count / 4;
+    const uint8_t* src = packed + first / 4;
+    uint64_t* dst = reinterpret_cast<uint64_t*>(reward + 2 * first);  // first % 4 == 0: 8-byte aligned if `reward` is
+    if ((reinterpret_cast<uintptr_t>(dst) & 7u) == 0) {
+        for (int64_t i = 0; i < whole; ++i) dst[i] = g_expand.pairs[src[i]];
+    } else {
+        for (int64_t i = 0; i < whole; ++i) memcpy(reinterpret_cast<uint8_t*>(dst) + 8 * i, &g_expand.pairs[src[i]], 8);
+    }
+    for (int64_t g = first + whole * 4; g < first + count; ++g) {
+        const uint16_t pair = bgs::reward_pair((uint32_t)(packed[g / 4] >> (2 * (g & 3))) & 3u);
+        memcpy(reward + 2 * g, &pair, 2);
+    }
+}
+
+int enter_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return BGS_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// reward sink: slots of pinned code buffers + worker threads
+// ------------------------------------------------------------------------------------------------
+struct bgs_reward_sink {
+    int device = 0;
+    int64_t max_games = 0;
+    int slots = 0;
+    int threads = 0;
+    std::vector<uint8_t*> pinned;     // [slots] page-locked code buffers, (max_games + 3) / 4 bytes each
+    std::vector<uint8_t*> scratch;    // [slots] device buffers the batch's codes are packed into
+    std::vector<hipEvent_t> landed;   // [slots] recorded behind the copy into pinned[slot]
+    struct Job {
+        int64_t n_games = 0;
+        int8_t* host_reward = nullptr;
+    };
+    std::vector<Job> jobs;            // [slots]
+    std::mutex mu;
+    std::condition_variable cv_submit;   // a job was published / shutdown
+    std::condition_variable cv_done;     // a job completed
+    int64_t submitted = 0;               // tickets handed out: jobs [0, submitted) are published
+    int64_t completed = 0;               // jobs [0, completed) are in their host arrays
+    std::vector<int> parts_done;         // [slots] workers that finished their share of the slot's job
+    bool stop = false;
+    bool failed = false;
+    std::vector<std::thread> workers;
+
+    void work(int t) {
+        (void)hipSetDevice(device);
+        for (int64_t ticket = 0;; ++ticket) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv_submit.wait(lock, [&] { return stop || submitted > ticket; });
+                if (submitted <= ticket) return;  // stop, nothing left for this worker
+                job = jobs[ticket % slots];
+            }
+            const int slot = (int)(ticket % slots);
+            // every worker waits for the copy itself: hipEventSynchronize from several threads on one event is fine,
+            // and nobody has to forward the wake-up
+            const bool ok = hipEventSynchronize(landed[slot]) == hipSuccess;
+            if (ok) {
+                // shares are multiples of 4 games (one code byte), so threads never touch the same output word
+                const int64_t bytes = (job.n_games + 3) / 4;
+                const int64_t b0 = bytes * t / threads, b1 = bytes * (t + 1) / threads;
+                const int64_t first = b0 * 4;
+                int64_t count = b1 * 4 - first;
+                if (first + count > job.n_games) count = job.n_games - first;
+                if (count > 0) expand_range(pinned[slot], first, count, job.host_reward);
+            }
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                if (!ok) failed = true;
+                if (++parts_done[slot] == threads) {
+                    parts_done[slot] = 0;
+                    ++completed;  // jobs complete in ticket order: every worker walks the tickets in order
+                    cv_done.notify_all();
+                }
+            }
+        }
+    }
+};
+
+namespace {
+
+// claim the next ticket's slot, waiting while the ring is full; returns the slot
+int64_t claim(bgs_reward_sink* s) {
+    std::unique_lock<std::mutex> lock(s->mu);
+    s->cv_done.wait(lock, [&] { return s->submitted - s->completed < s->slots; });
+    return s->submitted;
+}
+
+void publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward) {
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        s->jobs[ticket % s->slots].n_games = n_games;
+        s->jobs[ticket % s->slots].host_reward = host_reward;
+        s->submitted = ticket + 1;
+    }
+    s->cv_submit.notify_all();
+}
+
+}  // namespace
+
+extern "C" {
+
+int bgs_host_alloc(size_t bytes, void** host_ptr) {
+    NEED(host_ptr != nullptr && bytes > 0, "bad argument");
+    *host_ptr = nullptr;
+    HIP_TRY(hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+    return BGS_OK;
+}
+
+int bgs_host_free(void* host_ptr) {
+    if (host_ptr) HIP_TRY(hipHostFree(host_ptr));
+    return BGS_OK;
+}
+
+int bgs_event_create(int device, bgs_event** out) {
+    NEED(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int rc = enter_device(device);
+    if (rc) return rc;
+    bgs_event* e = new (std::nothrow) bgs_event();
+    NEED(e != nullptr, "out of host memory");
+    e->device = device;
+    hipError_t err = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+    if (err != hipSuccess) {
+        delete e;
+        return fail(BGS_ERR_RUNTIME, "hipEventCreateWithFlags failed: %s", hipGetErrorString(err));
+    }
+    *out = e;
+    return BGS_OK;
+}
+
+int bgs_event_destroy(bgs_event* e) {
+    if (!e) return BGS_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipEventDestroy(e->ev);
+    delete e;
+    return BGS_OK;
+}
+
+int bgs_event_synchronize(bgs_event* e) {
+    NEED(e != nullptr, "event is NULL");
+    HIP_TRY(hipEventSynchronize(e->ev));
+    return BGS_OK;
+}
+
+int bgs_event_query(bgs_event* e, int* done) {
+    NEED(e != nullptr && done != nullptr, "NULL argument");
+    const hipError_t err = hipEventQuery(e->ev);
+    if (err == hipSuccess) *done = 1;
+    else if (err == hipErrorNotReady) *done = 0;
+    else return fail(BGS_ERR_RUNTIME, "hipEventQuery failed: %s", hipGetErrorString(err));
+    return BGS_OK;
+}
+
+int bgs_read_reward_async(bgs_batch* b, int8_t* host_dst, bgs_event* done) {
+    NEED(b != nullptr && host_dst != nullptr, "NULL argument");
+    int rc = enter_device(b->device);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(host_dst, b->d_reward, (size_t)b->n * 2, hipMemcpyDeviceToHost, b->stream));
+    if (done) HIP_TRY(hipEventRecord(done->ev, b->stream));
+    return BGS_OK;
+}
+
+int bgs_read_outcomes_async(bgs_batch* b, uint8_t* host_dst, bgs_event* done) {
+    NEED(b != nullptr && host_dst != nullptr, "NULL argument");
+    int rc = enter_device(b->device);
+    if (rc) return rc;
+    const size_t bytes = (size_t)(b->n + 3) / 4;
+    NEED(bytes <= b->staging_bytes, "staging buffer too small");
+    // the codes are packed into the head of the staging region: calls that unpack through it are ordered behind this
+    // copy on the same stream
+    uint8_t* d_packed = b->d_staging;
+    bgs::pack_outcomes(b, d_packed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_dst, d_packed, bytes, hipMemcpyDeviceToHost, b->stream));
+    if (done) HIP_TRY(hipEventRecord(done->ev, b->stream));
+    return BGS_OK;
+}
+
+int bgs_expand_outcomes_host(const uint8_t* packed, int64_t first, int64_t count, int8_t* reward) {
+    NEED(packed != nullptr && reward != nullptr, "NULL argument");
+    NEED(first >= 0 && count >= 0 && (first & 3) == 0, "first must be a non-negative multiple of 4, count >= 0");
+    expand_range(packed, first, count, reward);
+    return BGS_OK;
+}
+
+int bgs_rollout_to_host(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, void* host_dst, int codes,
+                        bgs_event* done) {
+    int rc = bgs_rollout(b, seed, max_plies, flags);
+    if (rc) return rc;
+    return codes ? bgs_read_outcomes_async(b, static_cast<uint8_t*>(host_dst), done)
+                 : bgs_read_reward_async(b, static_cast<int8_t*>(host_dst), done);
+}
+
+int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_reward_sink** out) {
+    NEED(out != nullptr, "out is NULL");
+    *out = nullptr;
+    NEED(max_games >= 1 && slots >= 1 && slots <= 64 && threads >= 1 && threads <= 256,
+         "need max_games >= 1, 1 <= slots <= 64, 1 <= threads <= 256");
+    int rc = enter_device(device);
+    if (rc) return rc;
+    bgs_reward_sink* s = new (std::nothrow) bgs_reward_sink();
+    NEED(s != nullptr, "out of host memory");
+    s->device = device;
+    s->max_games = max_games;
+    s->slots = slots;
+    s->threads = threads;
+    s->jobs.resize(slots);
+    s->parts_done.assign(slots, 0);
+    const size_t bytes = (size_t)(max_games + 3) / 4;
+    hipError_t err = hipSuccess;
+    for (int k = 0; k < slots && err == hipSuccess; ++k) {
+        void* host = nullptr;
+        void* dev = nullptr;
+        hipEvent_t ev = nullptr;
+        err = hipHostMalloc(&host, bytes, hipHostMallocDefault);
+        if (err == hipSuccess) s->pinned.push_back(static_cast<uint8_t*>(host));
+        if (err == hipSuccess) err = hipMalloc(&dev, bytes);
+        if (err == hipSuccess) s->scratch.push_back(static_cast<uint8_t*>(dev));
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (err == hipSuccess) s->landed.push_back(ev);
+    }
+    if (err != hipSuccess) {
+        for (auto p : s->pinned) (void)hipHostFree(p);
+        for (auto p : s->scratch) (void)hipFree(p);
+        for (auto e : s->landed) (void)hipEventDestroy(e);
+        delete s;
+        return fail(BGS_ERR_RUNTIME, "reward sink allocation failed: %s", hipGetErrorString(err));
+    }
+    for (int t = 0; t < threads; ++t) s->workers.emplace_back([s, t] { s->work(t); });
+    *out = s;
+    return BGS_OK;
+}
+
+int bgs_sink_destroy(bgs_reward_sink* s) {
+    if (!s) return BGS_OK;
+    {
+        std::unique_lock<std::mutex> lock(s->mu);
+        s->cv_done.wait(lock, [&] { return s->completed == s->submitted; });  // let published jobs finish
+        s->stop = true;
+    }
+    s->cv_submit.notify_all();
+    for (auto& w : s->workers) w.join();
+    (void)hipSetDevice(s->device);
+    for (auto p : s->pinned) (void)hipHostFree(p);
+    for (auto p : s->scratch) (void)hipFree(p);
+    for (auto e : s->landed) (void)hipEventDestroy(e);
+    delete s;
+    return BGS_OK;
+}
+
+int bgs_sink_submit(bgs_reward_sink* s, bgs_batch* b, int8_t* host_reward, int64_t* ticket) {
+    NEED(s != nullptr && b != nullptr && host_reward != nullptr, "NULL argument");
+    NEED(b->device == s->device, "batch lives on device %d, the sink on device %d", b->device, s->device);
+    NEED(b->n <= s->max_games, "batch of %lld games exceeds the sink's %lld", (long long)b->n, (long long)s->max_games);
+    int rc = enter_device(s->device);
+    if (rc) return rc;
+    const int64_t t = claim(s);
+    const int slot = (int)(t % s->slots);
+    bgs::pack_outcomes(b, s->scratch[slot]);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(s->pinned[slot], s->scratch[slot], (size_t)(b->n + 3) / 4, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipEventRecord(s->landed[slot], b->stream));
+    publish(s, t, b->n, host_reward);
+    if (ticket) *ticket = t;
+    return BGS_OK;
+}
+
+int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* device_packed, int64_t n_games,
+                           int8_t* host_reward, int64_t* ticket) {
+    NEED(s != nullptr && device_packed != nullptr && host_reward != nullptr, "NULL argument");
+    NEED(n_games >= 1 && n_games <= s->max_games, "n_games %lld outside 1..%lld", (long long)n_games,
+         (long long)s->max_games);
+    int rc = enter_device(s->device);
+    if (rc) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const int64_t t = claim(s);
+    const int slot = (int)(t % s->slots);
+    HIP_TRY(hipMemcpyAsync(s->pinned[slot], device_packed, (size_t)(n_games + 3) / 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(s->landed[slot], stream));
+    publish(s, t, n_games, host_reward);
+    if (ticket) *ticket = t;
+    return BGS_OK;
+}
+
+int bgs_sink_wait(bgs_reward_sink* s, int64_t ticket) {
+    NEED(s != nullptr, "sink is NULL");
+    std::unique_lock<std::mutex> lock(s->mu);
+    NEED(ticket >= 0 && ticket < s->submitted, "unknown ticket %lld", (long long)ticket);
+    s->cv_done.wait(lock, [&] { return s->completed > ticket; });
+    if (s->failed) return fail(BGS_ERR_RUNTIME, "a reward copy failed (hipEventSynchronize)");
+    return BGS_OK;
+}
+
+}  // extern "C"

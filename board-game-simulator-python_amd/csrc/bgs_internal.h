@@ -60,6 +60,7 @@ struct bgs_batch {
     // pinned bounce buffers for large device -> host copies (allocated on first use)
     void* pinned[2];
     hipEvent_t pinned_done[2];
+    hipEvent_t order_event;  // orders the batch's work across a change of stream (bgs_set_stream)
 };
 
 namespace bgs {
@@ -85,5 +86,9 @@ void bounce_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t*
 void bounce_targets(const bgs_batch* b, uint64_t* d_targets, int32_t* d_count);
 void bounce_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_player, const int8_t* d_winner,
                  const int32_t* d_plies, int32_t* d_status_out);
+
+// ---- shared by the C-ABI translation units (bgs_capi.hip, bgs_host.hip) ----
+// status bytes -> 2-bit outcome codes, 4 boards per byte, enqueued on the batch's stream
+void pack_outcomes(const bgs_batch* b, uint8_t* d_packed);
 
 }  // namespace bgs

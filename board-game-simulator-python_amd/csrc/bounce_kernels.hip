@@ -29,6 +29,10 @@ struct Board {
     uint64_t v[4];
 };
 
+// plies are stored as uint16: a board that holds 65535 plies is not stepped any further (no wrap-around, no reuse
+// of philox blocks); bgs_step_actions reports BGS_ERR_ILLEGAL for it
+constexpr uint32_t kMaxPlies = 65535u;
+
 __device__ __forceinline__ uint64_t occupancy(const Board& b) { return b.v[0] | b.v[1] | b.v[2] | b.v[3]; }
 
 __device__ __forceinline__ uint32_t value_at(const Board& b, int c) {
@@ -408,7 +412,7 @@ k_bounce_step_actions(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
         if (sx >= 0) {
             rc = -2;  // BGS_ERR_ILLEGAL
             const bool inside = sx < g.w && sy >= 0 && sy < g.h && tx >= 0 && tx < g.w && ty >= 0 && ty < g.h;
-            if (inside && status[i] == BGS_ST_RUNNING) {
+            if (inside && status[i] == BGS_ST_RUNNING && plies_buf[i] < kMaxPlies) {
                 Board b = load_board(planes, n, i);
                 uint32_t plies = plies_buf[i];
                 const uint32_t mover = plies & 1u;
@@ -540,12 +544,12 @@ void bounce_reset(const bgs_batch* b) {
 void bounce_step_random(const bgs_batch* b, uint64_t seed) {
     hipLaunchKernelGGL((k_bounce_play<true, false>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
                        b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
-                       0xFFFFFFFFu, b->d_steps);
+                       kMaxPlies, b->d_steps);
 }
 
 void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
     uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
-    if (cap > 65535u) cap = 65535u;  // plies are stored as uint16
+    if (cap > kMaxPlies) cap = kMaxPlies;  // plies are stored as uint16
     if (b->bg.w <= kMaxTrackedColumns && !b->rollout_generic) {
         // lane-group mode (8 lanes per board) unless BGS_BOUNCE_GROUP=1 asks for one lane per board
         const int group = b->bounce_group;

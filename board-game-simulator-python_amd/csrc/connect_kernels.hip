@@ -868,15 +868,17 @@ k_connect_pack(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
     }
     if (!(c0 == c1 || c0 == c1 + 1)) ok = false;
     if (player && ok && player[i] != ((c0 + c1) & 1)) ok = false;
-    uint32_t st = BGS_ST_RUNNING;
+    // the status the grid itself implies: a k-run belongs to whoever moved last (a game stops at its first run, so
+    // a run of the side to move, or runs of both sides, cannot arise), a full board without a run is a draw
+    const bool run0 = has_run(g, p0), run1 = has_run(g, p1);
+    if ((run0 && run1) || (run0 && c0 != c1 + 1) || (run1 && c0 != c1)) ok = false;
+    uint32_t st = run0 ? 1u : (run1 ? 2u : (c0 + c1 == h * w ? BGS_ST_DRAW : BGS_ST_RUNNING));
     if (winner) {
+        // an explicit winner has to agree with the grid (winner = -1 on a board that holds a k-run would make the
+        // rollout kernels treat the board differently from one another)
         const int wv = winner[i];
         if (wv < -1 || wv > 2) ok = false;
-        st = wv == -1 ? 0u : (wv == 2 ? BGS_ST_DRAW : (uint32_t)(wv + 1));
-    } else if (ok) {
-        if (has_run(g, p0)) st = 1u;
-        else if (has_run(g, p1)) st = 2u;
-        else if (c0 + c1 == h * w) st = BGS_ST_DRAW;
+        else if ((wv == -1 ? 0u : (wv == 2 ? BGS_ST_DRAW : (uint32_t)(wv + 1))) != st) ok = false;
     }
     if (ok) {
         store_planes<NW>(planes, n, i, p0, p1);

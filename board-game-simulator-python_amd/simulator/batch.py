@@ -37,6 +37,142 @@ def _torch_cuda():
     return torch if torch.cuda.is_available() else None
 
 
+class PinnedArray:
+    """A page-locked host array (bgs_host_alloc) viewed as a numpy array: the destination of asynchronous device ->
+    host copies.  Keep the object alive while copies into it may be in flight."""
+
+    def __init__(self, shape, dtype):
+        self.shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        nbytes = max(int(np.prod(self.shape)) * self.dtype.itemsize, 1)
+        p = ctypes.c_void_p()
+        _abi.check(_abi.lib().bgs_host_alloc(nbytes, ctypes.byref(p)))
+        self._ptr = p
+        buf = (ctypes.c_uint8 * nbytes).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    @property
+    def ptr(self) -> int:
+        return self._ptr.value
+
+    def close(self) -> None:
+        if self._ptr:
+            self.array = None
+            _abi.lib().bgs_host_free(self._ptr)
+            self._ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostEvent:
+    """A device event the asynchronous hand-over records behind its copy (bgs_event)."""
+
+    def __init__(self, device: int = 0):
+        self._handle = _abi.c_handle()
+        _abi.check(_abi.lib().bgs_event_create(int(device), ctypes.byref(self._handle)))
+
+    def synchronize(self) -> None:
+        _abi.check(_abi.lib().bgs_event_synchronize(self._handle))
+
+    def done(self) -> bool:
+        flag = ctypes.c_int(0)
+        _abi.check(_abi.lib().bgs_event_query(self._handle, ctypes.byref(flag)))
+        return bool(flag.value)
+
+    def close(self) -> None:
+        if self._handle:
+            _abi.lib().bgs_event_destroy(self._handle)
+            self._handle = _abi.c_handle()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _host_ptr(dst) -> int:
+    """Address of a host destination: PinnedArray, numpy array or (pinned) CPU torch tensor."""
+    if isinstance(dst, PinnedArray):
+        return dst.ptr
+    if isinstance(dst, np.ndarray):
+        if not dst.flags.c_contiguous:
+            raise TypeError("host destination must be C-contiguous")
+        return dst.ctypes.data
+    if hasattr(dst, "data_ptr") and not getattr(dst, "is_cuda", False):
+        return dst.data_ptr()
+    raise TypeError("host destination must be a PinnedArray, a numpy array or a CPU torch tensor")
+
+
+def expand_outcomes_host(packed, n: int, out=None, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+    """Packed 2-bit outcome codes on the HOST (uint8[(n + 3) // 4]) -> reward int8[n, 2] (bgs_expand_outcomes_host)."""
+    if out is None:
+        out = np.empty((n, 2), dtype=np.int8)
+    cnt = n - first if count is None else count
+    _abi.check(_abi.lib().bgs_expand_outcomes_host(ctypes.c_void_p(_host_ptr(packed)), first, cnt, ctypes.c_void_p(_host_ptr(out))))
+    return out
+
+
+class RewardSink:
+    """Delivers the rewards of successive batch steps into host arrays int8[n, 2] while the GPU goes on playing
+    (bgs_sink_*): outcome codes cross PCIe into pinned slots, worker threads expand them on arrival."""
+
+    def __init__(self, max_games: int, slots: int = 4, threads: int = 4, device: int = 0):
+        self._handle = _abi.c_handle()
+        _abi.check(_abi.lib().bgs_sink_create(int(device), int(max_games), int(slots), int(threads), ctypes.byref(self._handle)))
+
+    def submit(self, batch: "_Batch", host_reward) -> int:
+        ticket = ctypes.c_int64(-1)
+        _abi.check(_abi.lib().bgs_sink_submit(self._handle, batch._handle, ctypes.c_void_p(_host_ptr(host_reward)), ctypes.byref(ticket)))
+        return ticket.value
+
+    def submit_packed(self, device_packed, n_games: int, host_reward, stream: int = 0) -> int:
+        """`device_packed`: CUDA uint8 tensor (or device address) of the codes of n_games games, e.g. the RCCL-gathered
+        codes of all ranks; copied on HIP stream `stream`."""
+        ptr = device_packed.data_ptr() if hasattr(device_packed, "data_ptr") else int(device_packed)
+        ticket = ctypes.c_int64(-1)
+        _abi.check(
+            _abi.lib().bgs_sink_submit_packed(
+                self._handle, ctypes.c_void_p(stream), ctypes.c_void_p(ptr), int(n_games), ctypes.c_void_p(_host_ptr(host_reward)), ctypes.byref(ticket)
+            )
+        )
+        return ticket.value
+
+    def wait(self, ticket: int) -> None:
+        _abi.check(_abi.lib().bgs_sink_wait(self._handle, int(ticket)))
+
+    def close(self) -> None:
+        if self._handle:
+            _abi.lib().bgs_sink_destroy(self._handle)
+            self._handle = _abi.c_handle()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceView:
+    """A batch buffer as a `__cuda_array_interface__` object (version 2; ROCm frameworks use the same protocol): a
+    zero-copy hand-over to torch (`torch.as_tensor(view, device="cuda")`), CuPy or Numba without importing any of
+    them here.  From a torch tensor, DLPack is one call away (`tensor.__dlpack__()`)."""
+
+    def __init__(self, owner, ptr: int, shape, typestr: str):
+        self._owner = owner  # keeps the batch (and its arena) alive
+        self.__cuda_array_interface__ = {
+            "shape": tuple(int(x) for x in shape),
+            "typestr": typestr,
+            "data": (int(ptr), False),
+            "version": 2,
+            "strides": None,
+        }
+
+
 class _Batch:
     """Common part of ConnectBatch / BounceBatch: lifetime, stepping, observation."""
 
@@ -154,6 +290,27 @@ class _Batch:
         _abi.check(_abi.lib().bgs_read_reward(self._handle, _ptr(out, ctypes.c_int8)))
         return out
 
+    # ---- asynchronous hand-over to host memory (the batch form of State.reward, connect.cpp:41) ----------------
+    def read_reward_async(self, host_dst, event: Optional[HostEvent] = None) -> None:
+        """Enqueue reward int8[n, 2] -> `host_dst` (page-locked) on the batch's stream; `event` fires behind the copy."""
+        _abi.check(_abi.lib().bgs_read_reward_async(self._handle, ctypes.c_void_p(_host_ptr(host_dst)), event._handle if event else None))
+
+    def read_outcomes_async(self, host_dst, event: Optional[HostEvent] = None) -> None:
+        """Enqueue the 2-bit outcome codes uint8[(n + 3) // 4] -> `host_dst` (page-locked); expand with
+        `expand_outcomes_host`."""
+        _abi.check(_abi.lib().bgs_read_outcomes_async(self._handle, ctypes.c_void_p(_host_ptr(host_dst)), event._handle if event else None))
+
+    def rollout_to_host(self, host_dst, seed: int = DEFAULT_SEED, max_plies: int = 2**31 - 1, from_initial: bool = False,
+                        codes: bool = False, event: Optional[HostEvent] = None) -> None:
+        """`rollout` + `read_reward_async` (or `read_outcomes_async` with codes=True) in one library call."""
+        flags = _abi.ROLLOUT_FROM_INITIAL if from_initial else 0
+        _abi.check(
+            _abi.lib().bgs_rollout_to_host(
+                self._handle, ctypes.c_uint64(seed), ctypes.c_int32(max_plies), ctypes.c_uint32(flags),
+                ctypes.c_void_p(_host_ptr(host_dst)), 1 if codes else 0, event._handle if event else None,
+            )
+        )
+
     @property
     def plies(self) -> np.ndarray:
         out = np.empty(self.n, dtype=np.int32)
@@ -189,8 +346,8 @@ class _Batch:
 
     def transition(self, grid=None, player=None, winner=None, plies=None, actions=None):
         """One round trip for the object API: optionally load boards, optionally apply one chosen move per board, then
-        observe.  Returns (status int32[n], grid, player, winner, plies, legal) with `legal` the Connect mask
-        uint8[n, W] or the Bounce target masks uint64[n, W + 1]."""
+        observe.  Returns (status int32[n], grid, player, winner, plies, legal, reward) with `legal` the Connect mask
+        uint8[n, W] or the Bounce target masks uint64[n, W + 1] and `reward` int8[n, 2] as the device holds it."""
         n = self.n
         i8 = ctypes.c_int8
         g = p = w = l = a = None
@@ -211,6 +368,7 @@ class _Batch:
         winner_out = np.empty(n, dtype=np.int8)
         plies_out = np.empty(n, dtype=np.int32)
         legal_out = self._empty_legal()
+        reward_out = np.empty((n, 2), dtype=np.int8)
         _abi.check(
             _abi.lib().bgs_transition(
                 self._handle,
@@ -225,9 +383,10 @@ class _Batch:
                 _ptr(winner_out, i8),
                 _ptr(plies_out, ctypes.c_int32),
                 ctypes.c_void_p(legal_out.ctypes.data),
+                _ptr(reward_out, i8),
             )
         )
-        return status, grid_out, player_out, winner_out, plies_out, legal_out
+        return status, grid_out, player_out, winner_out, plies_out, legal_out, reward_out
 
     # ---- device-side hand-over (torch / RCCL plumbing) -----------------------------------------------
     def buffer(self, buffer_id: int):
@@ -236,6 +395,20 @@ class _Batch:
         sz = ctypes.c_size_t()
         _abi.check(_abi.lib().bgs_buffer(self._handle, buffer_id, ctypes.byref(p), ctypes.byref(sz)))
         return p.value, sz.value
+
+    def device_view(self, what: str = "reward") -> DeviceView:
+        """`__cuda_array_interface__` view of a batch buffer without torch: "reward" int8[n, 2], "status" uint8[n],
+        "planes" uint64[planes, n]."""
+        if what == "reward":
+            ptr, _ = self.buffer(_abi.BUF_REWARD)
+            return DeviceView(self, ptr, (self.n, 2), "|i1")
+        if what == "status":
+            ptr, _ = self.buffer(_abi.BUF_STATUS)
+            return DeviceView(self, ptr, (self.n,), "|u1")
+        if what == "planes":
+            ptr, nbytes = self.buffer(_abi.BUF_PLANES)
+            return DeviceView(self, ptr, (nbytes // (8 * self.n), self.n), "<u8")
+        raise ValueError(f"unknown device view {what!r}")
 
     def _arena_view(self, buffer_id: int):
         if self._arena is None:
@@ -275,6 +448,49 @@ class _Batch:
             out = t.empty((self.n, self.height, self.width), dtype=t.int8, device=f"cuda:{self.device}")
         _abi.check(_abi.lib().bgs_export_device(self._handle, ord("g"), ctypes.c_void_p(out.data_ptr())))
         return out
+
+
+    def _export(self, what: str, out):
+        _abi.check(_abi.lib().bgs_export_device(self._handle, ord(what), ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def action_count_tensor(self, out=None):
+        """int32[n] on the device: len(state.actions) per board (0 once ended)."""
+        t = self._need_torch("action_count_tensor")
+        if out is None:
+            out = t.empty(self.n, dtype=t.int32, device=f"cuda:{self.device}")
+        return self._export("c", out)
+
+    def reward_copy_tensor(self, out=None):
+        """int8[n, 2] on the device: a copy of the reward buffer (bgs_export_device 'r')."""
+        t = self._need_torch("reward_copy_tensor")
+        if out is None:
+            out = t.empty((self.n, 2), dtype=t.int8, device=f"cuda:{self.device}")
+        return self._export("r", out)
+
+    def _need_torch(self, who: str):
+        if self._torch is None:
+            raise RuntimeError(f"{who} needs torch with a GPU")
+        return self._torch
+
+    # ---- snapshot / restore in the reference's wire format (State.to_json / State.from_json) -------------------
+    def to_json_states(self) -> list:
+        """The batch as a list of reference-shaped State JSON dicts {"grid", "player", "winner"}
+        (tests/test_connect.py:131-138, tests/test_bounce.py:392-403)."""
+        grid, player, winner = self.grid, self.player, self.winner
+        return [{"grid": grid[i].tolist(), "player": int(player[i]), "winner": int(winner[i])} for i in range(self.n)]
+
+    def from_json_states(self, states) -> np.ndarray:
+        """Load a list of n State JSON dicts; returns per-board status (0 ok, -1 malformed and left untouched)."""
+        if len(states) != self.n:
+            raise TypeError(f"expected {self.n} states, got {len(states)}")
+        try:
+            grid = np.array([s["grid"] for s in states], dtype=np.int8)
+            player = np.array([s["player"] for s in states], dtype=np.int8)
+            winner = np.array([s["winner"] for s in states], dtype=np.int8)
+        except (KeyError, TypeError, ValueError) as exc:
+            raise RuntimeError(f"invalid state JSON: {exc}") from None
+        return self.write_state(grid, player, winner)
 
 
 def expand_outcomes(packed, n: int, out=None):

@@ -38,6 +38,7 @@ SIGNATURES = {
     "bgs_version": (ctypes.c_int, []),
     "bgs_last_error": (ctypes.c_char_p, []),
     "bgs_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "bgs_build_id": (ctypes.c_char_p, []),
     "bgs_connect_arena_bytes": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]),
     "bgs_connect_create": (
         ctypes.c_int,
@@ -77,8 +78,30 @@ SIGNATURES = {
     "bgs_expand_outcomes": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "bgs_transition": (
         ctypes.c_int,
-        [c_handle, _i8p, _i8p, _i8p, _i32p, _i32p, _i32p, _i8p, _i8p, _i8p, _i32p, ctypes.c_void_p],
+        [c_handle, _i8p, _i8p, _i8p, _i32p, _i32p, _i32p, _i8p, _i8p, _i8p, _i32p, ctypes.c_void_p, _i8p],
     ),
+    # asynchronous hand-over to host memory
+    "bgs_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "bgs_host_free": (ctypes.c_int, [ctypes.c_void_p]),
+    "bgs_event_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_handle)]),
+    "bgs_event_destroy": (ctypes.c_int, [c_handle]),
+    "bgs_event_synchronize": (ctypes.c_int, [c_handle]),
+    "bgs_event_query": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_int)]),
+    "bgs_read_reward_async": (ctypes.c_int, [c_handle, ctypes.c_void_p, c_handle]),
+    "bgs_read_outcomes_async": (ctypes.c_int, [c_handle, ctypes.c_void_p, c_handle]),
+    "bgs_expand_outcomes_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "bgs_rollout_to_host": (
+        ctypes.c_int,
+        [c_handle, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int, c_handle],
+    ),
+    "bgs_sink_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_handle)]),
+    "bgs_sink_destroy": (ctypes.c_int, [c_handle]),
+    "bgs_sink_submit": (ctypes.c_int, [c_handle, c_handle, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "bgs_sink_submit_packed": (
+        ctypes.c_int,
+        [c_handle, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
+    ),
+    "bgs_sink_wait": (ctypes.c_int, [c_handle, ctypes.c_int64]),
     "bgs_write_state": (ctypes.c_int, [c_handle, _i8p, _i8p, _i8p, _i32p, _i32p]),
 }
 
@@ -142,6 +165,10 @@ def check(rc: int) -> None:
     if rc == BGS_ERR_ARG:
         raise ValueError(f"libbgs: {msg}")
     raise BgsError(rc, msg)
+
+
+def build_id() -> str:
+    return lib().bgs_build_id().decode("ascii")
 
 
 def device_count() -> int:

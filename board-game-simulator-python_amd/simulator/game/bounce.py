@@ -55,7 +55,7 @@ class _Engine:
     def _round_trip(self, grid=None, player=0, winner=-1, plies=0, move=None):
         """One fused call (bgs_transition): optional load, optional move, then the observations a State needs."""
         b = self.batch
-        status, g, p, w, l, masks = b.transition(
+        status, g, p, w, l, masks, reward = b.transition(
             None if grid is None else grid[None],
             None if grid is None else np.array([player], dtype=np.int8),
             None if grid is None else np.array([winner], dtype=np.int8),
@@ -79,7 +79,7 @@ class _Engine:
                         moves.append(((x, row), (c % width, c // width)))
                     m >>= 1
                     c += 1
-        return grid_out, player_out, winner_out, plies_out, tuple(moves)
+        return grid_out, player_out, winner_out, plies_out, tuple(moves), reward[0]
 
     def initial(self):
         with self.lock:
@@ -146,10 +146,10 @@ class Config(ValueObject):
 
 
 class State(ValueObject):
-    __slots__ = ("config", "_grid", "_player", "_winner", "_plies", "_moves")
+    __slots__ = ("config", "_grid", "_player", "_winner", "_plies", "_moves", "_reward")
     Action: ClassVar[type]
 
-    def __init__(self, config: Config, grid, player: int, winner: int, plies: int, moves):
+    def __init__(self, config: Config, grid, player: int, winner: int, plies: int, moves, reward):
         object.__setattr__(self, "config", config)
         g = np.array(grid, dtype=np.int8)
         g.setflags(write=False)
@@ -158,6 +158,9 @@ class State(ValueObject):
         object.__setattr__(self, "_winner", int(winner))
         object.__setattr__(self, "_plies", int(plies))
         object.__setattr__(self, "_moves", tuple(moves))
+        r = np.array(reward, dtype=np.int8)  # the pair the device computed (State::get_reward, bounce.cpp:38)
+        r.setflags(write=False)
+        object.__setattr__(self, "_reward", r)
 
     def __setattr__(self, name, value):
         raise AttributeError("State is immutable")
@@ -182,11 +185,7 @@ class State(ValueObject):
 
     @property
     def reward(self) -> np.ndarray:
-        r = np.zeros(2, dtype=np.int8)
-        if self._winner in (0, 1):
-            r[self._winner] = 1
-            r[1 - self._winner] = -1
-        return r
+        return self._reward.copy()
 
     @property
     def actions(self) -> List["Action"]:

@@ -47,7 +47,7 @@ class _Engine:
     def _round_trip(self, grid=None, player=0, winner=-1, column=None):
         """One fused call (bgs_transition): optional load, optional move, then the observations a State needs."""
         b = self.batch
-        status, g, p, w, _, legal = b.transition(
+        status, g, p, w, _, legal, reward = b.transition(
             None if grid is None else grid[None],
             None if grid is None else np.array([player], dtype=np.int8),
             None if grid is None else np.array([winner], dtype=np.int8),
@@ -58,7 +58,7 @@ class _Engine:
             raise RuntimeError(f"illegal action: column {column}")
         if status[0] != 0:
             raise RuntimeError("malformed Connect state")
-        return g[0], int(p[0]), int(w[0]), tuple(int(c) for c in np.flatnonzero(legal[0]))
+        return g[0], int(p[0]), int(w[0]), tuple(int(c) for c in np.flatnonzero(legal[0])), reward[0]
 
     def initial(self):
         with self.lock:
@@ -119,10 +119,10 @@ class Config(ValueObject):
 
 
 class State(ValueObject):
-    __slots__ = ("config", "_grid", "_player", "_winner", "_legal")
+    __slots__ = ("config", "_grid", "_player", "_winner", "_legal", "_reward")
     Action: ClassVar[type]
 
-    def __init__(self, config: Config, grid: np.ndarray, player: int, winner: int, legal: Tuple[int, ...]):
+    def __init__(self, config: Config, grid: np.ndarray, player: int, winner: int, legal: Tuple[int, ...], reward):
         object.__setattr__(self, "config", config)
         g = np.array(grid, dtype=np.int8)
         g.setflags(write=False)
@@ -130,6 +130,9 @@ class State(ValueObject):
         object.__setattr__(self, "_player", int(player))
         object.__setattr__(self, "_winner", int(winner))
         object.__setattr__(self, "_legal", tuple(legal))
+        r = np.array(reward, dtype=np.int8)  # the pair the device computed (State::get_reward, connect.cpp:41)
+        r.setflags(write=False)
+        object.__setattr__(self, "_reward", r)
 
     def __setattr__(self, name, value):
         raise AttributeError("State is immutable")
@@ -154,11 +157,7 @@ class State(ValueObject):
 
     @property
     def reward(self) -> np.ndarray:
-        r = np.zeros(2, dtype=np.int8)
-        if self._winner in (0, 1):
-            r[self._winner] = 1
-            r[1 - self._winner] = -1
-        return r
+        return self._reward.copy()
 
     @property
     def actions(self) -> List["Action"]:

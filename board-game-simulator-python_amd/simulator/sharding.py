@@ -3,8 +3,9 @@
 Boards never interact, so the path partitions without any data-path exchange: rank r of R owns the contiguous
 global game ids [r * per_rank, (r + 1) * per_rank).  RNG streams are keyed by GLOBAL game id
 (``Batch.set_first_game``), so the union of the shards is bit-identical to the unsharded run for any R.
-The single collective is the reward gather: every rank contributes int8[per_rank, 2]; torch.distributed's
-"nccl" backend is RCCL on ROCm (xGMI between the GPUs of a node), "gloo" runs the same code on CPUs in tests.
+The single collective is the reward gather to the rank that owns the host array: ranks contribute their 2-bit outcome
+codes (`gather_outcomes_to`; `gather_rewards` ships int8 pairs to every rank instead); torch.distributed's "nccl"
+backend is RCCL on ROCm (xGMI between the GPUs of a node), "gloo" runs the same code on CPUs in tests.
 """
 
 from __future__ import annotations
@@ -38,22 +39,24 @@ def gather_rewards(dist, local_reward, out=None):
     return out
 
 
-def gather_outcomes(dist, local_packed, out=None, async_op: bool = False):
-    """All-gather the ranks' packed 2-bit outcome codes (uint8[per_rank / 4] each; per_rank must be a multiple of 4)
-    into uint8[world * per_rank / 4], ordered by global game id.  0.25 B per game crosses xGMI instead of the 2 B of
-    an int8[.., 2] reward pair; `simulator.batch.expand_outcomes` turns the result into rewards on the device.
+def gather_outcomes_to(dist, local_packed, out=None, dst: int = 0, async_op: bool = False):
+    """Gather the ranks' packed 2-bit outcome codes (uint8[per_rank / 4] each; per_rank a multiple of 4) on rank `dst`:
+    `out` = uint8[world * per_rank / 4] there (ordered by global game id), None elsewhere.  0.25 B per game crosses
+    xGMI instead of the 2 B of an int8 reward pair, and only the rank that owns the host array receives anything
+    (a gather, not an all-gather); `RewardSink.submit_packed` then takes the codes to the host and expands them.
 
-    async_op=True returns (out, work): the collective then runs beside whatever the caller enqueues next, and
-    `work.wait()` (which only makes the CURRENT stream wait) is due before `out` is read."""
-    import torch
-
-    world = dist.get_world_size()
-    if out is None:
-        out = torch.empty(world * local_packed.numel(), dtype=local_packed.dtype, device=local_packed.device)
-    if out.numel() != world * local_packed.numel():
-        raise ValueError("gather buffer has the wrong size")
-    work = dist.all_gather_into_tensor(out, local_packed.contiguous(), async_op=async_op)
-    return (out, work) if async_op else out
+    async_op=True returns the work handle: the collective then runs beside whatever the caller enqueues next, and
+    `work.wait()` (which only makes the CURRENT stream wait) is due before `out` is read or `local_packed` reused."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    local = local_packed.contiguous()
+    if rank == dst:
+        if out is None or out.numel() != world * local.numel() or out.dtype != local.dtype:
+            raise ValueError("rank dst needs a gather buffer of world * len(local_packed) elements")
+        chunks = list(out.view(world, local.numel()).unbind(0))  # views: rank r's codes land in place
+        work = dist.gather(local, gather_list=chunks, dst=dst, async_op=async_op)
+    else:
+        work = dist.gather(local, dst=dst, async_op=async_op)
+    return work if async_op else out
 
 
 def sum_steps(dist, local_steps: int, device) -> int:

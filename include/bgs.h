@@ -62,6 +62,9 @@ typedef enum bgs_buffer_id {
 int bgs_version(void);
 const char* bgs_last_error(void);
 int bgs_device_count(int* count);
+/* hash of the kernel sources this library was built from (16 hex digits): measurement files under profiles/ carry the
+ * id of the build they were taken on, and bench.py refuses to quote instruction counts of another build */
+const char* bgs_build_id(void);
 
 /* ---- configuration + batch lifetime ------------------------------------------------------------- */
 /* replaces connect::Config(height, width, count) + Config::sample_initial_state (connect.cpp:26,32), N at a time.
@@ -76,7 +79,10 @@ int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, 
                       size_t arena_bytes, bgs_batch** out);
 int bgs_destroy(bgs_batch* b);
 
-int bgs_set_stream(bgs_batch* b, void* hip_stream);      /* hipStream_t; NULL = null stream */
+/* hipStream_t; NULL = null stream.  Work already enqueued for the batch on its previous stream is ordered before
+ * anything enqueued on the new one (event + stream wait), so a batch may be created under one stream and used on
+ * another without a host synchronisation. */
+int bgs_set_stream(bgs_batch* b, void* hip_stream);
 int bgs_set_first_game(bgs_batch* b, uint64_t first_game); /* global id of board 0 (sharding across GPUs) */
 int bgs_synchronize(bgs_batch* b);
 int bgs_info(const bgs_batch* b, int* game, int* height, int* width, int* count, int64_t* n, int* planes);
@@ -129,6 +135,47 @@ int bgs_pack_outcomes(bgs_batch* b, void* device_dst);
 /* inverse, batch-independent: packed codes of n boards -> reward int8[n][2] (8-byte aligned), on `device` / stream */
 int bgs_expand_outcomes(int device, void* hip_stream, const void* device_packed, int64_t n, int8_t* device_reward);
 
+/* ---- asynchronous hand-over to HOST memory ------------------------------------------------------------
+ * The reference hands `reward` out as a host ndarray on every call (State::get_reward, connect.cpp:41 / bounce.cpp:38,
+ * tensor.hpp:69-87).  For a batch the hand-over is part of the path: these entry points enqueue it on the batch's
+ * stream and return at once; the caller waits on a bgs_event (or bgs_synchronize) before reading the host buffer.
+ * Destinations must be page-locked (bgs_host_alloc, hipHostMalloc or torch pin_memory) for the copy to be
+ * asynchronous. */
+typedef struct bgs_event bgs_event; /* opaque: a HIP event on the batch's device */
+int bgs_host_alloc(size_t bytes, void** host_ptr);
+int bgs_host_free(void* host_ptr);
+int bgs_event_create(int device, bgs_event** out);
+int bgs_event_destroy(bgs_event* e);
+int bgs_event_synchronize(bgs_event* e);       /* block the calling thread until the work recorded before it is done */
+int bgs_event_query(bgs_event* e, int* done);  /* *done = 1 when that work has completed */
+/* reward int8[n][2] -> host_dst, then record `done` (may be NULL) */
+int bgs_read_reward_async(bgs_batch* b, int8_t* host_dst, bgs_event* done);
+/* 2-bit outcome codes (as bgs_pack_outcomes) uint8[(n + 3) / 4] -> host_dst, then record `done` (may be NULL): 8x
+ * fewer bytes over PCIe than the int8 pairs; bgs_expand_outcomes_host finishes the job on the host */
+int bgs_read_outcomes_async(bgs_batch* b, uint8_t* host_dst, bgs_event* done);
+/* host-side inverse of bgs_pack_outcomes for games [first, first + count) (first a multiple of 4): a table look-up,
+ * no game rule; reward int8[n][2] is indexed by game, so callers may split a batch over threads */
+int bgs_expand_outcomes_host(const uint8_t* packed, int64_t first, int64_t count, int8_t* reward);
+/* bgs_rollout followed by bgs_read_reward_async (codes == 0) or bgs_read_outcomes_async (codes != 0): one call per
+ * batch step for host loops that are launch-rate bound */
+int bgs_rollout_to_host(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, void* host_dst, int codes,
+                        bgs_event* done);
+
+/* A reward sink delivers the rewards of successive batch steps into caller-owned host arrays int8[n][2] while the GPU
+ * goes on playing: per submission the outcome codes cross PCIe into one of `slots` pinned buffers and `threads` host
+ * worker threads expand them as soon as the copy has landed.  Submissions complete in order. */
+typedef struct bgs_reward_sink bgs_reward_sink;
+int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_reward_sink** out);
+int bgs_sink_destroy(bgs_reward_sink* s);
+/* enqueue on the batch's stream: pack -> copy -> (workers) expand into host_reward int8[n][2] (any host memory);
+ * *ticket identifies the submission.  Blocks only while all slots are still in use. */
+int bgs_sink_submit(bgs_reward_sink* s, bgs_batch* b, int8_t* host_reward, int64_t* ticket);
+/* the same for packed codes that are already on the device (the RCCL-gathered codes of all ranks on rank 0):
+ * device_packed uint8[(n_games + 3) / 4], copied on `hip_stream` */
+int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* device_packed, int64_t n_games,
+                           int8_t* host_reward, int64_t* ticket);
+int bgs_sink_wait(bgs_reward_sink* s, int64_t ticket); /* until that submission's rewards are in its host array */
+
 /* ---- loading boards (State::from_json, connect.cpp:46 / bounce.cpp:45; policy-driven stepping) ---- */
 /* grid int8[n][h][w]; player int8[n] (Connect: may be NULL, derived from the stone counts); winner int8[n]
  * (NULL = all running; Connect re-derives wins and draws from the grid when NULL); plies int32[n] (Bounce; NULL =
@@ -142,11 +189,12 @@ int bgs_write_state(bgs_batch* b, const int8_t* grid, const int8_t* player, cons
  *   grid != NULL     load the boards first (as bgs_write_state; player and winner required, plies optional);
  *   actions != NULL  then apply one caller-chosen move per board (as bgs_step_actions; negative first entry skips);
  *   then observe: grid int8[n][h][w], player int8[n], winner int8[n], plies int32[n] and the legal moves of the side
- *   to move -- Connect: uint8[n][width] mask, Bounce: uint64[n][width + 1] target masks (bgs_bounce_read_targets).
+ *   to move -- Connect: uint8[n][width] mask, Bounce: uint64[n][width + 1] target masks (bgs_bounce_read_targets) --
+ *   and reward int8[n][2] as the device holds it (State::get_reward; may be NULL).
  * status int32[n]: 0, BGS_ERR_ARG (malformed board: nothing loaded) or BGS_ERR_ILLEGAL (move refused). */
 int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const int8_t* winner, const int32_t* plies,
                    const int32_t* actions, int32_t* status, int8_t* grid_out, int8_t* player_out, int8_t* winner_out,
-                   int32_t* plies_out, void* legal_out);
+                   int32_t* plies_out, void* legal_out, int8_t* reward_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,419 @@
+"""GPU tests of what sits either side of the rollout kernels: the asynchronous hand-over of rewards to host memory
+(the batch form of State.reward, reference connect.cpp:41 / tensor.hpp:69-87), the device-tensor interface for
+policy-driven stepping (N2), batch <-> reference-shaped JSON states (N4), stream ordering, loader validation and
+bench.py's own N = 2 loop.  Everything goes through the C ABI and is compared with the CPU oracle, bit-exact."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = 0x0123456789ABCDEF
+
+DEFAULT_BOUNCE = np.zeros((9, 6), dtype=np.int8)
+DEFAULT_BOUNCE[1] = DEFAULT_BOUNCE[7] = [1, 2, 3, 3, 2, 1]
+
+
+@pytest.fixture(scope="module")
+def bm():
+    from simulator import batch
+
+    return batch
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    return torch
+
+
+# ------------------------------------------------------------------------------------------------ hand-over
+
+@pytest.mark.parametrize("n", [1, 5, 4096, 100003])
+def test_async_reward_and_outcome_reads(bm, n):
+    dev = bm.ConnectBatch(6, 7, 4, n)
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    pairs = bm.PinnedArray((n, 2), np.int8)
+    codes = bm.PinnedArray(((n + 3) // 4,), np.uint8)
+    ev1, ev2 = bm.HostEvent(0), bm.HostEvent(0)
+    pairs.array[:] = 55
+    dev.rollout(SEED + 1, from_initial=True)
+    dev.read_reward_async(pairs, ev1)
+    dev.read_outcomes_async(codes, ev2)
+    orc.rollout(SEED + 1)
+    ev2.synchronize()  # same stream: the earlier copy has landed too
+    assert ev1.done() and ev2.done()
+    np.testing.assert_array_equal(pairs.array, orc.reward)
+    np.testing.assert_array_equal(bm.expand_outcomes_host(codes, n), orc.reward)
+    # one library call per step, both forms; an unfinished batch (capped) reports 0 / 0 for running boards
+    dev.rollout_to_host(pairs, SEED + 2, max_plies=9, from_initial=True, codes=False, event=ev1)
+    dev.rollout_to_host(codes, SEED + 3, from_initial=True, codes=True, event=ev2)
+    ev1.synchronize()
+    orc.reset()
+    orc.rollout(SEED + 2, max_plies=9)
+    np.testing.assert_array_equal(pairs.array, orc.reward)
+    ev2.synchronize()
+    orc.reset()
+    orc.rollout(SEED + 3)
+    np.testing.assert_array_equal(bm.expand_outcomes_host(codes, n), orc.reward)
+    for obj in (pairs, codes, ev1, ev2, dev):
+        obj.close()
+
+
+@pytest.mark.parametrize("game", ["connect", "bounce"])
+def test_reward_sink_delivers_every_step_in_order(bm, game):
+    """K steps through a sink with fewer slots than steps and several batches in flight: every step's host array must
+    equal the oracle's rewards of that step's seed (the last K steps of a bench-like loop)."""
+    n, steps, depth = 30000, 7, 3
+    if game == "connect":
+        make_dev = lambda: bm.ConnectBatch(6, 7, 4, n)
+        make_orc = lambda: oracle.ConnectOracle(6, 7, 4, n)
+        kw = {}
+    else:
+        n = 3000
+        make_dev = lambda: bm.BounceBatch(DEFAULT_BOUNCE, n)
+        make_orc = lambda: oracle.BounceOracle(DEFAULT_BOUNCE, n)
+        kw = {"max_plies": 300}
+    batches = [make_dev() for _ in range(depth)]
+    sink = bm.RewardSink(n, slots=2, threads=3)
+    hosts = [np.full((n, 2), 42, dtype=np.int8) for _ in range(steps)]
+    tickets = []
+    for i in range(steps):
+        b = batches[i % depth]
+        b.rollout(SEED + i, from_initial=True, **kw)
+        tickets.append(sink.submit(b, hosts[i]))
+    assert tickets == list(range(steps))
+    sink.wait(tickets[-1])  # submissions complete in order
+    orc = make_orc()
+    for i in range(steps):
+        orc.reset()
+        orc.rollout(SEED + i, **kw)
+        np.testing.assert_array_equal(hosts[i], orc.reward, err_msg=f"step {i}")
+    with pytest.raises(ValueError):
+        sink.wait(steps)  # unknown ticket
+    sink.close()
+    for b in batches:
+        b.close()
+
+
+def test_reward_sink_takes_gathered_codes(bm, torch_mod):
+    """Rank 0's side of the multi-GPU gather: codes of several shards, already on the device, to one host array."""
+    torch = torch_mod
+    n, shards = 8192, 3
+    parts = []
+    want = []
+    for r in range(shards):
+        b = bm.ConnectBatch(6, 7, 4, n, use_torch=True)
+        b.set_first_game(r * n)
+        b.rollout(SEED, from_initial=True)
+        parts.append(b.outcomes_tensor())
+        o = oracle.ConnectOracle(6, 7, 4, n)
+        o.rollout(SEED, first_game=r * n)
+        want.append(o.reward)
+        b.close()
+    gathered = torch.cat(parts)
+    torch.cuda.synchronize()
+    sink = bm.RewardSink(shards * n, slots=2, threads=2)
+    host = np.zeros((shards * n, 2), dtype=np.int8)
+    t = sink.submit_packed(gathered, shards * n, host, stream=torch.cuda.current_stream().cuda_stream)
+    sink.wait(t)
+    np.testing.assert_array_equal(host, np.concatenate(want))
+    whole = oracle.ConnectOracle(6, 7, 4, shards * n)
+    whole.rollout(SEED)
+    np.testing.assert_array_equal(host, whole.reward)
+    sink.close()
+
+
+def test_batch_created_under_a_side_stream_is_ordered(bm, torch_mod):
+    """A batch created inside `with torch.cuda.stream(s)` resets itself on the stream it is created on and is then
+    re-bound to s: the first work on s must see the reset boards (stream-ordering race)."""
+    torch = torch_mod
+    n = 1 << 18
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    orc.rollout(SEED ^ 9)
+    for _ in range(4):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            dev = bm.ConnectBatch(6, 7, 4, n, use_torch=True)
+            dev.rollout(SEED ^ 9, from_initial=False)  # reads the planes and status the reset has to have written
+        s.synchronize()
+        np.testing.assert_array_equal(dev.reward, orc.reward)
+        np.testing.assert_array_equal(dev.plies, orc.plies)
+        dev.close()
+
+
+# ------------------------------------------------------------------------------------------------ N2: device tensors
+
+def test_connect_policy_loop_on_device_tensors(bm, torch_mod):
+    """Config 2's geometry: legal mask / grid / action count as device tensors, actions as a device int32 tensor --
+    no host round trip -- against the host readers and the oracle, ply by ply."""
+    torch = torch_mod
+    n = 1 << 16
+    dev = bm.ConnectBatch(6, 7, 4, n, use_torch=True)
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    legal = torch.empty((n, 7), dtype=torch.uint8, device="cuda")
+    grid = torch.empty((n, 6, 7), dtype=torch.int8, device="cuda")
+    for ply in range(43):  # 42 cells + the ply lost to the refused moves below
+        dev.legal_tensor(legal)
+        np.testing.assert_array_equal(legal.cpu().numpy(), orc.legal(), err_msg=f"legal, ply {ply}")
+        if ply % 6 == 0:
+            np.testing.assert_array_equal(dev.grid_tensor(grid).cpu().numpy(), orc.grid)
+            np.testing.assert_array_equal(dev.action_count_tensor().cpu().numpy(), orc.legal().sum(axis=1))
+            np.testing.assert_array_equal(legal.cpu().numpy(), dev.legal)
+        # a torch "policy": random scores, illegal columns masked out; boards that have ended skip (-1)
+        scores = torch.rand((n, 7), device="cuda", generator=gen) + legal.float()
+        cols = torch.where(legal.any(dim=1), scores.argmax(dim=1), torch.full((n,), -1, device="cuda")).to(torch.int32)
+        if ply == 3:
+            cols[::97] = 7  # out of range: refused, board untouched
+        st_dev = dev.step_actions(cols)
+        st_orc = orc.step_actions(cols.cpu().numpy())
+        np.testing.assert_array_equal(st_dev, st_orc)
+        np.testing.assert_array_equal(dev.reward_copy_tensor().cpu().numpy(), orc.reward, err_msg=f"reward, ply {ply}")
+    assert orc.ended.all() and (st_orc == 0).all()
+    np.testing.assert_array_equal(dev.grid, orc.grid)
+    assert dev.steps == int(orc.plies.sum())
+    # without a status read-back the call does not synchronise at all
+    dev.reset()
+    orc.reset()
+    cols = torch.full((n,), 3, dtype=torch.int32, device="cuda")
+    assert dev.step_actions(cols, want_status=False) is None
+    orc.step_actions(cols.cpu().numpy())
+    np.testing.assert_array_equal(dev.grid, orc.grid)
+    with pytest.raises(TypeError):
+        dev.step_actions(cols.to(torch.int64))
+    dev.close()
+
+
+def test_bounce_device_targets_and_moves(bm, torch_mod):
+    """Config 4's geometry: target masks ('t'), action counts ('c') and rewards ('r') exported to device memory,
+    moves chosen on the device from the masks, against the oracle's action lists."""
+    torch = torch_mod
+    n = 1 << 12
+    dev = bm.BounceBatch(DEFAULT_BOUNCE, n, use_torch=True)
+    orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+    w = 6
+    targets = torch.empty((n, w + 1), dtype=torch.int64, device="cuda")
+    rng = np.random.default_rng(8)
+    for ply in range(40):
+        dev._export("t", targets)
+        t_host = targets.cpu().numpy().view(np.uint64)
+        np.testing.assert_array_equal(t_host, dev.targets)
+        counts = dev.action_count_tensor().cpu().numpy()
+        np.testing.assert_array_equal(counts, orc.count_actions(), err_msg=f"ply {ply}")
+        # pick the k-th action of the canonical list per board from the device masks (sources ascending x, targets
+        # ascending cell index) and check a sample of boards against the oracle's explicit lists
+        moves = np.full((n, 4), -1, dtype=np.int32)
+        pick = (rng.random(n) * np.maximum(counts, 1)).astype(np.int64)
+        for i in np.flatnonzero(counts > 0):
+            row, k = int(t_host[i, w]), int(pick[i])
+            for x in range(w):
+                m = int(t_host[i, x])
+                c = bin(m).count("1")
+                if k < c:
+                    cells = [b for b in range(54) if (m >> b) & 1]
+                    moves[i] = (x, row, cells[k] % w, cells[k] // w)
+                    break
+                k -= c
+        for i in rng.integers(0, n, size=16):
+            if counts[i]:
+                src, dst = orc.actions(int(i))[int(pick[i])]
+                assert tuple(moves[i]) == (*src, *dst)
+        st_dev = dev.step_actions(torch.from_numpy(moves).cuda())
+        st_orc = orc.step_actions(moves)
+        np.testing.assert_array_equal(st_dev, st_orc)
+        np.testing.assert_array_equal(dev.reward_copy_tensor().cpu().numpy(), orc.reward)
+        np.testing.assert_array_equal(dev.grid_tensor().cpu().numpy(), orc.grid)
+    assert orc.ended.any()
+    dev.close()
+
+
+def test_device_views_and_dlpack(bm, torch_mod):
+    torch = torch_mod
+    n = 5000
+    dev = bm.ConnectBatch(6, 7, 4, n, use_torch=True)
+    dev.rollout(SEED, from_initial=True)
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    orc.rollout(SEED)
+    rt = dev.reward_tensor()  # zero-copy torch view of the batch's own reward buffer
+    again = torch.from_dlpack(rt.__dlpack__())  # the standard hand-over from here: DLPack, no copy
+    assert again.data_ptr() == rt.data_ptr() == dev.buffer(3)[0]
+    np.testing.assert_array_equal(again.cpu().numpy(), orc.reward)
+    # without torch on the producing side: __cuda_array_interface__ views of the library's buffers
+    for what, want in (("reward", orc.reward), ("status", np.where(orc.winner == 2, 3, orc.winner + 1).astype(np.uint8))):
+        view = dev.device_view(what)
+        t = torch.as_tensor(view, device="cuda")
+        assert t.data_ptr() == view.__cuda_array_interface__["data"][0]
+        np.testing.assert_array_equal(t.cpu().numpy(), want)
+    planes = torch.as_tensor(dev.device_view("planes"), device="cuda")
+    assert tuple(planes.shape) == (2, n)
+    stones = np.array([bin(int(a) & (2**64 - 1)).count("1") + bin(int(b) & (2**64 - 1)).count("1")
+                       for a, b in planes.cpu().numpy().T[:64]])
+    np.testing.assert_array_equal(stones, orc.plies[:64])
+    dev.close()
+
+
+# ------------------------------------------------------------------------------------------------ N4: JSON states
+
+def test_batch_json_states_against_the_reference_fixtures(bm, golden_dir):
+    """Batch.from_json_states / to_json_states on the State JSON dicts the reference's own tests hold
+    (tests/test_connect.py:131-138, tests/test_bounce.py:392-403)."""
+    with open(os.path.join(golden_dir, "reference_connect.json")) as fh:
+        ref = json.load(fh)
+    state = ref["json"]["state"]
+    cfg = ref["json"]["config"]
+    dev = bm.ConnectBatch(cfg["height"], cfg["width"], cfg["count"], 3)
+    assert (dev.from_json_states([state, state, state]) == 0).all()
+    assert dev.to_json_states() == [state] * 3
+    np.testing.assert_array_equal(dev.player, [state["player"]] * 3)
+    dev.close()
+    with open(os.path.join(golden_dir, "reference_bounce.json")) as fh:
+        ref = json.load(fh)
+    state = ref["json"]["state"]
+    dev = bm.BounceBatch(np.array(ref["json"]["config"]["grid"], dtype=np.int8), 2)
+    assert (dev.from_json_states([state, state]) == 0).all()
+    assert dev.to_json_states() == [state, state]
+    dev.close()
+
+
+def test_batch_json_round_trip_of_played_positions(bm):
+    n = 600
+    dev = bm.ConnectBatch(6, 7, 4, n)
+    dev.rollout(SEED, max_plies=23, from_initial=True)  # a mix of running and finished boards
+    states = dev.to_json_states()
+    assert any(s["winner"] == -1 for s in states) and any(s["winner"] in (0, 1) for s in states)
+    other = bm.ConnectBatch(6, 7, 4, n)
+    assert (other.from_json_states(states) == 0).all()
+    assert other.to_json_states() == states
+    np.testing.assert_array_equal(other.reward, dev.reward)
+    dev.rollout(SEED)
+    other.rollout(SEED)
+    np.testing.assert_array_equal(other.grid, dev.grid)
+    bdev = bm.BounceBatch(DEFAULT_BOUNCE, 200)
+    bdev.rollout(SEED, max_plies=12, from_initial=True)
+    states = bdev.to_json_states()
+    bother = bm.BounceBatch(DEFAULT_BOUNCE, 200)
+    assert (bother.from_json_states(states) == 0).all()
+    assert bother.to_json_states() == states
+    with pytest.raises(TypeError):
+        bother.from_json_states(states[:3])
+    with pytest.raises(RuntimeError):
+        bother.from_json_states([{"grid": 1}] * 200)
+    for b in (dev, other, bdev, bother):
+        b.close()
+
+
+# ------------------------------------------------------------------------------------------------ loader validation
+
+def test_connect_loader_cross_checks_the_winner_against_the_grid(bm):
+    """A declared winner has to be the one the grid implies: winner = -1 on a board that holds a
+    k-run, a run for the side that did not move last, or a wrong winner are refused and leave the board untouched."""
+    dev = bm.ConnectBatch(6, 7, 4, 6)
+    e = -1
+    won = np.full((6, 7), e, dtype=np.int8)  # player 0 has four in the bottom row, player 1 three stones
+    won[0, :4] = 0
+    won[1, :3] = 1
+    running = np.full((6, 7), e, dtype=np.int8)
+    running[0, :3] = 0
+    running[1, :3] = 1
+    late = won.copy()  # ... and player 1 moved once more AFTER the run was complete
+    late[1, 3] = 1
+    grids = np.stack([won, won, won, running, running, late])
+    winner = np.array([0, -1, 1, -1, 0, 0], dtype=np.int8)
+    player = np.array([1, 1, 1, 0, 0, 0], dtype=np.int8)
+    status = dev.write_state(grids, player, winner)
+    np.testing.assert_array_equal(status, [0, -1, -1, 0, -1, -1])
+    np.testing.assert_array_equal(dev.winner, [0, -1, -1, -1, -1, -1])
+    np.testing.assert_array_equal(dev.reward[0], [1, -1])
+    # derived winners (winner=None) agree with the oracle's verdict on played-out boards
+    big = bm.ConnectBatch(6, 7, 4, 4000)
+    orc = oracle.ConnectOracle(6, 7, 4, 4000)
+    orc.rollout(SEED)
+    assert (big.write_state(orc.grid) == 0).all()
+    np.testing.assert_array_equal(big.winner, orc.winner)
+    np.testing.assert_array_equal(big.reward, orc.reward)
+    # the fused kernels and the per-ply kernel agree on what a loaded board is: nothing moves on finished boards
+    big.rollout(SEED)
+    np.testing.assert_array_equal(big.grid, orc.grid)
+    assert big.steps == 0
+    dev.close()
+    big.close()
+
+
+def test_bounce_plies_saturate_instead_of_wrapping(bm):
+    """Plies are stored as uint16: a board at 65535 plies is not stepped any further."""
+    n = 4
+    dev = bm.BounceBatch(DEFAULT_BOUNCE, n)
+    grid = np.repeat(DEFAULT_BOUNCE[None], n, axis=0)
+    plies = np.array([65535, 65534, 65533, 0], dtype=np.int32)
+    player = (plies & 1).astype(np.int8)
+    assert (dev.write_state(grid, player, None, plies) == 0).all()
+    for _ in range(3):
+        dev.step_random(SEED)
+    np.testing.assert_array_equal(dev.plies, [65535, 65535, 65535, 3])
+    moves = np.array([[0, 7, 0, 6]] * n, dtype=np.int32)  # a legal move for player 1 on the untouched board 0
+    assert dev.step_actions(moves)[0] == -2
+    np.testing.assert_array_equal(dev.grid[0], DEFAULT_BOUNCE)
+    dev.close()
+
+
+def test_object_api_reward_comes_from_the_device(bm):
+    from simulator.game.connect import Config
+
+    s = Config(2, 3, 2).sample_initial_state()
+    np.testing.assert_array_equal(s.reward, [0, 0])
+    for col in (1, 1, 2):
+        s = s.action_at(col).sample_next_state()
+    assert s.has_ended
+    np.testing.assert_array_equal(s.reward, [1, -1])  # tests/test_connect.py:115
+    assert s.reward.dtype == np.int8 and s.reward is not s.reward
+
+
+# ------------------------------------------------------------------------------------------------ bench.py, N = 2
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_two_ranks_gloo_rehearsal():
+    """bench.py's own N > 1 loop (shards, per-step gather of codes to rank 0, sink, host array) as two child processes
+    sharing this box's GPU, with gloo standing in for RCCL: rank 0's host array must verify."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch",
+               str(1 << 16), "--no-cpu-baseline"]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["gathered_rewards_verified"] is True
+    assert d["config"]["rewards_to_host"] is True and d["config"]["global_batch"] == 2 << 16
+    assert not outs[1][0].strip()  # only rank 0 prints
+
+
+def test_bench_single_gpu_line():
+    """The default hand-over on one GPU at a small batch: contract fields, host rewards verified against the oracle."""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--batch",
+                           str(1 << 16)], capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["rewards_to_host"] is True and d["cpu_baseline"]["parity_with_host_rewards"] is True
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] <= 1
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    assert d["device_resident"]["value"] > 0 and d["steps"] == 12 and d["warmup"] == 3

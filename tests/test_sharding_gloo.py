@@ -1,7 +1,9 @@
-"""N > 1 path on CPU: two `gloo` ranks shard a batch by global game id, gather the rewards with the same host code
-bench.py uses over RCCL, and rank 0 compares with the unsharded run.  The boards themselves come from the CPU oracle
-here (no GPU in this test); on the GPU box the same property is checked on the device by
-tests/test_gpu_parity.py::test_connect_sharding_is_invisible."""
+"""N > 1 path on CPU: two `gloo` ranks shard a batch by global game id and deliver the rewards to rank 0's host array
+with the same host code bench.py runs over RCCL -- `gather_outcomes_to` (2-bit codes, gather to rank 0, synchronous and
+async_op + wait) followed by the library's host expansion -- and rank 0 compares with the unsharded run, game order
+included.  The boards themselves come from the CPU oracle here (no GPU in this test); on the GPU box
+tests/test_gpu_handover.py::test_bench_two_ranks_gloo_rehearsal runs bench.py's own N = 2 loop, and
+tests/test_gpu_parity.py::test_connect_sharding_is_invisible checks the sharding property on the device."""
 
 import os
 import socket
@@ -17,7 +19,13 @@ WORKER = textwrap.dedent(
     sys.path[:0] = [{root!r}, os.path.join({root!r}, "board-game-simulator-python_amd")]
     import numpy as np, torch, torch.distributed as dist
     from oracle import oracle
-    from simulator.sharding import gather_rewards, shard_range, sum_steps
+    from simulator.batch import expand_outcomes_host
+    from simulator.sharding import gather_outcomes_to, gather_rewards, shard_range, sum_steps
+
+    def pack_codes(winner):  # what bgs_pack_outcomes does on the device: 2 bits per game, game 4i in the low bits
+        status = np.where(winner == -1, 0, np.where(winner == 2, 3, winner + 1)).astype(np.uint8)
+        q = status.reshape(-1, 4)
+        return (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8)
 
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -27,11 +35,29 @@ WORKER = textwrap.dedent(
     shard = oracle.ConnectOracle(6, 7, 4, count)
     steps = shard.rollout(seed, first_game=first)
     gathered = gather_rewards(dist, torch.from_numpy(shard.reward))
+    # the path bench.py takes: codes -> gather to rank 0 -> host expansion into the one array
+    local = torch.from_numpy(pack_codes(shard.winner))
+    buf = torch.empty(world * local.numel(), dtype=torch.uint8) if rank == 0 else None
+    out = gather_outcomes_to(dist, local, buf, dst=0)
+    assert (out is None) == (rank != 0)
+    buf2 = torch.zeros(world * local.numel(), dtype=torch.uint8) if rank == 0 else None
+    work = gather_outcomes_to(dist, local, buf2, dst=0, async_op=True)
+    work.wait()
     all_steps = sum_steps(dist, steps, "cpu")
     if rank == 0:
         whole = oracle.ConnectOracle(6, 7, 4, total)
         assert whole.rollout(seed) == all_steps
         assert np.array_equal(gathered.numpy(), whole.reward)
+        assert torch.equal(buf, buf2)
+        host = np.full((total, 2), 77, dtype=np.int8)
+        expand_outcomes_host(buf2.numpy(), total, host)
+        assert np.array_equal(host, whole.reward), "gathered codes are not in global game order"
+        assert not np.array_equal(host[:count], host[count:])  # the shards differ, so the order check means something
+        try:
+            gather_outcomes_to(dist, local, torch.empty(3, dtype=torch.uint8), dst=0)
+            raise SystemExit("a wrong gather buffer was accepted")
+        except ValueError:
+            pass
         print("GLOO_SHARDING_OK", all_steps)
     dist.barrier()
     dist.destroy_process_group()

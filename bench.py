@@ -252,25 +252,32 @@ def main() -> int:
     def one_step(i, with_handover, ev=None):
         k = i % depth
         b = batches[k]
+        if dist is None:
+            # one GPU: library calls only (each batch is bound to its own stream), no torch stream switching
+            if with_handover:
+                settle(k)
+            if ev is not None:
+                ev[0].record(streams[k])
+            if not with_handover or handover == "none":
+                b.rollout(SEED + i, from_initial=True)
+            elif handover == "codes":
+                tickets[k] = sink.rollout(b, host_rewards[k], SEED + i, from_initial=True)
+            else:
+                b.rollout_to_host(host_rewards[k], SEED + i, from_initial=True, codes=False, event=events[k])
+                events[k].armed = True
+            if ev is not None:
+                ev[1].record(streams[k])  # (with a hand-over the bracket includes the pack kernel or the copy: the
+                # rollout kernel's own duration is taken from the device-resident pass then)
+            return
         with torch.cuda.stream(streams[k]):
             if with_handover:
                 settle(k)
             if ev is not None:
                 ev[0].record(streams[k])
-            if with_handover and handover == "pairs":
-                b.rollout_to_host(host_rewards[k], SEED + i, from_initial=True, codes=False, event=events[k])
-                events[k].armed = True
-                if ev is not None:
-                    ev[1].record(streams[k])  # (includes the copy: the kernel-only duration comes from stride steps of
-                    # the device-resident pass when this mode is chosen)
-                return
             b.rollout(SEED + i, from_initial=True)
             if ev is not None:
                 ev[1].record(streams[k])
             if not with_handover or handover == "none":
-                return
-            if dist is None:
-                tickets[k] = sink.submit(b, host_rewards[k])
                 return
             # N > 1: the path's only exchange -- every rank's outcome codes to rank 0 (RCCL over xGMI), asynchronous, so
             # the stream goes straight on to its next rollout; rank 0's sink takes the codes to the host one turn later
@@ -349,8 +356,8 @@ def main() -> int:
             st_local = sum_steps(dist, st_local, device)
         device_resident = {"value": st_local / dt, "unit": "env-steps/s", "ms_per_step": dt / reps * 1e3, "steps": reps,
                            "kernel_ms_per_launch": k_ms}
-        if handover == "pairs":
-            kernel_ms = k_ms  # the pairs-mode brackets include the copy
+        if dist is None:
+            kernel_ms = k_ms  # the hand-over brackets include the pack kernel / the copy
 
     if rank == 0:
         value = steps_total / elapsed

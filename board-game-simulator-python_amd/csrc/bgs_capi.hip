@@ -242,6 +242,29 @@ k_pack_outcomes(const uint8_t* __restrict__ status, int64_t n, uint8_t* __restri
     packed[t] = (uint8_t)((four & 3u) | ((four >> 6) & 0xCu) | ((four >> 12) & 0x30u) | ((four >> 18) & 0xC0u));
 }
 
+// the same codes, 64 boards per lane: four 16-byte status loads in, one 16-byte store out, so a wave writes 1 KiB of
+// contiguous codes -- the form used when the destination is page-locked HOST memory and every store is a PCIe write
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_pack_outcomes_wide(const uint8_t* __restrict__ status, int64_t groups, uint4* __restrict__ packed) {
+    const int64_t t = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (t >= groups) return;
+    const uint4* src = reinterpret_cast<const uint4*>(status) + t * 4;
+    uint32_t out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 v = src[q];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t four = w[j];
+            acc |= ((four & 3u) | ((four >> 6) & 0xCu) | ((four >> 12) & 0x30u) | ((four >> 18) & 0xC0u)) << (8 * j);
+        }
+        out[q] = acc;
+    }
+    packed[t] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_expand_outcomes(const uint8_t* __restrict__ packed, int64_t n, uint16_t* __restrict__ reward) {
     const int64_t t = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
@@ -281,9 +304,17 @@ int reset_impl(bgs_batch* b) {
 
 namespace bgs {
 void pack_outcomes(const bgs_batch* b, uint8_t* d_packed) {
-    const int64_t bytes = (b->n + 3) / 4;
-    hipLaunchKernelGGL(k_pack_outcomes, dim3((unsigned)((bytes + BGS_BLOCK - 1) / BGS_BLOCK)), dim3(BGS_BLOCK), 0, b->stream,
-                       b->d_status, b->n, d_packed);
+    // whole groups of 64 boards go through the wide kernel (16-byte aligned destination), the rest byte by byte
+    const int64_t groups = ((uintptr_t)d_packed % 16 == 0) ? b->n / 64 : 0;
+    if (groups)
+        hipLaunchKernelGGL(k_pack_outcomes_wide, dim3((unsigned)((groups + BGS_BLOCK - 1) / BGS_BLOCK)), dim3(BGS_BLOCK), 0,
+                           b->stream, b->d_status, groups, reinterpret_cast<uint4*>(d_packed));
+    const int64_t done = groups * 64, rest = b->n - done;
+    if (rest > 0) {
+        const int64_t bytes = (rest + 3) / 4;
+        hipLaunchKernelGGL(k_pack_outcomes, dim3((unsigned)((bytes + BGS_BLOCK - 1) / BGS_BLOCK)), dim3(BGS_BLOCK), 0,
+                           b->stream, b->d_status + done, rest, d_packed + done / 4);
+    }
 }
 }  // namespace bgs
 

@@ -4,10 +4,13 @@
 // bounce.cpp:38, through the copying caster tensor.hpp:69-87).  For a batch that hand-over is part of the path and has
 // to keep up with the rollout kernel (one batch of 2^20 games every ~50 us), so it is
 //   device:  status bytes -> 2-bit outcome codes (k_pack_outcomes, 0.25 B per game)
-//   PCIe:    one hipMemcpyAsync of the codes into a page-locked slot (256 KiB per 2^20 games)
-//   host:    worker threads expand codes -> int8[n][2] reward pairs in the caller's array (table look-up)
+//   PCIe:    the pack kernel stores the codes straight into a page-locked, device-mapped slot (256 KiB per 2^20
+//            games, 16-byte stores; no copy call: a hipMemcpyAsync costs the launching thread more than the kernel)
+//   host:    worker threads expand codes -> int8[n][2] reward pairs in the caller's array (AVX2 / table look-up)
 // all of it enqueued behind the rollout on the batch's stream and overlapped with the next batches' kernels.
 // No game rule lives here: a reward pair is a fixed function of the outcome code (bgs_common.h reward_pair).
+#include <immintrin.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
@@ -43,16 +46,41 @@ struct ExpandTable {
 };
 const ExpandTable g_expand;
 
+// 8 code bytes (32 games) -> 64 reward bytes per iteration with AVX2: every code byte is replicated to the four byte
+// positions of its games, the 2-bit field of each position is isolated in place, and "field == 1" / "field == 2"
+// compares (0 / -1 per byte) give r0 = is2 - is1 and r1 = is1 - is2, interleaved into (r0, r1) pairs.
+__attribute__((target("avx2"))) int64_t expand_avx2(const uint8_t* src, int64_t code_bytes, int8_t* dst) {
+    const __m256i spread = _mm256_setr_epi8(0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3,
+                                            4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7);
+    const __m256i field = _mm256_set1_epi32((int)0xC0300C03u);  // bytes 0x03, 0x0C, 0x30, 0xC0
+    const __m256i one = _mm256_set1_epi32(0x40100401);           // code 1 in each position
+    const __m256i two = _mm256_set1_epi32((int)0x80200802u);    // code 2 in each position
+    int64_t i = 0;
+    for (; i + 8 <= code_bytes; i += 8) {
+        long long eight;
+        memcpy(&eight, src + i, 8);
+        const __m256i rep = _mm256_shuffle_epi8(_mm256_set1_epi64x(eight), spread);
+        const __m256i f = _mm256_and_si256(rep, field);
+        const __m256i is1 = _mm256_cmpeq_epi8(f, one), is2 = _mm256_cmpeq_epi8(f, two);
+        const __m256i r0 = _mm256_sub_epi8(is2, is1), r1 = _mm256_sub_epi8(is1, is2);
+        const __m256i lo = _mm256_unpacklo_epi8(r0, r1), hi = _mm256_unpackhi_epi8(r0, r1);
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + 8 * i), _mm256_permute2x128_si256(lo, hi, 0x20));
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + 8 * i + 32), _mm256_permute2x128_si256(lo, hi, 0x31));
+    }
+    return i;  // code bytes consumed
+}
+
+const bool g_have_avx2 = __builtin_cpu_supports("avx2");
+
 void expand_range(const uint8_t* packed, int64_t first, int64_t count, int8_t* reward) {
-    // whole code bytes through the table, 8 bytes per look-up; a ragged tail pair by pair
+    // whole code bytes: AVX2 where the CPU has it, the 256-entry table otherwise and for the last few bytes; a ragged
+    // tail pair by pair
     const int64_t whole = count / 4;
     const uint8_t* src = packed + first / 4;
-    uint64_t* dst = reinterpret_cast<uint64_t*>(reward + 2 * first);  // first % 4 == 0: 8-byte aligned if `reward` is
-    if ((reinterpret_cast<uintptr_t>(dst) & 7u) == 0) {
-        for (int64_t i = 0; i < whole; ++i) dst[i] = g_expand.pairs[src[i]];
-    } else {
-        for (int64_t i = 0; i < whole; ++i) memcpy(reinterpret_cast<uint8_t*>(dst) + 8 * i, &g_expand.pairs[src[i]], 8);
-    }
+    int8_t* out = reward + 2 * first;
+    int64_t i0 = 0;
+    if (g_have_avx2) i0 = expand_avx2(src, whole, out);
+    for (int64_t i = i0; i < whole; ++i) memcpy(out + 8 * i, &g_expand.pairs[src[i]], 8);
     for (int64_t g = first + whole * 4; g < first + count; ++g) {
         const uint16_t pair = bgs::reward_pair((uint32_t)(packed[g / 4] >> (2 * (g & 3))) & 3u);
         memcpy(reward + 2 * g, &pair, 2);
@@ -75,7 +103,8 @@ struct bgs_reward_sink {
     int slots = 0;
     int threads = 0;
     std::vector<uint8_t*> pinned;     // [slots] page-locked code buffers, (max_games + 3) / 4 bytes each
-    std::vector<uint8_t*> scratch;    // [slots] device buffers the batch's codes are packed into
+    std::vector<uint8_t*> mapped;     // [slots] the same buffers as the device sees them: the pack kernel stores its
+                                      //         codes straight into host memory (one PCIe write per 16 B, no copy call)
     std::vector<hipEvent_t> landed;   // [slots] recorded behind the copy into pinned[slot]
     struct Job {
         int64_t n_games = 0;
@@ -264,16 +293,15 @@ int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_r
         void* host = nullptr;
         void* dev = nullptr;
         hipEvent_t ev = nullptr;
-        err = hipHostMalloc(&host, bytes, hipHostMallocDefault);
+        err = hipHostMalloc(&host, bytes, hipHostMallocMapped);
         if (err == hipSuccess) s->pinned.push_back(static_cast<uint8_t*>(host));
-        if (err == hipSuccess) err = hipMalloc(&dev, bytes);
-        if (err == hipSuccess) s->scratch.push_back(static_cast<uint8_t*>(dev));
+        if (err == hipSuccess) err = hipHostGetDevicePointer(&dev, host, 0);
+        if (err == hipSuccess) s->mapped.push_back(static_cast<uint8_t*>(dev));
         if (err == hipSuccess) err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (err == hipSuccess) s->landed.push_back(ev);
     }
     if (err != hipSuccess) {
         for (auto p : s->pinned) (void)hipHostFree(p);
-        for (auto p : s->scratch) (void)hipFree(p);
         for (auto e : s->landed) (void)hipEventDestroy(e);
         delete s;
         return fail(BGS_ERR_RUNTIME, "reward sink allocation failed: %s", hipGetErrorString(err));
@@ -294,7 +322,6 @@ int bgs_sink_destroy(bgs_reward_sink* s) {
     for (auto& w : s->workers) w.join();
     (void)hipSetDevice(s->device);
     for (auto p : s->pinned) (void)hipHostFree(p);
-    for (auto p : s->scratch) (void)hipFree(p);
     for (auto e : s->landed) (void)hipEventDestroy(e);
     delete s;
     return BGS_OK;
@@ -308,13 +335,19 @@ int bgs_sink_submit(bgs_reward_sink* s, bgs_batch* b, int8_t* host_reward, int64
     if (rc) return rc;
     const int64_t t = claim(s);
     const int slot = (int)(t % s->slots);
-    bgs::pack_outcomes(b, s->scratch[slot]);
+    bgs::pack_outcomes(b, s->mapped[slot]);  // the codes go straight into the page-locked slot
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(s->pinned[slot], s->scratch[slot], (size_t)(b->n + 3) / 4, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipEventRecord(s->landed[slot], b->stream));
     publish(s, t, b->n, host_reward);
     if (ticket) *ticket = t;
     return BGS_OK;
+}
+
+int bgs_sink_rollout(bgs_reward_sink* s, bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags,
+                     int8_t* host_reward, int64_t* ticket) {
+    int rc = bgs_rollout(b, seed, max_plies, flags);
+    if (rc) return rc;
+    return bgs_sink_submit(s, b, host_reward, ticket);
 }
 
 int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* device_packed, int64_t n_games,

@@ -130,6 +130,19 @@ class RewardSink:
         _abi.check(_abi.lib().bgs_sink_submit(self._handle, batch._handle, ctypes.c_void_p(_host_ptr(host_reward)), ctypes.byref(ticket)))
         return ticket.value
 
+    def rollout(self, batch: "_Batch", host_reward, seed: int = DEFAULT_SEED, max_plies: int = 2**31 - 1,
+                from_initial: bool = False) -> int:
+        """`batch.rollout(...)` + `submit(batch, host_reward)` in one library call (bgs_sink_rollout)."""
+        flags = _abi.ROLLOUT_FROM_INITIAL if from_initial else 0
+        ticket = ctypes.c_int64(-1)
+        _abi.check(
+            _abi.lib().bgs_sink_rollout(
+                self._handle, batch._handle, ctypes.c_uint64(seed), ctypes.c_int32(max_plies), ctypes.c_uint32(flags),
+                ctypes.c_void_p(_host_ptr(host_reward)), ctypes.byref(ticket),
+            )
+        )
+        return ticket.value
+
     def submit_packed(self, device_packed, n_games: int, host_reward, stream: int = 0) -> int:
         """`device_packed`: CUDA uint8 tensor (or device address) of the codes of n_games games, e.g. the RCCL-gathered
         codes of all ranks; copied on HIP stream `stream`."""

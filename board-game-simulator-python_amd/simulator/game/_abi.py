@@ -97,6 +97,10 @@ SIGNATURES = {
     "bgs_sink_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_handle)]),
     "bgs_sink_destroy": (ctypes.c_int, [c_handle]),
     "bgs_sink_submit": (ctypes.c_int, [c_handle, c_handle, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "bgs_sink_rollout": (
+        ctypes.c_int,
+        [c_handle, c_handle, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
+    ),
     "bgs_sink_submit_packed": (
         ctypes.c_int,
         [c_handle, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],

@@ -167,9 +167,13 @@ int bgs_rollout_to_host(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t
 typedef struct bgs_reward_sink bgs_reward_sink;
 int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_reward_sink** out);
 int bgs_sink_destroy(bgs_reward_sink* s);
-/* enqueue on the batch's stream: pack -> copy -> (workers) expand into host_reward int8[n][2] (any host memory);
- * *ticket identifies the submission.  Blocks only while all slots are still in use. */
+/* enqueue on the batch's stream: the pack kernel stores the codes straight into a page-locked slot (device-mapped host
+ * memory: no copy call), an event marks their arrival, the workers expand into host_reward int8[n][2] (any host
+ * memory); *ticket identifies the submission.  Blocks only while all slots are still in use. */
 int bgs_sink_submit(bgs_reward_sink* s, bgs_batch* b, int8_t* host_reward, int64_t* ticket);
+/* bgs_rollout followed by bgs_sink_submit: one library call per batch step */
+int bgs_sink_rollout(bgs_reward_sink* s, bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags,
+                     int8_t* host_reward, int64_t* ticket);
 /* the same for packed codes that are already on the device (the RCCL-gathered codes of all ranks on rank 0):
  * device_packed uint8[(n_games + 3) / 4], copied on `hip_stream` */
 int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* device_packed, int64_t n_games,

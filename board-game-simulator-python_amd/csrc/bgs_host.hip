@@ -113,28 +113,46 @@ struct bgs_reward_sink {
     std::vector<Job> jobs;            // [slots]
     std::mutex mu;
     std::condition_variable cv_submit;   // a job was published / shutdown
+    std::condition_variable cv_landed;   // a job's codes have arrived in its slot / shutdown
     std::condition_variable cv_done;     // a job completed
     int64_t submitted = 0;               // tickets handed out: jobs [0, submitted) are published
+    int64_t landed_upto = 0;             // the codes of jobs [0, landed_upto) are in their slots
     int64_t completed = 0;               // jobs [0, completed) are in their host arrays
     std::vector<int> parts_done;         // [slots] workers that finished their share of the slot's job
     bool stop = false;
     bool failed = false;
     std::vector<std::thread> workers;
 
+    // Worker 0 is the only thread that waits in the HIP runtime: it sleeps until a job is published, waits for the
+    // slot's event, then releases the others.  (Every worker waiting on the event itself kept several cores spinning
+    // in hipEventSynchronize beside the thread that launches the kernels.)
     void work(int t) {
         (void)hipSetDevice(device);
         for (int64_t ticket = 0;; ++ticket) {
-            Job job;
-            {
-                std::unique_lock<std::mutex> lock(mu);
-                cv_submit.wait(lock, [&] { return stop || submitted > ticket; });
-                if (submitted <= ticket) return;  // stop, nothing left for this worker
-                job = jobs[ticket % slots];
-            }
             const int slot = (int)(ticket % slots);
-            // every worker waits for the copy itself: hipEventSynchronize from several threads on one event is fine,
-            // and nobody has to forward the wake-up
-            const bool ok = hipEventSynchronize(landed[slot]) == hipSuccess;
+            Job job;
+            bool ok = true;
+            if (t == 0) {
+                {
+                    std::unique_lock<std::mutex> lock(mu);
+                    cv_submit.wait(lock, [&] { return stop || submitted > ticket; });
+                    if (submitted <= ticket) return;  // stop, nothing left
+                    job = jobs[slot];
+                }
+                ok = hipEventSynchronize(landed[slot]) == hipSuccess;
+                {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (!ok) failed = true;
+                    landed_upto = ticket + 1;
+                }
+                cv_landed.notify_all();
+            } else {
+                std::unique_lock<std::mutex> lock(mu);
+                cv_landed.wait(lock, [&] { return stop || landed_upto > ticket; });
+                if (landed_upto <= ticket) return;  // stop, nothing left
+                job = jobs[slot];  // published before its event could complete, and not reused before this job is done
+                ok = !failed;
+            }
             if (ok) {
                 // shares are multiples of 4 games (one code byte), so threads never touch the same output word
                 const int64_t bytes = (job.n_games + 3) / 4;
@@ -146,7 +164,6 @@ struct bgs_reward_sink {
             }
             {
                 std::lock_guard<std::mutex> lock(mu);
-                if (!ok) failed = true;
                 if (++parts_done[slot] == threads) {
                     parts_done[slot] = 0;
                     ++completed;  // jobs complete in ticket order: every worker walks the tickets in order
@@ -173,7 +190,7 @@ void publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_r
         s->jobs[ticket % s->slots].host_reward = host_reward;
         s->submitted = ticket + 1;
     }
-    s->cv_submit.notify_all();
+    s->cv_submit.notify_one();  // only worker 0 waits here
 }
 
 }  // namespace
@@ -319,6 +336,7 @@ int bgs_sink_destroy(bgs_reward_sink* s) {
         s->stop = true;
     }
     s->cv_submit.notify_all();
+    s->cv_landed.notify_all();
     for (auto& w : s->workers) w.join();
     (void)hipSetDevice(s->device);
     for (auto p : s->pinned) (void)hipHostFree(p);

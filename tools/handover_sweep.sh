@@ -10,13 +10,14 @@ run() {
     python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'args': '$*', 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'kernel_ms': d['roofline']['kernel_ms_per_launch'], 'device_resident': (d.get('device_resident') or {}).get('value')}))" >> $out
   tail -1 $out
 }
-run --handover none --inflight 2 --no-device-resident
-run --handover none --inflight 3 --no-device-resident
-run --handover none --inflight 4 --no-device-resident
-for d in 2 3 4; do
-  run --handover pairs --inflight $d --no-device-resident
-  for t in 2 4 8; do
-    run --handover codes --inflight $d --host-threads $t --no-device-resident
+for rep in 1 2; do
+  run --handover none --inflight 2 --no-device-resident
+  run --handover none --inflight 3 --no-device-resident
+  run --handover pairs --inflight 2 --no-device-resident
+  for d in 2 3 4; do
+    for t in 1 2 3 4 6; do
+      run --handover codes --inflight $d --host-threads $t --no-device-resident
+    done
   done
 done
-run --handover codes --inflight 3 --host-threads 4
+run --handover codes --inflight 3 --host-threads 3

@@ -141,7 +141,7 @@ def main() -> int:
                     "rollout, its copy to the host and (N > 1) its reward gather overlap the next rollouts (default 3)")
     ap.add_argument("--handover", choices=("codes", "pairs", "none"), default="codes",
                     help="how a step's rewards reach the host array (see the module docstring)")
-    ap.add_argument("--host-threads", type=int, default=4, help="worker threads of the reward sink (--handover codes)")
+    ap.add_argument("--host-threads", type=int, default=3, help="worker threads of the reward sink (--handover codes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-resident", action="store_true",
                     help="skip the extra, separately timed pass without hand-over that fills `device_resident`")
@@ -195,6 +195,10 @@ def main() -> int:
     owner = rank == 0  # rank 0 owns "the one host array"
     # per in-flight slot: the batch; (N > 1) its packed outcome codes and, on rank 0, the gathered codes of all ranks;
     # the HOST array the step's rewards end in: int8[world * n, 2] on rank 0 (N = 1: int8[n, 2])
+    # One GPU: the hand-over pipeline is deeper than the GPU's (twice as many host arrays / sink slots as streams), so
+    # the launching thread waits for the delivery of step i - 2 * depth, not i - depth, before it enqueues step i:
+    # waiting on the previous step of the SAME stream would leave the GPU one batch short for the length of the delivery
+    host_slots = 2 * depth if world == 1 else depth
     batches, packed, all_packed, host_rewards, events = [], [], [], [], []
     for s in streams:
         with torch.cuda.stream(s):
@@ -203,6 +207,7 @@ def main() -> int:
             batches.append(b)
             packed.append(torch.empty(code_bytes, dtype=torch.uint8, device=gpu) if world > 1 else None)
             all_packed.append(torch.empty(world * code_bytes, dtype=torch.uint8, device=gpu) if world > 1 and owner else None)
+    for _ in range(host_slots):
         if handover == "pairs":
             host_rewards.append(PinnedArray((n, 2), np.int8))
             events.append(HostEvent(local_rank))
@@ -212,7 +217,7 @@ def main() -> int:
         else:
             host_rewards.append(None)
             events.append(None)
-    sink = RewardSink(world * n, slots=depth, threads=max(1, args.host_threads), device=local_rank) \
+    sink = RewardSink(world * n, slots=host_slots, threads=max(1, args.host_threads), device=local_rank) \
         if handover == "codes" and owner else None
     device = gpu if backend == "nccl" else torch.device("cpu")
 
@@ -222,8 +227,8 @@ def main() -> int:
             dist.barrier()
             torch.cuda.synchronize()
 
-    tickets = [None] * depth   # the sink ticket of the step last submitted from each slot
-    pending = [None] * depth   # the in-flight reward gather of each slot (N > 1)
+    tickets = [None] * host_slots  # the sink ticket of the step last delivered into each host array
+    pending = [None] * depth       # the in-flight reward gather of each stream slot (N > 1)
 
     def settle(k, final=False):
         """Bring slot k's earlier steps one stage further before the slot is reused.  The stages of a step are
@@ -233,7 +238,7 @@ def main() -> int:
         if tickets[k] is not None:      # the step submitted to the sink one turn ago: its rewards are in the host array
             sink.wait(tickets[k])
             tickets[k] = None
-        if pending[k] is not None:      # the gather started one turn ago
+        if k < depth and pending[k] is not None:      # the gather started one turn ago
             pending[k].wait()           # (only makes stream k wait for the collective)
             pending[k] = None
             if owner:                   # the gathered codes are on rank 0's device: the sink takes them to the host
@@ -254,17 +259,18 @@ def main() -> int:
         b = batches[k]
         if dist is None:
             # one GPU: library calls only (each batch is bound to its own stream), no torch stream switching
+            h = i % host_slots
             if with_handover:
-                settle(k)
+                settle(h)
             if ev is not None:
                 ev[0].record(streams[k])
             if not with_handover or handover == "none":
                 b.rollout(SEED + i, from_initial=True)
             elif handover == "codes":
-                tickets[k] = sink.rollout(b, host_rewards[k], SEED + i, from_initial=True)
+                tickets[h] = sink.rollout(b, host_rewards[h], SEED + i, from_initial=True)
             else:
-                b.rollout_to_host(host_rewards[k], SEED + i, from_initial=True, codes=False, event=events[k])
-                events[k].armed = True
+                b.rollout_to_host(host_rewards[h], SEED + i, from_initial=True, codes=False, event=events[h])
+                events[h].armed = True
             if ev is not None:
                 ev[1].record(streams[k])  # (with a hand-over the bracket includes the pack kernel or the copy: the
                 # rollout kernel's own duration is taken from the device-resident pass then)
@@ -290,8 +296,8 @@ def main() -> int:
                     expand_outcomes_host(got.numpy(), world * n, host_rewards[k])
 
     def drain():
-        for k in range(depth):
-            with torch.cuda.stream(streams[k]):
+        for k in range(host_slots):
+            with torch.cuda.stream(streams[k % depth]):
                 settle(k, final=True)
 
     def timed_region(first_step, count, with_handover, stride):
@@ -332,7 +338,8 @@ def main() -> int:
     # the host array of the LAST timed step (a copy: the extra passes below reuse the slots)
     final_host = None
     if owner and handover != "none":
-        final_host = np.array(host_rewards[last % depth].array if handover == "pairs" else host_rewards[last % depth])
+        slot = last % host_slots
+        final_host = np.array(host_rewards[slot].array if handover == "pairs" else host_rewards[slot])
 
     gather_ok = None
     if dist is not None and owner:

@@ -1,30 +1,47 @@
+"""Host enqueue cost of the bench loop's library calls (one GPU): per repetition, the time the launching thread needs
+per step (enqueue) and the time per step until the GPU has finished (total).  enqueue ~ total means the loop is bound
+by the launching thread, not by the GPU."""
 import os, sys, time
 sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "board-game-simulator-python_amd")]
 os.environ.setdefault("BGS_ROLLOUT_WPS", "2")
+import numpy as np
 import torch
-from simulator.batch import ConnectBatch
-streams = [torch.cuda.Stream() for _ in range(2)]
+from simulator.batch import ConnectBatch, RewardSink
+
+D = int(os.environ.get("DEPTH", "3"))
+N = 1 << 20
+streams = [torch.cuda.Stream() for _ in range(D)]
 batches = []
 for s in streams:
     with torch.cuda.stream(s):
-        batches.append(ConnectBatch(6, 7, 4, 1 << 20, use_torch=True))
-for i in range(10):
-    batches[i % 2].rollout(i, from_initial=True)
-torch.cuda.synchronize()
-K = 400
-t0 = time.perf_counter()
-for i in range(K):
-    k = i % 2
-    with torch.cuda.stream(streams[k]):
-        batches[k].rollout(100 + i, from_initial=True)
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"with-context: enqueue {1e6*(t1-t0)/K:.1f} us/step, total {1e6*(t2-t0)/K:.1f} us/step")
-t0 = time.perf_counter()
-for i in range(K):
-    batches[i % 2].rollout(1000 + i, from_initial=True)
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"bare calls  : enqueue {1e6*(t1-t0)/K:.1f} us/step, total {1e6*(t2-t0)/K:.1f} us/step")
+        batches.append(ConnectBatch(6, 7, 4, N, use_torch=True))
+hosts = [np.zeros((N, 2), dtype=np.int8) for _ in range(D)]
+sink = RewardSink(N, slots=D, threads=int(os.environ.get("THREADS", "3")))
+K = 300
+print("affinity:", sorted(os.sched_getaffinity(0)))
+
+def bare(i):
+    batches[i % D].rollout(100 + i, from_initial=True)
+
+tickets = [None] * D
+def with_sink(i):
+    k = i % D
+    if tickets[k] is not None:
+        sink.wait(tickets[k])
+    tickets[k] = sink.rollout(batches[k], hosts[k], 100 + i, from_initial=True)
+
+for name, fn in (("bare rollout", bare), ("sink.rollout", with_sink), ("bare rollout", bare), ("sink.rollout", with_sink)):
+    rows = []
+    for rep in range(8):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            fn(i)
+        t1 = time.perf_counter()
+        for k in range(D):
+            if tickets[k] is not None:
+                sink.wait(tickets[k]); tickets[k] = None
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        rows.append((1e6 * (t1 - t0) / K, 1e6 * (t2 - t0) / K))
+    print(f"{name:13s} enqueue/total us per step:", "  ".join(f"{a:.1f}/{b:.1f}" for a, b in rows))

@@ -212,7 +212,8 @@ def main() -> int:
             host_rewards.append(PinnedArray((n, 2), np.int8))
             events.append(HostEvent(local_rank))
         elif handover == "codes" and owner:
-            host_rewards.append(np.zeros((world * n, 2), dtype=np.int8))  # written by the sink's worker threads
+            # written by the sink's worker threads; filled here so that every page is mapped before the clock starts
+            host_rewards.append(np.full((world * n, 2), 0x55, dtype=np.int8))
             events.append(None)
         else:
             host_rewards.append(None)
@@ -323,7 +324,7 @@ def main() -> int:
         one_step(i, True)
     drain()
     # HIP-event pairs bracket a sample of the launches (each record is a marker packet on the stream): about 32 pairs
-    stride = max(1, args.steps // 32)
+    stride = max(2, args.steps // 32)
     elapsed, steps_local, kernel_ms = timed_region(args.warmup, args.steps, True, stride)
     last = args.warmup + args.steps - 1
 
@@ -355,7 +356,7 @@ def main() -> int:
     device_resident = None
     if not args.no_device_resident and handover != "none":
         reps = min(args.steps, 100)
-        dt, st_local, k_ms = timed_region(last + 1, reps, False, max(1, reps // 32))
+        dt, st_local, k_ms = timed_region(last + 1, reps, False, max(2, reps // 32))
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

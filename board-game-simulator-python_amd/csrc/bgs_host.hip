@@ -121,6 +121,7 @@ struct bgs_reward_sink {
     std::vector<int> parts_done;         // [slots] workers that finished their share of the slot's job
     bool stop = false;
     bool failed = false;
+    bool poll = false;                   // worker 0 polls the slot's event instead of sleeping on it (BGS_SINK_POLL=1)
     std::vector<std::thread> workers;
 
     // Worker 0 is the only thread that waits in the HIP runtime: it sleeps until a job is published, waits for the
@@ -139,7 +140,15 @@ struct bgs_reward_sink {
                     if (submitted <= ticket) return;  // stop, nothing left
                     job = jobs[slot];
                 }
-                ok = hipEventSynchronize(landed[slot]) == hipSuccess;
+                if (poll) {
+                    // busy-poll: the wake-up out of hipEventSynchronize costs tens of microseconds, which matters at
+                    // the end of a short run (the last delivery is not overlapped with anything)
+                    hipError_t e;
+                    while ((e = hipEventQuery(landed[slot])) == hipErrorNotReady) _mm_pause();
+                    ok = e == hipSuccess;
+                } else {
+                    ok = hipEventSynchronize(landed[slot]) == hipSuccess;
+                }
                 {
                     std::lock_guard<std::mutex> lock(mu);
                     if (!ok) failed = true;
@@ -303,6 +312,7 @@ int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_r
     s->slots = slots;
     s->threads = threads;
     s->jobs.resize(slots);
+    if (const char* env = getenv("BGS_SINK_POLL")) s->poll = atoi(env) != 0;
     s->parts_done.assign(slots, 0);
     const size_t bytes = (size_t)(max_games + 3) / 4;
     hipError_t err = hipSuccess;

@@ -444,8 +444,9 @@ def test_transition_round_trip_matches_separate_calls(batch_mod):
         orc.step_random(SEED)
     dev = batch_mod.ConnectBatch(6, 7, 4, n)
     cols = rng.integers(-1, 8, size=n).astype(np.int32)
-    status, grid, player, winner, plies, legal = dev.transition(orc.grid, orc.player, orc.winner, None, cols)
+    status, grid, player, winner, plies, legal, reward = dev.transition(orc.grid, orc.player, orc.winner, None, cols)
     np.testing.assert_array_equal(status, orc.step_actions(cols))
+    np.testing.assert_array_equal(reward, orc.reward)
     np.testing.assert_array_equal(grid, orc.grid)
     np.testing.assert_array_equal(player, orc.player)
     np.testing.assert_array_equal(winner, orc.winner)
@@ -471,8 +472,9 @@ def test_transition_round_trip_matches_separate_calls(batch_mod):
             moves[i] = [sx, sy, tx, ty]
         elif rng.random() < 0.5:
             moves[i] = rng.integers(0, 9, size=4)
-    status, grid, player, winner, plies, masks = bd.transition(bo.grid, bo.player, bo.winner, bo.plies, moves)
+    status, grid, player, winner, plies, masks, reward = bd.transition(bo.grid, bo.player, bo.winner, bo.plies, moves)
     np.testing.assert_array_equal(status, bo.step_actions(moves))
+    np.testing.assert_array_equal(reward, bo.reward)
     np.testing.assert_array_equal(grid, bo.grid)
     np.testing.assert_array_equal(winner, bo.winner)
     np.testing.assert_array_equal(plies, bo.plies)

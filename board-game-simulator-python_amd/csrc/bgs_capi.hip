@@ -318,6 +318,20 @@ void pack_outcomes(const bgs_batch* b, uint8_t* d_packed) {
 }
 }  // namespace bgs
 
+namespace bgs {
+int rollout_with_codes(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, uint8_t* codes_out) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(max_plies >= 0, "max_plies must be >= 0");
+    NEED(codes_out != nullptr && ((uintptr_t)codes_out % 16) == 0, "codes destination must be 16-byte aligned");
+    bool fused = false;
+    if (b->game == BGS_GAME_CONNECT) fused = bgs::connect_rollout(b, seed, max_plies, flags, reinterpret_cast<uint32_t*>(codes_out));
+    else bgs::bounce_rollout(b, seed, max_plies, flags);
+    if (!fused) bgs::pack_outcomes(b, codes_out);
+    return finish_launch();
+}
+}  // namespace bgs
+
 extern "C" {
 
 int bgs_version(void) { return 200; }
@@ -545,7 +559,7 @@ int bgs_rollout(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) 
     int rc = enter(b);
     if (rc) return rc;
     NEED(max_plies >= 0, "max_plies must be >= 0");
-    if (b->game == BGS_GAME_CONNECT) bgs::connect_rollout(b, seed, max_plies, flags);
+    if (b->game == BGS_GAME_CONNECT) (void)bgs::connect_rollout(b, seed, max_plies, flags, nullptr);
     else bgs::bounce_rollout(b, seed, max_plies, flags);
     return finish_launch();
 }

@@ -314,7 +314,7 @@ int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_r
     s->jobs.resize(slots);
     if (const char* env = getenv("BGS_SINK_POLL")) s->poll = atoi(env) != 0;
     s->parts_done.assign(slots, 0);
-    const size_t bytes = (size_t)(max_games + 3) / 4;
+    const size_t bytes = (size_t)(max_games + 63) / 64 * 16;  // whole 16-byte units: kernels store codes dword- / uint4-wise
     hipError_t err = hipSuccess;
     for (int k = 0; k < slots && err == hipSuccess; ++k) {
         void* host = nullptr;
@@ -373,9 +373,19 @@ int bgs_sink_submit(bgs_reward_sink* s, bgs_batch* b, int8_t* host_reward, int64
 
 int bgs_sink_rollout(bgs_reward_sink* s, bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags,
                      int8_t* host_reward, int64_t* ticket) {
-    int rc = bgs_rollout(b, seed, max_plies, flags);
+    NEED(s != nullptr && b != nullptr && host_reward != nullptr, "NULL argument");
+    NEED(b->device == s->device, "batch lives on device %d, the sink on device %d", b->device, s->device);
+    NEED(b->n <= s->max_games, "batch of %lld games exceeds the sink's %lld", (long long)b->n, (long long)s->max_games);
+    const int64_t t = claim(s);
+    const int slot = (int)(t % s->slots);
+    // the rollout kernel stores the outcome codes of the games it finishes straight into the page-locked slot (or the
+    // pack kernel does, for kernels without that epilogue): when the event fires the codes are in host memory
+    int rc = bgs::rollout_with_codes(b, seed, max_plies, flags, s->mapped[slot]);
     if (rc) return rc;
-    return bgs_sink_submit(s, b, host_reward, ticket);
+    HIP_TRY(hipEventRecord(s->landed[slot], b->stream));
+    publish(s, t, b->n, host_reward);
+    if (ticket) *ticket = t;
+    return BGS_OK;
 }
 
 int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* device_packed, int64_t n_games,

@@ -69,7 +69,7 @@ namespace bgs {
 void connect_reset(const bgs_batch* b);
 void connect_step_random(const bgs_batch* b, uint64_t seed);
 void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out);
-void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags);
+bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, uint32_t* codes_out);
 void connect_unpack_grid(const bgs_batch* b, int8_t* d_grid);
 void connect_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies);
 void connect_legal(const bgs_batch* b, uint8_t* d_legal, int32_t* d_count);
@@ -90,5 +90,8 @@ void bounce_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_playe
 // ---- shared by the C-ABI translation units (bgs_capi.hip, bgs_host.hip) ----
 // status bytes -> 2-bit outcome codes, 4 boards per byte, enqueued on the batch's stream
 void pack_outcomes(const bgs_batch* b, uint8_t* d_packed);
+// bgs_rollout with the outcome codes delivered to `codes_out` (16-byte aligned, (n + 63) / 64 * 16 bytes; device or
+// device-mapped host memory): by the rollout kernel itself where it can, by k_pack_outcomes behind it otherwise
+int rollout_with_codes(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, uint8_t* codes_out);
 
 }  // namespace bgs

@@ -369,6 +369,33 @@ __device__ __forceinline__ bool four_in_a_row(uint64_t b, int h) {
     return (acc_lo | acc_hi) != 0u;
 }
 
+// The same test split the way the rollout uses it: a run that the stone just dropped on `pos` completes is either
+// vertical -- then it is the four cells ending at pos, one shift and one compare (a shift amount below zero wraps to
+// 61..63 and leaves at most three bits, and a stone lower than row 3 has the previous column's always-empty sentinel in
+// its window) -- or lies in one of the three other directions, tested on the whole board as above.
+__device__ __forceinline__ bool four_in_a_row_at(uint64_t b, int h, uint32_t pos) {
+    const int dirs[3] = {h + 1, h + 2, h};
+    uint32_t acc_lo = 0, acc_hi = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const uint64_t s1 = b >> dirs[d];
+        const uint32_t pl = (uint32_t)b & (uint32_t)s1, ph = (uint32_t)(b >> 32) & (uint32_t)(s1 >> 32);
+        const uint64_t pairs = ((uint64_t)ph << 32) | pl;
+        uint64_t s2;
+        asm("v_lshrrev_b64 %0, %1, %2" : "=v"(s2) : "s"(2 * dirs[d]), "v"(pairs));
+        if (d == 0) {
+            acc_lo = pl & (uint32_t)s2;
+            acc_hi = ph & (uint32_t)(s2 >> 32);
+        } else {
+            acc_lo = and_or(pl, (uint32_t)s2, acc_lo);
+            acc_hi = and_or(ph, (uint32_t)(s2 >> 32), acc_hi);
+        }
+    }
+    uint32_t column = (uint32_t)(b >> ((pos - 3u) & 63u));  // the stone and the three cells below it
+    asm("" : "+v"(column));  // (keeps the compare 32 bits wide: hipcc would otherwise widen it and add a move)
+    return ((acc_lo | acc_hi) != 0u) | ((column & 15u) == 15u);
+}
+
 // board policy B: one-word boards with W <= 8 and H <= 8 (Connect4 6x7).  Column state is one nibble per column,
 // v = (H + 7) - height, so bit 3 of the nibble says "column open"; the i-th open column is found without a loop:
 // a multiply by 0x11111111 turns the open flags into per-nibble prefix counts, and a SWAR compare against the
@@ -553,16 +580,42 @@ k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
     add_steps(steps, stepped);
 }
 
+// Outcome codes of a wave's chunk, accumulated where the games end (the fused form of k_pack_outcomes): 2 bits per
+// game, 16 games per dword, in a wave-private slice of LDS; when the chunk is finished the wave stores its dwords to
+// `codes_out` -- for the host hand-over that is page-locked HOST memory mapped into the device, so the codes are in
+// host memory when the kernel completes and no pack kernel or copy has to follow it on the stream.  A chunk starts at
+// a multiple of 16 games (the launcher rounds chunks to 64), so no two waves share a dword.
+struct WaveCodes {
+    uint32_t* slice;   // this wave's LDS dwords
+    uint32_t words;    // dwords that hold games of this wave's chunk
+    __device__ __forceinline__ void init(uint32_t* lds, uint32_t games_per_wave, uint32_t avail) {
+        slice = lds + (threadIdx.x >> 6) * (games_per_wave >> 4);
+        words = (avail + 15u) >> 4;
+        for (uint32_t i = threadIdx.x & 63u; i < words; i += 64u) slice[i] = 0u;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void add(uint32_t game, uint32_t code) {
+        atomicOr(slice + (game >> 4), code << (2u * (game & 15u)));  // ds_or_b32, no return
+    }
+    __device__ __forceinline__ void flush(uint32_t* __restrict__ codes_out, int64_t begin) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the ds_or of every lane before the reads below
+        __builtin_amdgcn_wave_barrier();
+        uint32_t* dst = codes_out + (begin >> 4);
+        for (uint32_t i = threadIdx.x & 63u; i < words; i += 64u) dst[i] = slice[i];
+    }
+};
+
 // K2a: the same rollout for boards that start from the initial state on a one-word geometry (W <= 8, H <= 8),
 // written without per-ply control flow.  Every game starts at a 4-ply boundary, so inside a block the mover of
 // sub-step j is player j & 1: no plane swap, no ply counter.  A lane that is not playing executes the same
 // instructions with `live` = 0 -- the stone it drops is (live << position) = 0 -- so the four plies of a block and
 // the philox call in front of them form ONE basic block for the scheduler; only refill and store are conditional.
-template <class G, bool CAPPED, bool FROM_INITIAL>
+template <class G, bool CAPPED, bool FROM_INITIAL, bool CODES>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                           int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
-                          unsigned long long* __restrict__ steps, uint32_t games_per_wave) {
+                          unsigned long long* __restrict__ steps, uint32_t games_per_wave, uint32_t* __restrict__ codes_out) {
+    extern __shared__ uint32_t code_lds[];  // CODES: games_per_wave / 16 dwords per wave
     constexpr uint32_t ONES = 0x11111111u;
     const uint32_t top = (uint32_t)g.h() + 7u;
     const uint32_t columns = g.w() >= 8 ? ONES : (ONES & ((1u << (4 * g.w())) - 1u));
@@ -583,13 +636,15 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
     uint64_t p[2] = {0, 0};      // stones of player 0 / player 1
     uint32_t hts = 0;            // nibble per column: (H + 7) - height; bit 3 = column open
     uint32_t blk = 0;            // 4-ply blocks this game has played
-    uint64_t live = 0;           // 1 while this lane's game is running (64-bit: it is shifted into the planes)
+    uint32_t live = 0;           // all ones while this lane's game is running, else 0 (a mask: see the stone below)
     uint32_t st = 0;             // winner code once somebody won
     uint32_t game = 0;           // offset of this lane's game in the wave's chunk
     uint32_t skip = 0;           // loaded boards: sub-steps to sit out in the first block (= plies already in it)
     uint32_t stepped = 0;
 
     if (avail == 0u) return;  // (whole wave: the chunk is empty; nothing was counted)
+    WaveCodes codes;
+    if (CODES) codes.init(code_lds, games_per_wave, avail);
     do {
         // ---- refill: idle lanes take the next games of the chunk
         const uint64_t need = __builtin_amdgcn_ballot_w64(live == 0);
@@ -603,7 +658,7 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
                     p[1] = 0;
                     hts = top * columns;
                     blk = 0;
-                    live = (!CAPPED || max_plies > 0u) ? 1u : 0u;
+                    live = (!CAPPED || max_plies > 0u) ? ~0u : 0u;
                     if (CAPPED && live == 0) {  // max_plies == 0: the boards still have to be written once
                         plane0[game] = 0;
                         plane1[game] = 0;
@@ -628,7 +683,9 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
                     }
                     blk = ply0 >> 2;
                     skip = ply0 & 3u;
-                    live = (status_out[game] == BGS_ST_RUNNING && (!CAPPED || ply0 < max_plies)) ? 1u : 0u;
+                    const uint32_t st0 = status_out[game];
+                    live = (st0 == BGS_ST_RUNNING && (!CAPPED || ply0 < max_plies)) ? ~0u : 0u;
+                    if (CODES && live == 0) codes.add(game, st0);  // a board that does not play keeps its outcome
                 }
             }
             const uint32_t wanted = (uint32_t)__popcll(need);
@@ -636,7 +693,7 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
         }
 
         // ---- one philox block, four plies, no control flow
-        const uint64_t was_live = live;
+        const uint32_t was_live = live;
         const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk);
         uint32_t open = (hts >> 3) & ONES;
 #pragma unroll
@@ -653,23 +710,29 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
             asm("" : "+v"(base));  // keep (col * stride + top) one multiply-add; then one subtract
             uint32_t pos = base - v;
             if ((uint32_t)g.w() * stride + top > 63u) pos &= 63u;  // only a lane that is not playing can exceed 63
-            const uint64_t act = (FROM_INITIAL || j >= skip) ? live : 0;  // this lane plays this sub-step
+            const uint32_t act = (FROM_INITIAL || j >= skip) ? live : 0u;  // mask: this lane plays this sub-step
             uint64_t& mine = p[j & 1u];
-            mine |= act << pos;
-            hts -= (uint32_t)act << sh;
+            // the stone of a lane that is not playing is masked away: (bit & act) | mine, one v_bitop3 per half
+            const uint64_t bit = 1ull << pos;
+            mine = ((uint64_t)and_or((uint32_t)(bit >> 32), act, (uint32_t)(mine >> 32)) << 32) |
+                   and_or((uint32_t)bit, act, (uint32_t)mine);
+            hts += act << sh;  // act is 0 or -1: one stone more in the column = its nibble one lower
             open = (hts >> 3) & ONES;
             bool won;
             if (g.k() == 4) {
-                won = four_in_a_row(mine, g.h());
+                won = four_in_a_row_at(mine, g.h(), pos);
             } else {
                 Bits<1> b;
                 b.w[0] = mine;
                 won = has_run(g, b);
             }
-            stepped += (uint32_t)act;
-            st = (act != 0 && won) ? (j & 1u) + 1u : st;
-            live = (won || open == 0u) ? 0 : live;
-            if (CAPPED) live = (4u * blk + j + 1u < max_plies) ? live : 0;
+            stepped -= act;
+            // no "act &&": a lane that is not playing re-tests a plane that did not change.  A running game holds no
+            // run, so `won` can only be true there for the plane that ended this lane's game -- it names the same
+            // winner again -- or on a lane whose result is not stored any more
+            st = won ? (j & 1u) + 1u : st;
+            live = (won || open == 0u) ? 0u : live;
+            if (CAPPED) live = (4u * blk + j + 1u < max_plies) ? live : 0u;
         }
         blk += 1u;
         skip = 0;
@@ -682,8 +745,10 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
             *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane1) + (game * 8u)) = p[1];
             *(reinterpret_cast<uint8_t*>(status_out) + game) = (uint8_t)code;
             *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(reward_out) + (game * 2u)) = reward_pair(code);
+            if (CODES) codes.add(game, code);
         }
     } while (__builtin_amdgcn_ballot_w64(live != 0) || taken < avail);
+    if (CODES) codes.flush(codes_out, begin);
     add_steps(steps, stepped);
 }
 
@@ -947,13 +1012,21 @@ void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t*
     });
 }
 
-void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
+// codes_out != nullptr asks the kernel to deliver the 2-bit outcome codes itself (uint32[(n + 15) / 16], device or
+// device-mapped host memory); returns whether the kernel chosen for this batch does so (otherwise the caller runs
+// k_pack_outcomes behind it)
+bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, uint32_t* codes_out) {
     const uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
-    // resident waves: CUs x 4 SIMDs x waves per SIMD; every wave gets an equal contiguous chunk of games
+    // resident waves: CUs x 4 SIMDs x waves per SIMD; every wave gets an equal contiguous chunk of games, a multiple
+    // of 64 (whole dwords of outcome codes per wave, whole refill rounds)
     const int64_t resident = (int64_t)b->num_cus * 4 * b->rollout_wps;
     int64_t per_wave = (b->n + resident - 1) / resident;
-    if (per_wave < BGS_WAVE) per_wave = BGS_WAVE;
+    per_wave = (per_wave + BGS_WAVE - 1) / BGS_WAVE * BGS_WAVE;
     const int64_t waves = (b->n + per_wave - 1) / per_wave;
+    // the wave-private LDS slices of the fused codes: 4 waves x per_wave / 16 dwords per workgroup
+    const size_t code_lds = (size_t)4 * (per_wave / 16) * sizeof(uint32_t);
+    const bool fuse_codes = codes_out != nullptr && code_lds <= (32u << 10);
+    bool fused = false;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     const bool nibble_ok = b->cg.nw == 1 && b->cg.w <= 8 && b->cg.h <= 8;
     dispatch(b->cg, [&](auto g) {
@@ -983,9 +1056,17 @@ void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
                 auto launch_aligned = [&](auto capped_tag, auto initial_tag) {
                     constexpr bool CAPPED = decltype(capped_tag)::value;
                     constexpr bool INITIAL = decltype(initial_tag)::value;
-                    hipLaunchKernelGGL((k_connect_rollout_aligned<G, CAPPED, INITIAL>), dim3(blocks), dim3(BGS_BLOCK), 0,
-                                       b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
-                                       seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+                    if (fuse_codes) {
+                        hipLaunchKernelGGL((k_connect_rollout_aligned<G, CAPPED, INITIAL, true>), dim3(blocks), dim3(BGS_BLOCK),
+                                           code_lds, b->stream, g, b->d_planes, b->d_status,
+                                           reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps,
+                                           (uint32_t)per_wave, codes_out);
+                        fused = true;
+                    } else {
+                        hipLaunchKernelGGL((k_connect_rollout_aligned<G, CAPPED, INITIAL, false>), dim3(blocks), dim3(BGS_BLOCK),
+                                           0, b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward),
+                                           b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr);
+                    }
                 };
                 if (flags & 1u) {
                     if (capped) launch_aligned(std::true_type{}, std::true_type{});
@@ -1011,6 +1092,7 @@ void connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
         }
         with_game(Tag<GenericGame<G>>{});
     });
+    return fused;
 }
 
 void connect_unpack_grid(const bgs_batch* b, int8_t* d_grid) {

@@ -109,6 +109,40 @@ def test_reward_sink_delivers_every_step_in_order(bm, game):
         b.close()
 
 
+@pytest.mark.parametrize("h,w,k,n", [(6, 7, 4, 70001), (4, 5, 3, 999), (8, 8, 4, 4096), (12, 13, 5, 3000), (6, 7, 4, 16)])
+def test_sink_rollout_fused_codes_all_entry_states(bm, h, w, k, n):
+    """bgs_sink_rollout lets the rollout kernel itself deliver the outcome codes where it can (one-word boards; the
+    pack kernel follows otherwise): from the initial state, from mid-game positions that include finished boards,
+    capped, and with ragged batch sizes, the host rewards must equal the oracle's."""
+    dev = bm.ConnectBatch(h, w, k, n)
+    orc = oracle.ConnectOracle(h, w, k, n)
+    sink = bm.RewardSink(n, slots=2, threads=2)
+    host = np.full((n, 2), 9, dtype=np.int8)
+    sink.wait(sink.rollout(dev, host, SEED + 4, from_initial=True))
+    orc.rollout(SEED + 4)
+    np.testing.assert_array_equal(host, orc.reward)
+    np.testing.assert_array_equal(dev.reward, orc.reward)
+    # mid-game: some boards already over, the rest resume; then a cap that leaves boards unfinished (reward 0 / 0)
+    dev.reset()
+    orc.reset()
+    for _ in range(min(h * w, 9)):
+        dev.step_random(SEED ^ 3)
+        orc.step_random(SEED ^ 3)
+    cap = min(h * w, 9) + 3
+    host[:] = 9
+    sink.wait(sink.rollout(dev, host, SEED ^ 3, max_plies=cap))
+    orc.rollout(SEED ^ 3, max_plies=cap)
+    np.testing.assert_array_equal(host, orc.reward)
+    host[:] = 9
+    sink.wait(sink.rollout(dev, host, SEED ^ 3))
+    orc.rollout(SEED ^ 3)
+    np.testing.assert_array_equal(host, orc.reward)
+    np.testing.assert_array_equal(dev.grid, orc.grid)
+    assert dev.steps == int(orc.plies.sum())
+    sink.close()
+    dev.close()
+
+
 def test_reward_sink_takes_gathered_codes(bm, torch_mod):
     """Rank 0's side of the multi-GPU gather: codes of several shards, already on the device, to one host array."""
     torch = torch_mod

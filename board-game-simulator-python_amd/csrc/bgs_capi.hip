@@ -221,6 +221,7 @@ int device_facts(bgs_batch* b) {
         if (v >= 1 && v <= 8) b->rollout_wps = v;
     }
     b->rollout_generic = getenv("BGS_ROLLOUT_GENERIC") != nullptr;
+    b->rollout_no_lds = getenv("BGS_ROLLOUT_NO_LDS") != nullptr;
     b->bounce_group = 8;
     if (const char* env = getenv("BGS_BOUNCE_GROUP")) b->bounce_group = atoi(env) == 1 ? 1 : 8;
     return BGS_OK;

@@ -46,6 +46,7 @@ struct bgs_batch {
     int rollout_wps;         // waves per SIMD the fused rollout is sized for
     int bounce_group;        // lanes per board in the fused Bounce rollout: 8 (default) or 1 (BGS_BOUNCE_GROUP)
     int rollout_generic;     // 1: never take the block-aligned from-initial kernel (A/B timing, BGS_ROLLOUT_GENERIC)
+    int rollout_no_lds;      // 1: large boards stay in registers (K2b) instead of the LDS-staged kernel (BGS_ROLLOUT_NO_LDS)
     // device buffers (inside the arena)
     void* arena;
     size_t arena_bytes;

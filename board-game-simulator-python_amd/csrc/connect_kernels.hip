@@ -121,6 +121,7 @@ __device__ __forceinline__ bool test_bit(const Bits<NW>& a, int t) {
 template <int NW_, int SH, int SW, int SK>
 struct Geo {
     static constexpr int NW = NW_;
+    static constexpr int STATIC_H = SH, STATIC_W = SW, STATIC_K = SK;
     static constexpr int MAXW = SW ? SW : BGS_CONNECT_MAX_W;  // unroll bound of per-column loops
     int rh, rw, rk;
     __device__ __forceinline__ int h() const { return SH ? SH : rh; }
@@ -844,6 +845,190 @@ k_connect_rollout_aligned_wide(G g, uint64_t* __restrict__ planes, uint8_t* __re
     add_steps(steps, stepped);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2c: the rollout for large boards of a compile-time geometry (Connect(12,13,5): 3 words per plane), with the boards
+// staged in LDS.  The bit-planes of a lane's game live in the workgroup's LDS tile, one dword COLUMN per lane
+// (dword d of lane t at [d][t]: the bank is the lane, so a per-lane dynamic dword index never conflicts).  A ply then
+//   drops its stone with one ds_or_b32 into the dword that holds the cell, and
+//   tests for a run only where one can have appeared: it reads the 128-bit window of the mover's plane centred on
+//     the stone (5 dwords from a dynamic index, aligned with v_alignbit so the stone sits at bit R = (k-1)(H+2)),
+//     runs the shift-and-AND run test on those 4 dwords in the three slanted / horizontal directions, and checks the
+//     column with one field extract.
+// The generic kernel K2b re-scans all three 64-bit words of the plane in four directions every ply and selects the
+// word that takes the stone with compares; this one needs neither.  Zero padding around the plane (PB dwords below,
+// PT above) makes the window valid at the board's edges.
+// ------------------------------------------------------------------------------------------------
+template <class G>
+struct LdsBoard {
+    static constexpr int H = G::STATIC_H, W = G::STATIC_W, K = G::STATIC_K;
+    static constexpr int R = (K - 1) * (H + 2);          // reach of a run through the stone, in bits
+    static constexpr bool fits = H > 0 && K >= 2 && 2 * R <= 127;
+    static constexpr int PB = (R + 31) / 32;             // zero dwords below the plane
+    static constexpr int PD = 2 * G::NW;                 // dwords of the plane itself
+    static constexpr int ND = PB + PD + PB + 2;          // dwords per plane column (covers the window of any lane)
+    static constexpr size_t lds_bytes = (size_t)2 * ND * BGS_BLOCK * sizeof(uint32_t);
+};
+
+struct Win {
+    uint32_t d[4];
+};
+
+// logical right shift of the 128-bit window by the compile-time amount C
+template <int C>
+__device__ __forceinline__ Win win_shr(const Win& x) {
+    constexpr int q = C >> 5, r = C & 31;
+    Win y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = (i + q < 4) ? x.d[(i + q) & 3] : 0u;
+        const uint32_t hi = (i + q + 1 < 4) ? x.d[(i + q + 1) & 3] : 0u;
+        y.d[i] = r ? __builtin_amdgcn_alignbit(hi, lo, r) : lo;
+    }
+    return y;
+}
+
+__device__ __forceinline__ Win win_and(const Win& a, const Win& b) {
+    Win y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y.d[i] = a.d[i] & b.d[i];
+    return y;
+}
+
+// runs of K stones with stride D anywhere in the window: run doubling, LEN = length already established in m
+template <int D, int LEN, int K>
+__device__ __forceinline__ Win win_runs(const Win& m) {
+    if constexpr (LEN >= K) {
+        return m;
+    } else if constexpr (2 * LEN <= K) {
+        return win_runs<D, 2 * LEN, K>(win_and(m, win_shr<LEN * D>(m)));
+    } else {
+        return win_and(m, win_shr<(K - LEN) * D>(m));
+    }
+}
+
+template <class G, bool CAPPED, bool CODES>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
+                      int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
+                      unsigned long long* __restrict__ steps, uint32_t games_per_wave, uint32_t* __restrict__ codes_out) {
+    using L = LdsBoard<G>;
+    constexpr int NW = G::NW, H = L::H, W = L::W, K = L::K, R = L::R, PB = L::PB, ND = L::ND;
+    constexpr uint32_t ONES = 0x11111111u;
+    constexpr uint32_t open_lo0 = W >= 8 ? ONES : (ONES & ((1u << (4 * (W & 7))) - 1u));
+    constexpr uint32_t open_hi0 = W <= 8 ? 0u : (W >= 16 ? ONES : (ONES & ((1u << (4 * ((W - 8) & 7))) - 1u)));
+    extern __shared__ uint32_t lds_tile[];   // [2 players][ND dwords][256 lanes], then the CODES slices
+    uint32_t* const column = lds_tile + threadIdx.x;   // this lane's dword column
+    auto cell = [&](int player, uint32_t dword) -> uint32_t& { return column[(player * ND + dword) * BGS_BLOCK]; };
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
+    const int64_t begin = (int64_t)wave * games_per_wave;
+    const int64_t end = begin + games_per_wave < n ? begin + games_per_wave : n;
+    const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
+    uint32_t taken = 0;
+
+    uint64_t hts = 0;                     // nibble per column: its height
+    uint32_t open_lo = 0, open_hi = 0;    // nibble-spread "column open" flags (columns 0-7 / 8-15)
+    uint32_t blk = 0, st = 0, game = 0, stepped = 0;
+    uint32_t live = 0;                    // all ones while this lane's game is running
+
+    if (avail == 0u) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int d = 0; d < ND; ++d) cell(q, d) = 0u;   // padding (and planes) start out empty
+    WaveCodes codes;
+    if (CODES) codes.init(lds_tile + 2 * ND * BGS_BLOCK, games_per_wave, avail);
+    do {
+        const uint64_t need = __builtin_amdgcn_ballot_w64(live == 0);
+        if (need && taken < avail) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (live == 0 && taken + rank < avail) {
+                game = taken + rank;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int d = 0; d < 2 * NW; ++d) cell(q, PB + d) = 0u;
+                hts = 0;
+                open_lo = open_lo0;
+                open_hi = open_hi0;
+                blk = 0;
+                st = 0;
+                live = (!CAPPED || max_plies > 0u) ? ~0u : 0u;
+                if (CAPPED && live == 0) {
+                    const Bits<NW> none = zero_bits<NW>();
+                    store_planes<NW>(planes, n, begin + game, none, none);
+                    status[begin + game] = 0;
+                    reward[begin + game] = 0;
+                }
+            }
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            taken = avail - taken < wanted ? avail : taken + wanted;
+        }
+
+        const uint32_t was_live = live;
+        const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t count_lo = (uint32_t)__popc(open_lo);
+            const uint32_t idx = sample_index(draws.v[j], count_lo + (uint32_t)__popc(open_hi));
+            const bool in_lo = idx < count_lo;
+            const uint32_t part = in_lo ? open_lo : open_hi;
+            const uint32_t rank_in_part = in_lo ? idx : idx - count_lo;
+            const uint32_t cmp = (rank_in_part - part) * ONES + 0x88888888u;  // nibble x: 8 + rank - (open among 0..x)
+            const uint32_t col = ((uint32_t)__popc(cmp & 0x88888888u) & 7u) + (in_lo ? 0u : 8u);
+            const uint32_t v = (uint32_t)(hts >> (4u * col)) & 15u;
+            const uint32_t at = col * (uint32_t)(H + 1) + v + 32u * PB;   // the cell's bit index in the padded column
+            const int me = (int)(j & 1u);
+            // the stone: one LDS OR into the dword that holds the cell (nothing for a lane that is not playing)
+            atomicOr(&cell(me, at >> 5), live & (1u << (at & 31u)));
+            hts += (uint64_t)(live & 1u) << (4u * col);
+            const uint32_t filled = (live != 0 && v + 1u == (uint32_t)H) ? (1u << (4u * (col & 7u))) : 0u;
+            open_lo &= ~(in_lo ? filled : 0u);
+            open_hi &= ~(in_lo ? 0u : filled);
+            // the 128-bit window of the mover's plane that starts R bits below the stone
+            const uint32_t from = at - (uint32_t)R, first = from >> 5, shift = from & 31u;
+            uint32_t y[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) y[i] = cell(me, first + i);
+            Win x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x.d[i] = __builtin_amdgcn_alignbit(y[i + 1], y[i], shift);
+            const Win r1 = win_runs<H + 1, 1, K>(x), r2 = win_runs<H + 2, 1, K>(x), r3 = win_runs<H, 1, K>(x);
+            uint32_t any_run = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) any_run |= r1.d[i] | r2.d[i] | r3.d[i];
+            // the column: the stone (window bit R) and the K - 1 cells below it
+            constexpr int lowest = R - (K - 1);
+            constexpr uint32_t kmask = (1u << K) - 1u;
+            const uint64_t pair = ((uint64_t)x.d[(lowest >> 5) + 1] << 32) | x.d[lowest >> 5];
+            const uint32_t below = (uint32_t)(pair >> (lowest & 31)) & kmask;
+            const bool won = any_run != 0u || below == kmask;
+            stepped -= live;
+            st = won ? (j & 1u) + 1u : st;   // (a lane that is not playing re-finds at most its own finished game's run)
+            live = (won || (open_lo | open_hi) == 0u) ? 0u : live;
+            if (CAPPED) live = (4u * blk + j + 1u < max_plies) ? live : 0u;
+        }
+        blk += 1u;
+
+        if (was_live != 0 && live == 0) {
+            const int64_t i = begin + game;
+            const uint32_t code = st ? st : ((open_lo | open_hi) == 0u ? BGS_ST_DRAW : BGS_ST_RUNNING);
+            Bits<NW> p0, p1;
+#pragma unroll
+            for (int wd = 0; wd < NW; ++wd) {
+                p0.w[wd] = ((uint64_t)cell(0, PB + 2 * wd + 1) << 32) | cell(0, PB + 2 * wd);
+                p1.w[wd] = ((uint64_t)cell(1, PB + 2 * wd + 1) << 32) | cell(1, PB + 2 * wd);
+            }
+            store_planes<NW>(planes, n, i, p0, p1);
+            status[i] = (uint8_t)code;
+            reward[i] = reward_pair(code);
+            if (CODES) codes.add(game, code);
+        }
+    } while (__builtin_amdgcn_ballot_w64(live != 0) || taken < avail);
+    if (CODES) codes.flush(codes_out, begin);
+    add_steps(steps, stepped);
+}
+
 // K4: packed planes -> reference layout int8[n][H][W] (row 0 = bottom; -1 empty, 0, 1).  One lane expands one board
 // into the workgroup's LDS tile (256 boards x H*W bytes, already in output order); the workgroup then streams the
 // tile to HBM with 16-byte stores.
@@ -1078,6 +1263,29 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
                 return;
             }
             if (nibble_ok) { with_game(Tag<NibbleGame<G>>{}); return; }
+        }
+        if constexpr (LdsBoard<G>::fits && G::NW > 1) {
+            if ((flags & 1u) && !b->rollout_generic && !b->rollout_no_lds) {
+                // a compile-time multi-word geometry: boards staged in LDS, run test on the window around the stone
+                const size_t tile = LdsBoard<G>::lds_bytes;
+                auto launch_lds = [&](auto capped_tag) {
+                    constexpr bool CAPPED = decltype(capped_tag)::value;
+                    if (fuse_codes) {
+                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, true>), dim3(blocks), dim3(BGS_BLOCK),
+                                           tile + code_lds, b->stream, g, b->d_planes, b->d_status,
+                                           reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps,
+                                           (uint32_t)per_wave, codes_out);
+                        fused = true;
+                    } else {
+                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, false>), dim3(blocks), dim3(BGS_BLOCK), tile,
+                                           b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward),
+                                           b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr);
+                    }
+                };
+                if (capped) launch_lds(std::true_type{});
+                else launch_lds(std::false_type{});
+                return;
+            }
         }
         if ((flags & 1u) && !b->rollout_generic) {
             if (capped)

@@ -41,7 +41,7 @@ constexpr size_t kStepBytes = (size_t)BGS_STEP_SHARDS * BGS_STEP_STRIDE * sizeof
 inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-    size_t planes, status, plies, reward, steps, staging, total, staging_bytes;
+    size_t planes, status, plies, reward, steps, worklist, work_count, staging, total, staging_bytes;
 };
 
 Layout layout_for(int planes, int64_t n, int h, int w) {
@@ -52,6 +52,8 @@ Layout layout_for(int planes, int64_t n, int h, int w) {
     l.plies = off; off += align_up((size_t)n * 2);
     l.reward = off; off += align_up((size_t)n * 2);
     l.steps = off; off += align_up(kStepBytes);
+    l.worklist = off; off += align_up((size_t)n * 4);
+    l.work_count = off; off += align_up(sizeof(uint32_t) * BGS_BOUNCE_MAX_PASSES);
     size_t per_board = (size_t)h * w;
     if (per_board < (size_t)8 * (w + 1)) per_board = (size_t)8 * (w + 1);
     if (per_board < 16) per_board = 16;
@@ -128,6 +130,8 @@ int carve(bgs_batch* b, void* arena, size_t arena_bytes, const Layout& l) {
     b->d_plies = reinterpret_cast<uint16_t*>(base + l.plies);
     b->d_reward = reinterpret_cast<int8_t*>(base + l.reward);
     b->d_steps = reinterpret_cast<unsigned long long*>(base + l.steps);
+    b->d_worklist = reinterpret_cast<uint32_t*>(base + l.worklist);
+    b->d_work_count = reinterpret_cast<uint32_t*>(base + l.work_count);
     b->d_staging = base + l.staging;
     b->staging_bytes = l.staging_bytes;
     return BGS_OK;
@@ -224,6 +228,27 @@ int device_facts(bgs_batch* b) {
     b->rollout_no_lds = getenv("BGS_ROLLOUT_NO_LDS") != nullptr;
     b->bounce_group = 8;
     if (const char* env = getenv("BGS_BOUNCE_GROUP")) b->bounce_group = atoi(env) == 1 ? 1 : 8;
+    // multi-pass Bounce rollout (bounce_kernels.hip, bounce_rollout): "cap:lanes,..."; the last entry's cap is the
+    // caller's max_plies whatever it says; "single" = one launch that plays every game to the end
+    {
+        const char* plan = getenv("BGS_BOUNCE_PLAN");
+        if (!plan) plan = "32:1,512:1,0:8";
+        b->bounce_passes = 0;
+        if (strcmp(plan, "single") != 0) {
+            const char* p = plan;
+            while (*p && b->bounce_passes < BGS_BOUNCE_MAX_PASSES) {
+                char* endp = nullptr;
+                const long cap = strtol(p, &endp, 10);
+                int lanes = 1;
+                if (endp && *endp == ':') lanes = (int)strtol(endp + 1, &endp, 10);
+                b->bounce_pass_cap[b->bounce_passes] = cap > 0 ? (uint32_t)cap : 0xFFFFFFFFu;
+                b->bounce_pass_group[b->bounce_passes] = lanes == 8 ? 8 : 1;
+                ++b->bounce_passes;
+                if (!endp || *endp != ',') break;
+                p = endp + 1;
+            }
+        }
+    }
     return BGS_OK;
 }
 

@@ -13,7 +13,8 @@ enum {
     BGS_CONNECT_MAX_H = 15,      // column heights are kept 4 bits per column
     BGS_CONNECT_MAX_W = 16,
     BGS_BOUNCE_MAX_CELLS = 64,   // height * width <= 64: one bit per cell in a uint64
-    BGS_BOUNCE_MAX_VALUE = 15    // 4 value bit-planes
+    BGS_BOUNCE_MAX_VALUE = 15,   // 4 value bit-planes
+    BGS_BOUNCE_MAX_PASSES = 8    // passes of the multi-pass Bounce rollout
 };
 
 struct ConnectGeom {
@@ -44,7 +45,10 @@ struct bgs_batch {
     int planes;              // uint64 planes per board
     int num_cus;             // compute units of the device
     int rollout_wps;         // waves per SIMD the fused rollout is sized for
-    int bounce_group;        // lanes per board in the fused Bounce rollout: 8 (default) or 1 (BGS_BOUNCE_GROUP)
+    int bounce_group;        // lanes per board of a single-launch Bounce rollout: 8 (default) or 1 (BGS_BOUNCE_GROUP)
+    int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board
+    uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];
+    int bounce_pass_group[BGS_BOUNCE_MAX_PASSES];
     int rollout_generic;     // 1: never take the block-aligned from-initial kernel (A/B timing, BGS_ROLLOUT_GENERIC)
     int rollout_no_lds;      // 1: large boards stay in registers (K2b) instead of the LDS-staged kernel (BGS_ROLLOUT_NO_LDS)
     // device buffers (inside the arena)
@@ -58,6 +62,8 @@ struct bgs_batch {
     unsigned long long* d_steps;
     uint8_t* d_staging;
     size_t staging_bytes;
+    uint32_t* d_worklist;    // [n] board indices still to play (Bounce multi-pass rollout)
+    uint32_t* d_work_count;  // [BGS_BOUNCE_MAX_PASSES] list lengths, device-resident
     // pinned bounce buffers for large device -> host copies (allocated on first use)
     void* pinned[2];
     hipEvent_t pinned_done[2];

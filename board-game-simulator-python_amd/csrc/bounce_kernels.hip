@@ -301,15 +301,21 @@ __device__ __forceinline__ void pick_from(const Moves& m, uint32_t idx, int& src
 
 // GL = lanes per board: 1 (a lane owns a board) or 8 (a lane group shares a board; all eight lanes hold the same
 // state and take the same decisions, lane 0 of the group stores)
+// worklist != nullptr: the launch plays the boards worklist[0 .. *work_count) (indices into the batch, any order)
+// instead of boards 0 .. n-1 -- the later passes of the multi-pass rollout, see bounce_rollout().  Results do not
+// depend on which wave or lane plays a board: RNG streams are keyed by the board's global game id.
 template <bool FROM_INITIAL, int GL>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                  uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
-                 unsigned long long* __restrict__ steps, uint32_t games_per_wave) {
+                 unsigned long long* __restrict__ steps, uint32_t games_per_wave, const uint32_t* __restrict__ worklist,
+                 const uint32_t* __restrict__ work_count) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
+    const int64_t total = worklist ? (int64_t)*work_count : n;
     const int64_t begin = (int64_t)wave * games_per_wave;
-    const int64_t end = begin + games_per_wave < n ? begin + games_per_wave : n;
+    const int64_t end = begin + games_per_wave < total ? begin + games_per_wave : total;
     const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
+    if (avail == 0u) return;  // (whole wave; nothing to count)
     uint32_t taken = 0;
     const uint32_t lane = threadIdx.x & 63u;
     const bool stores = GL == 1 || (lane & (GL - 1)) == 0;           // the lane that owns the board in memory
@@ -330,8 +336,8 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
         if (need && taken < avail) {
             const uint32_t rank = (uint32_t)__popcll(need & below_group);  // the same in every lane of a group
             if (!live && taken + rank < avail) {
-                game = taken + rank;
-                const int64_t i = begin + game;
+                game = worklist ? worklist[begin + taken + rank] : (uint32_t)(begin + taken + rank);  // board index
+                const int64_t i = game;
                 if (FROM_INITIAL) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) b.v[j] = g.init[j];
@@ -362,7 +368,7 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
         // ---- one ply on every live lane
         if (live) {
             if (!have_block || (plies & 3u) == 0u) {
-                blk = philox4x32_10(seed, first_game + (uint64_t)(begin + game), plies >> 2);
+                blk = philox4x32_10(seed, first_game + (uint64_t)game, plies >> 2);
                 have_block = true;
             }
             const uint32_t mover = plies & 1u;
@@ -385,7 +391,7 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
         // ---- boards that stopped go to memory
         if (!live && dirty) {
             if (stores) {
-                const int64_t i = begin + game;
+                const int64_t i = game;
                 store_board(planes, n, i, b);
                 status[i] = (uint8_t)st;
                 plies_buf[i] = (uint16_t)plies;
@@ -532,6 +538,21 @@ k_bounce_pack(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__
     if (result) result[i] = ok ? 0 : -1;
 }
 
+// boards that are still running below `cap` plies -> worklist (order irrelevant), one atomic per wave
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_compact(const uint8_t* __restrict__ status, const uint16_t* __restrict__ plies_buf, int64_t n, uint32_t cap,
+                 uint32_t* __restrict__ worklist, uint32_t* __restrict__ work_count) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    const bool running = i < n && status[i] == BGS_ST_RUNNING && plies_buf[i] < cap;
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(running);
+    if (!mask) return;
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(work_count, (uint32_t)__popcll(mask));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (running)
+        worklist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)i;
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + BGS_BLOCK - 1) / BGS_BLOCK); }
 
 }  // namespace
@@ -547,31 +568,74 @@ void bounce_step_random(const bgs_batch* b, uint64_t seed) {
                        kMaxPlies, b->d_steps);
 }
 
+// One launch of the fused rollout: over the whole batch (worklist == nullptr) or over a work list.
+// group = lanes per board (1 or 8), wps = waves per SIMD the grid is sized for.
+static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool from_initial, int group, int wps,
+                           const uint32_t* worklist, const uint32_t* work_count) {
+    const int64_t slots_per_wave = BGS_WAVE / group;
+    int64_t per_wave, waves;
+    if (worklist) {
+        // the list's length is only known on the device: one refill round per wave, the grid covers the worst case
+        // (every board) and waves beyond the list return at once
+        per_wave = slots_per_wave;
+        waves = (b->n + per_wave - 1) / per_wave;
+    } else {
+        const int64_t resident = (int64_t)b->num_cus * 4 * wps;
+        per_wave = (b->n + resident - 1) / resident;
+        if (per_wave < slots_per_wave) per_wave = slots_per_wave;
+        waves = (b->n + per_wave - 1) / per_wave;
+    }
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    auto launch = [&](auto initial_tag, auto group_tag) {
+        constexpr bool INITIAL = decltype(initial_tag)::value;
+        constexpr int GL = decltype(group_tag)::value;
+        hipLaunchKernelGGL((k_bounce_rollout<INITIAL, GL>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
+                           b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap,
+                           b->d_steps, (uint32_t)per_wave, worklist, work_count);
+    };
+    auto with_group = [&](auto initial_tag) {
+        if (group == 1) launch(initial_tag, std::integral_constant<int, 1>{});
+        else launch(initial_tag, std::integral_constant<int, 8>{});
+    };
+    if (from_initial) with_group(std::true_type{});
+    else with_group(std::false_type{});
+}
+
+// Random Bounce games have no length bound: most end within a few dozen plies, a few run for hundreds and some
+// never end (they stop at max_plies).  One launch that plays every game to the end spends most of its instruction
+// issue on waves in which a single long game is still alive.  The rollout therefore runs in PASSES with growing ply
+// caps (32, 512, max_plies by default): after a pass the boards that are still running are compacted into a work list
+// (k_bounce_compact) and the next pass plays only those, 64 (or 8) to a wave again.  A board resumes exactly where it
+// stopped (state in memory, RNG keyed by game id and ply), so the result is the one-launch result bit for bit.  The
+// passes are enqueued back to back on the batch's stream; the list lengths never visit the host.
+// Bulk passes use one lane per board (fewest instructions per ply); the last pass uses 8 lanes per board (shortest
+// ply latency, which is what a handful of very long games is bound by).  BGS_BOUNCE_PLAN="cap:lanes,..." overrides.
 void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
     uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
     if (cap > kMaxPlies) cap = kMaxPlies;  // plies are stored as uint16
+    const bool from_initial = (flags & 1u) != 0u;
     if (b->bg.w <= kMaxTrackedColumns && !b->rollout_generic) {
-        // lane-group mode (8 lanes per board) unless BGS_BOUNCE_GROUP=1 asks for one lane per board
-        const int group = b->bounce_group;
-        const int64_t slots_per_wave = BGS_WAVE / group;
-        const int64_t resident = (int64_t)b->num_cus * 4 * (group == 1 ? b->rollout_wps : 8);
-        int64_t per_wave = (b->n + resident - 1) / resident;
-        if (per_wave < slots_per_wave) per_wave = slots_per_wave;
-        const int64_t waves = (b->n + per_wave - 1) / per_wave;
-        const unsigned blocks = (unsigned)((waves + 3) / 4);
-        auto launch = [&](auto initial_tag, auto group_tag) {
-            constexpr bool INITIAL = decltype(initial_tag)::value;
-            constexpr int GL = decltype(group_tag)::value;
-            hipLaunchKernelGGL((k_bounce_rollout<INITIAL, GL>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, b->bg,
-                               b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
-                               b->first_game, cap, b->d_steps, (uint32_t)per_wave);
-        };
-        auto with_group = [&](auto initial_tag) {
-            if (group == 1) launch(initial_tag, std::integral_constant<int, 1>{});
-            else launch(initial_tag, std::integral_constant<int, 8>{});
-        };
-        if (flags & 1u) with_group(std::true_type{});
-        else with_group(std::false_type{});
+        if (b->bounce_passes <= 1) {  // single launch (BGS_BOUNCE_PLAN=single, or a plan with one entry)
+            launch_rollout(b, seed, cap, from_initial, b->bounce_group, b->bounce_group == 1 ? b->rollout_wps : 8, nullptr, nullptr);
+            return;
+        }
+        uint32_t* list = b->d_worklist;
+        uint32_t* counts = b->d_work_count;
+        (void)hipMemsetAsync(counts, 0, sizeof(uint32_t) * BGS_BOUNCE_MAX_PASSES, b->stream);
+        for (int pass = 0; pass < b->bounce_passes; ++pass) {
+            const bool last = pass + 1 == b->bounce_passes;
+            const uint32_t pass_cap = (last || b->bounce_pass_cap[pass] > cap) ? cap : b->bounce_pass_cap[pass];
+            const int group = b->bounce_pass_group[pass];
+            if (pass == 0) {
+                launch_rollout(b, seed, pass_cap, from_initial, group, group == 1 ? b->rollout_wps : 8, nullptr, nullptr);
+            } else {
+                // boards still running below the final cap after the previous pass -> this pass's list
+                hipLaunchKernelGGL(k_bounce_compact, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->d_status, b->d_plies,
+                                   b->n, cap, list, counts + pass);
+                launch_rollout(b, seed, pass_cap, false, group, 0, list, counts + pass);
+            }
+            if (pass_cap >= cap) break;  // nothing can be left for a later pass
+        }
         return;
     }
     // wider boards: one lane per board, two-pass enumeration

@@ -40,6 +40,25 @@ __device__ __forceinline__ uint32_t value_at(const Board& b, int c) {
            ((uint32_t)((b.v[2] >> c) & 1ull) << 2) | ((uint32_t)((b.v[3] >> c) & 1ull) << 3);
 }
 
+// position of the k-th set bit of m (k < popcount(m)) without a loop: a popcount-guided binary search.  The loop form
+// (clear the lowest bit k times) costs a wave the largest k of its 64 lanes.
+__device__ __forceinline__ uint32_t select_bit64(uint64_t m, uint32_t k) {
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    const uint32_t below = (uint32_t)__popc(lo);
+    const bool upper = k >= below;
+    uint32_t word = upper ? hi : lo, pos = upper ? 32u : 0u;
+    k -= upper ? below : 0u;
+#pragma unroll
+    for (uint32_t half = 16u; half >= 1u; half >>= 1) {
+        const uint32_t cnt = (uint32_t)__popc(word & ((1u << half) - 1u));
+        const bool up = k >= cnt;
+        word = up ? word >> half : word;
+        pos += up ? half : 0u;
+        k -= up ? cnt : 0u;
+    }
+    return pos;
+}
+
 // every legal landing cell of the piece on cell `src` for `player` (SURVEY Appendix B rules 4-5).
 // Walkers only ever stand on interior cells (the start piece, empty interior cells), so a forward step never leaves
 // the board and needs no mask; forward is "<< w" for player 0 and ">> w" for player 1, written as two shifts one of
@@ -108,9 +127,8 @@ __device__ __forceinline__ void pick_action(const BounceGeom& g, const Board& b,
         uint64_t t = reach(g, b, occ, player, s);
         const uint32_t cnt = (uint32_t)__popcll(t);
         if (idx < cnt) {
-            for (uint32_t j = 0; j < idx; ++j) t &= t - 1;
             src_cell = s;
-            dst_cell = __ffsll((unsigned long long)t) - 1;
+            dst_cell = (int)select_bit64(t, idx);
             return;
         }
         idx -= cnt;
@@ -258,26 +276,48 @@ __device__ __forceinline__ void enumerate(const BounceGeom& g, const Board& b, u
 }
 
 // The same list computed by the 8 lanes that share one board (lane-group mode): lane `sub` of the group searches the
-// piece in column `sub` of the active row, then every lane collects all eight masks (ds_bpermute within the group).
-// The move search of a board is a handful of independent walks; one lane runs them one after the other, eight
-// lanes run them side by side -- a ply then costs one walk, which is what the latency-bound end of a batch needs.
-__device__ __forceinline__ void enumerate_group(const BounceGeom& g, const Board& b, uint64_t occ, uint32_t player, Moves& m) {
-    const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, leader = lane & ~7u;
+// piece in column `sub` of the active row and KEEPS its mask; the group only exchanges counts (an 8-lane prefix sum)
+// and, when a move is picked, the one (source, target) pair.  The move search of a board is a handful of independent
+// walks; one lane runs them one after the other, eight lanes run them side by side -- a ply then costs one walk, which
+// is what the latency-bound end of a batch needs.
+struct GroupMoves {
+    uint64_t mine;       // legal landing cells of the piece in this lane's column of the active row (0 if none)
+    uint32_t before;     // actions of the columns left of this lane's
+    uint32_t row_base;   // cell index of column 0 of the active row
+    uint32_t n;          // number of actions of the board
+};
+
+__device__ __forceinline__ void enumerate_group(const BounceGeom& g, const Board& b, uint64_t occ, uint32_t player,
+                                                GroupMoves& m) {
+    const uint32_t sub = threadIdx.x & 7u;
     const uint64_t src = movable(g, occ, player);
     const int first = src ? __ffsll((unsigned long long)src) - 1 : 0;
     const int row = (int)(((uint32_t)first * g.inv_w) >> 16);
     m.row_base = (uint32_t)(row * g.w);
     const int c = (int)(m.row_base + sub) & 63;
-    uint64_t mine = 0;
-    if (sub < (uint32_t)g.w && ((src >> c) & 1ull)) mine = reach(g, b, occ, player, c);
-    m.n = 0;
+    m.mine = 0;
+    if (sub < (uint32_t)g.w && ((src >> c) & 1ull)) m.mine = reach(g, b, occ, player, c);
+    const uint32_t cnt = (uint32_t)__popcll(m.mine);
+    uint32_t incl = cnt;  // inclusive prefix sum over the group's 8 lanes
 #pragma unroll
-    for (int x = 0; x < kMaxTrackedColumns; ++x) {
-        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mine, (int)(leader + x), BGS_WAVE);
-        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(mine >> 32), (int)(leader + x), BGS_WAVE);
-        m.t[x] = ((uint64_t)hi << 32) | lo;
-        m.n += (uint32_t)__popcll(m.t[x]);
+    for (int d = 1; d < 8; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 8);
+        incl += sub >= (uint32_t)d ? up : 0u;
     }
+    m.before = incl - cnt;
+    m.n = (uint32_t)__shfl((int)incl, 7, 8);
+}
+
+// the idx-th action of the canonical list: the lane whose column holds it works it out, an OR over the group hands
+// the pair to all eight lanes
+__device__ __forceinline__ void pick_group(const GroupMoves& m, uint32_t idx, int& src_cell, int& dst_cell) {
+    const uint32_t k = idx - m.before;
+    const bool here = k < (uint32_t)__popcll(m.mine);  // (unsigned: idx < before wraps to a huge k)
+    uint32_t pair = here ? ((m.row_base + (threadIdx.x & 7u)) | (select_bit64(m.mine, here ? k : 0u) << 8)) : 0u;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) pair |= (uint32_t)__shfl_xor((int)pair, d, 8);
+    src_cell = (int)(pair & 255u);
+    dst_cell = (int)(pair >> 8);
 }
 
 // the idx-th action of the canonical list (sources by ascending x, targets by ascending cell index)
@@ -294,9 +334,8 @@ __device__ __forceinline__ void pick_from(const Moves& m, uint32_t idx, int& src
         idx = (found || here) ? idx : idx - cnt;
         found = found || here;
     }
-    for (uint32_t j = 0; j < idx; ++j) chosen &= chosen - 1;
     src_cell = (int)(m.row_base + column);
-    dst_cell = __ffsll((unsigned long long)chosen) - 1;
+    dst_cell = (int)select_bit64(chosen, idx);
 }
 
 // GL = lanes per board: 1 (a lane owns a board) or 8 (a lane group shares a board; all eight lanes hold the same
@@ -323,7 +362,7 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
 
     Board b;
     b.v[0] = b.v[1] = b.v[2] = b.v[3] = 0;
-    Moves mv;
+    typename std::conditional<GL == 1, Moves, GroupMoves>::type mv;
     uint32_t st = 0, plies = 0, first_ply = 0, game = 0, stepped = 0;
     bool live = false, dirty = false;
     Philox4 blk;
@@ -352,7 +391,7 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
                 dirty = FROM_INITIAL;
                 have_block = false;
                 if (st == BGS_ST_RUNNING) {
-                    if (GL == 1) enumerate(g, b, occupancy(b), plies & 1u, mv);
+                    if constexpr (GL == 1) enumerate(g, b, occupancy(b), plies & 1u, mv);
                     else enumerate_group(g, b, occupancy(b), plies & 1u, mv);
                     if (mv.n == 0) {  // a running board whose side to move is blocked: settle it now
                         st = settle_blocked(g, b, plies & 1u);
@@ -373,7 +412,8 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
             }
             const uint32_t mover = plies & 1u;
             int s, t;
-            pick_from(mv, sample_index(philox_word(blk, plies), mv.n), s, t);
+            if constexpr (GL == 1) pick_from(mv, sample_index(philox_word(blk, plies), mv.n), s, t);
+            else pick_group(mv, sample_index(philox_word(blk, plies), mv.n), s, t);
             move_piece(b, s, t);
             ++plies;
             dirty = true;
@@ -381,7 +421,7 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
                 st = mover + 1u;
             } else {
                 const uint64_t occ = occupancy(b);
-                if (GL == 1) enumerate(g, b, occ, 1u - mover, mv);
+                if constexpr (GL == 1) enumerate(g, b, occ, 1u - mover, mv);
                 else enumerate_group(g, b, occ, 1u - mover, mv);
                 if (mv.n == 0) st = count_actions(g, b, occ, mover) ? mover + 1u : BGS_ST_DRAW;
             }

@@ -548,13 +548,17 @@ int bgs_reset(bgs_batch* b) {
     return reset_impl(b);
 }
 
-int bgs_step_random(bgs_batch* b, uint64_t seed) {
+int bgs_step_random_n(bgs_batch* b, uint64_t seed, int32_t plies) {
     int rc = enter(b);
     if (rc) return rc;
-    if (b->game == BGS_GAME_CONNECT) bgs::connect_step_random(b, seed);
-    else bgs::bounce_step_random(b, seed);
+    NEED(plies >= 0 && plies <= 4096, "plies must be in 0..4096");
+    if (plies == 0) return BGS_OK;
+    if (b->game == BGS_GAME_CONNECT) bgs::connect_step_random(b, seed, (uint32_t)plies);
+    else bgs::bounce_step_random(b, seed, (uint32_t)plies);
     return finish_launch();
 }
+
+int bgs_step_random(bgs_batch* b, uint64_t seed) { return bgs_step_random_n(b, seed, 1); }
 
 int bgs_step_actions(bgs_batch* b, const int32_t* actions, int actions_on_device, int32_t* status) {
     int rc = enter(b);

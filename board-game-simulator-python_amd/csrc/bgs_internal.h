@@ -74,7 +74,7 @@ namespace bgs {
 
 // ---- Connect (connect_kernels.hip) ----
 void connect_reset(const bgs_batch* b);
-void connect_step_random(const bgs_batch* b, uint64_t seed);
+void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count);  // count plies per board
 void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out);
 bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, uint32_t* codes_out);
 void connect_unpack_grid(const bgs_batch* b, int8_t* d_grid);
@@ -85,7 +85,7 @@ void connect_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_play
 
 // ---- Bounce (bounce_kernels.hip) ----
 void bounce_reset(const bgs_batch* b);
-void bounce_step_random(const bgs_batch* b, uint64_t seed);
+void bounce_step_random(const bgs_batch* b, uint64_t seed, uint32_t count);
 void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out);
 void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags);
 void bounce_unpack_grid(const bgs_batch* b, int8_t* d_grid);

@@ -602,7 +602,8 @@ void bounce_reset(const bgs_batch* b) {
                        b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n);
 }
 
-void bounce_step_random(const bgs_batch* b, uint64_t seed) {
+void bounce_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
+    for (uint32_t q = 0; q < count; ++q)
     hipLaunchKernelGGL((k_bounce_play<true, false>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
                        b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
                        kMaxPlies, b->d_steps);

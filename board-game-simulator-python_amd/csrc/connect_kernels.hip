@@ -581,6 +581,125 @@ k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
     add_steps(steps, stepped);
 }
 
+// position of the k-th set bit of m (k < popcount(m)) without a loop: a popcount-guided binary search
+__device__ __forceinline__ uint32_t select_bit64(uint64_t m, uint32_t k) {
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    const uint32_t below = (uint32_t)__popc(lo);
+    const bool upper = k >= below;
+    uint32_t word = upper ? hi : lo, pos = upper ? 32u : 0u;
+    k -= upper ? below : 0u;
+#pragma unroll
+    for (uint32_t half = 16u; half >= 1u; half >>= 1) {
+        const uint32_t cnt = (uint32_t)__popc(word & ((1u << half) - 1u));
+        const bool up = k >= cnt;
+        word = up ? word >> half : word;
+        pos += up ? half : 0u;
+        k -= up ? cnt : 0u;
+    }
+    return pos;
+}
+
+// `count` uniformly sampled plies on one one-word board held in registers (K1s below).  No column heights are kept:
+// with one always-empty sentinel bit on top of every column, (stones + column bottoms) carries through the stones of
+// each column and leaves exactly one bit per column, on the cell the next stone would take -- masked to the real
+// cells that is the list of legal moves AND the stone positions, and the idx-th legal column is its idx-th set bit.
+template <class G>
+__device__ __forceinline__ uint32_t play_plies(const G& g, uint64_t bottoms, uint64_t cells, uint64_t& p0, uint64_t& p1,
+                                               uint32_t& st, uint64_t seed, uint64_t game, uint32_t count) {
+    if (st != BGS_ST_RUNNING) return 0u;
+    uint32_t ply = (uint32_t)__popcll(p0) + (uint32_t)__popcll(p1);
+    const uint32_t full = (uint32_t)(g.h() * g.w());
+    Philox4 blk = philox4x32_10(seed, game, ply >> 2);
+    uint32_t played = 0;
+    for (uint32_t q = 0; q < count; ++q) {
+        const uint64_t landing = ((p0 | p1) + bottoms) & cells;
+        const uint32_t idx = sample_index(philox_word(blk, ply), (uint32_t)__popcll(landing));
+        const uint32_t pos = select_bit64(landing, idx);
+        const bool second = ply & 1u;
+        uint64_t mine = (second ? p1 : p0) | (1ull << pos);
+        p0 = second ? p0 : mine;
+        p1 = second ? mine : p1;
+        bool won;
+        if (g.k() == 4) {
+            won = four_in_a_row_at(mine, g.h(), pos);
+        } else {
+            Bits<1> b;
+            b.w[0] = mine;
+            won = has_run(g, b);
+        }
+        ++ply;
+        ++played;
+        if (won) { st = (second ? 2u : 1u); break; }
+        if (ply == full) { st = BGS_ST_DRAW; break; }
+        if ((ply & 3u) == 0u && q + 1u < count) blk = philox4x32_10(seed, game, ply >> 2);
+    }
+    return played;
+}
+
+// K1s: the streaming form of K1 for one-word boards and even batch sizes.  K1 is the one kernel of the path that
+// really is HBM bound (a board is read and written once per ply), and it was held back by memory-level parallelism: a
+// wave of K1 has 17 bytes per lane in flight and exits after 64 boards.  Here a lane owns PAIRS of boards -- 16-byte
+// loads and stores on both planes -- the grid is sized to the chip and strides over the batch, and the loads of the
+// next pair are issued before the current one is played, so every wave always has a pair's 34 bytes per lane in
+// flight while it computes.  `count` plies are played per launch on the boards in registers (bgs_step_random_n): the
+// per-ply traffic divides by count.
+template <class G>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
+                             int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps,
+                             uint32_t count) {
+    const int64_t pairs = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * BGS_BLOCK;
+    uint64_t bottoms = 0, cells = 0;  // wave-uniform geometry masks
+    for (int x = 0; x < g.w(); ++x) {
+        bottoms |= 1ull << (x * (g.h() + 1));
+        cells |= ((1ull << g.h()) - 1ull) << (x * (g.h() + 1));
+    }
+    const ulonglong2* plane0 = reinterpret_cast<const ulonglong2*>(planes);
+    const ulonglong2* plane1 = reinterpret_cast<const ulonglong2*>(planes + n);
+    const uint16_t* status2 = reinterpret_cast<const uint16_t*>(status);
+    uint32_t stepped = 0;
+    int64_t t = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    ulonglong2 a{0, 0}, b{0, 0};
+    uint32_t s2 = 0;
+    if (t < pairs) {
+        a = plane0[t];
+        b = plane1[t];
+        s2 = status2[t];
+    }
+    while (t < pairs) {
+        // the next pair's loads go out before this pair is played
+        const int64_t tn = t + stride;
+        ulonglong2 an{0, 0}, bn{0, 0};
+        uint32_t s2n = 0;
+        if (tn < pairs) {
+            an = plane0[tn];
+            bn = plane1[tn];
+            s2n = status2[tn];
+        }
+        uint32_t st0 = s2 & 255u, st1 = s2 >> 8;
+        const uint32_t was0 = st0, was1 = st1;
+        const uint64_t game = first_game + 2ull * (uint64_t)t;
+        uint64_t p00 = a.x, p01 = b.x, p10 = a.y, p11 = b.y;  // board 2t: planes p00 / p01, board 2t + 1: p10 / p11
+        const uint32_t n0 = play_plies(g, bottoms, cells, p00, p01, st0, seed, game, count);
+        const uint32_t n1 = play_plies(g, bottoms, cells, p10, p11, st1, seed, game + 1ull, count);
+        if (n0 | n1) {
+            reinterpret_cast<ulonglong2*>(planes)[t] = ulonglong2{p00, p10};
+            reinterpret_cast<ulonglong2*>(planes + n)[t] = ulonglong2{p01, p11};
+            if (st0 != was0 || st1 != was1) {
+                reinterpret_cast<uint16_t*>(status)[t] = (uint16_t)(st0 | (st1 << 8));
+                reinterpret_cast<uint32_t*>(reward)[t] = (uint32_t)reward_pair(st0) | ((uint32_t)reward_pair(st1) << 16);
+            }
+        }
+        stepped += n0 + n1;
+        a = an;
+        b = bn;
+        s2 = s2n;
+        t = tn;
+    }
+    add_steps(steps, stepped);
+}
+
 // Outcome codes of a wave's chunk, accumulated where the games end (the fused form of k_pack_outcomes): 2 bits per
 // game, 16 games per dword, in a wave-private slice of LDS; when the chunk is finished the wave stores its dwords to
 // `codes_out` -- for the host hand-over that is page-locked HOST memory mapped into the device, so the codes are in
@@ -1179,7 +1298,23 @@ void dispatch_game(const ConnectGeom& cg, F&& f) {
     });
 }
 
-void connect_step_random(const bgs_batch* b, uint64_t seed) {
+void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
+    // one-word boards, even batch: the streaming kernel (pairs of boards per lane, `count` plies per launch)
+    if (b->cg.nw == 1 && (b->n & 1) == 0 && !b->rollout_generic) {
+        const int64_t pairs = b->n >> 1;
+        int64_t blocks = (pairs + BGS_BLOCK - 1) / BGS_BLOCK;
+        const int64_t resident = (int64_t)b->num_cus * 8;  // 8 workgroups of 4 waves per CU
+        if (blocks > resident) blocks = resident;
+        dispatch(b->cg, [&](auto g) {
+            using G = decltype(g);
+            if constexpr (G::NW == 1)
+                hipLaunchKernelGGL((k_connect_step_random_stream<G>), dim3((unsigned)blocks), dim3(BGS_BLOCK), 0, b->stream, g,
+                                   b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
+                                   b->first_game, b->d_steps, count);
+        });
+        return;
+    }
+    for (uint32_t q = 0; q < count; ++q)
     dispatch_game(b->cg, [&](auto g, auto game_tag) {
         using G = decltype(g);
         using Game = typename decltype(game_tag)::type;

@@ -240,8 +240,10 @@ class _Batch:
     def reset(self) -> None:
         _abi.check(_abi.lib().bgs_reset(self._handle))
 
-    def step_random(self, seed: int = DEFAULT_SEED) -> None:
-        _abi.check(_abi.lib().bgs_step_random(self._handle, ctypes.c_uint64(seed)))
+    def step_random(self, seed: int = DEFAULT_SEED, plies: int = 1) -> None:
+        """`plies` uniformly sampled plies on every running board (one launch where the kernel can keep the boards
+        in registers in between)."""
+        _abi.check(_abi.lib().bgs_step_random_n(self._handle, ctypes.c_uint64(seed), ctypes.c_int32(plies)))
 
     def rollout(self, seed: int = DEFAULT_SEED, max_plies: int = 2**31 - 1, from_initial: bool = False) -> None:
         flags = _abi.ROLLOUT_FROM_INITIAL if from_initial else 0

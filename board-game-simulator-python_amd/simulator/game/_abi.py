@@ -60,6 +60,7 @@ SIGNATURES = {
     "bgs_buffer": (ctypes.c_int, [c_handle, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]),
     "bgs_reset": (ctypes.c_int, [c_handle]),
     "bgs_step_random": (ctypes.c_int, [c_handle, ctypes.c_uint64]),
+    "bgs_step_random_n": (ctypes.c_int, [c_handle, ctypes.c_uint64, ctypes.c_int32]),
     "bgs_step_actions": (ctypes.c_int, [c_handle, ctypes.c_void_p, ctypes.c_int, _i32p]),
     "bgs_rollout": (ctypes.c_int, [c_handle, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32]),
     "bgs_steps": (ctypes.c_int, [c_handle, _u64p]),

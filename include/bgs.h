@@ -95,6 +95,10 @@ int bgs_reset(bgs_batch* b);
 /* ONE ply on every running board: State::get_actions (connect.cpp:43, bounce.cpp:40) -> uniform choice
  * (README.md:62 random.choice) -> Action::sample_next_state (connect.cpp:52, bounce.cpp:51) -> has_ended / reward */
 int bgs_step_random(bgs_batch* b, uint64_t seed);
+/* `plies` such plies on every board that is (still) running, boards held in registers in between where the kernel
+ * allows it (Connect boards of one 64-bit word: the per-ply memory traffic divides by `plies`); the result is the one
+ * of `plies` calls of bgs_step_random */
+int bgs_step_random_n(bgs_batch* b, uint64_t seed, int32_t plies);
 /* ONE caller-chosen ply: State::get_action_at (connect.cpp:44 / bounce.cpp:42) + Action::sample_next_state.
  * Connect: actions int32[n] = column; Bounce: int32[n][4] = source x, y, target x, y.  A negative first entry
  * skips the board.  actions_on_device != 0: `actions` is a device pointer.  status (host int32[n], may be

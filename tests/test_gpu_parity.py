@@ -69,6 +69,27 @@ def test_connect_step_random_lockstep(batch_mod, h, w, k):
     assert orc.ended.all()
 
 
+@pytest.mark.parametrize("h,w,k,n", [(6, 7, 4, 5000), (6, 7, 4, 4999), (2, 3, 2, 64), (4, 5, 3, 1002), (8, 8, 4, 770),
+                                     (7, 8, 5, 300), (12, 13, 5, 500), (1, 6, 2, 130)])
+def test_connect_step_random_n(batch_mod, h, w, k, n):
+    """bgs_step_random_n == that many bgs_step_random calls: the streaming kernel (one-word boards, even n: pairs of
+    boards per lane, several plies per launch, philox block boundaries inside a launch) and the fallbacks (odd n,
+    multi-word boards)."""
+    dev = batch_mod.ConnectBatch(h, w, k, n)
+    orc = oracle.ConnectOracle(h, w, k, n)
+    dev.set_first_game(12345)
+    total = 0
+    for plies in (1, 3, 4, 2, 5, 7, 1, 64):
+        dev.step_random(SEED ^ 77, plies=plies)
+        for _ in range(plies):
+            total += orc.step_random(SEED ^ 77, first_game=12345)
+        assert_same(dev, orc, f"after {plies} more plies")
+        assert dev.steps == total
+    assert orc.ended.all()
+    dev.step_random(SEED, plies=0)  # nothing to do
+    assert dev.steps == total
+
+
 @pytest.mark.parametrize("h,w,k", CONNECT_GEOMETRIES)
 @pytest.mark.parametrize("from_initial", [False, True])
 def test_connect_rollout(batch_mod, h, w, k, from_initial):

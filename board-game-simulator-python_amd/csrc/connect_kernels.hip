@@ -603,10 +603,11 @@ __device__ __forceinline__ uint32_t select_bit64(uint64_t m, uint32_t k) {
 // with one always-empty sentinel bit on top of every column, (stones + column bottoms) carries through the stones of
 // each column and leaves exactly one bit per column, on the cell the next stone would take -- masked to the real
 // cells that is the list of legal moves AND the stone positions, and the idx-th legal column is its idx-th set bit.
-template <class G>
+template <bool SINGLE, class G>
 __device__ __forceinline__ uint32_t play_plies(const G& g, uint64_t bottoms, uint64_t cells, uint64_t& p0, uint64_t& p1,
                                                uint32_t& st, uint64_t seed, uint64_t game, uint32_t count) {
     if (st != BGS_ST_RUNNING) return 0u;
+    if (SINGLE) count = 1u;  // (straight-line code: no loop, no second philox block)
     uint32_t ply = (uint32_t)__popcll(p0) + (uint32_t)__popcll(p1);
     const uint32_t full = (uint32_t)(g.h() * g.w());
     Philox4 blk = philox4x32_10(seed, game, ply >> 2);
@@ -643,7 +644,7 @@ __device__ __forceinline__ uint32_t play_plies(const G& g, uint64_t bottoms, uin
 // next pair are issued before the current one is played, so every wave always has a pair's 34 bytes per lane in
 // flight while it computes.  `count` plies are played per launch on the boards in registers (bgs_step_random_n): the
 // per-ply traffic divides by count.
-template <class G>
+template <class G, bool SINGLE>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                              int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps,
@@ -681,8 +682,8 @@ k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __rest
         const uint32_t was0 = st0, was1 = st1;
         const uint64_t game = first_game + 2ull * (uint64_t)t;
         uint64_t p00 = a.x, p01 = b.x, p10 = a.y, p11 = b.y;  // board 2t: planes p00 / p01, board 2t + 1: p10 / p11
-        const uint32_t n0 = play_plies(g, bottoms, cells, p00, p01, st0, seed, game, count);
-        const uint32_t n1 = play_plies(g, bottoms, cells, p10, p11, st1, seed, game + 1ull, count);
+        const uint32_t n0 = play_plies<SINGLE>(g, bottoms, cells, p00, p01, st0, seed, game, count);
+        const uint32_t n1 = play_plies<SINGLE>(g, bottoms, cells, p10, p11, st1, seed, game + 1ull, count);
         if (n0 | n1) {
             reinterpret_cast<ulonglong2*>(planes)[t] = ulonglong2{p00, p10};
             reinterpret_cast<ulonglong2*>(planes + n)[t] = ulonglong2{p01, p11};
@@ -1307,10 +1308,16 @@ void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
         if (blocks > resident) blocks = resident;
         dispatch(b->cg, [&](auto g) {
             using G = decltype(g);
-            if constexpr (G::NW == 1)
-                hipLaunchKernelGGL((k_connect_step_random_stream<G>), dim3((unsigned)blocks), dim3(BGS_BLOCK), 0, b->stream, g,
-                                   b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
-                                   b->first_game, b->d_steps, count);
+            if constexpr (G::NW == 1) {
+                if (count == 1u)
+                    hipLaunchKernelGGL((k_connect_step_random_stream<G, true>), dim3((unsigned)blocks), dim3(BGS_BLOCK), 0,
+                                       b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
+                                       seed, b->first_game, b->d_steps, count);
+                else
+                    hipLaunchKernelGGL((k_connect_step_random_stream<G, false>), dim3((unsigned)blocks), dim3(BGS_BLOCK), 0,
+                                       b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
+                                       seed, b->first_game, b->d_steps, count);
+            }
         });
         return;
     }

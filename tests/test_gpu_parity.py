@@ -79,7 +79,7 @@ def test_connect_step_random_n(batch_mod, h, w, k, n):
     orc = oracle.ConnectOracle(h, w, k, n)
     dev.set_first_game(12345)
     total = 0
-    for plies in (1, 3, 4, 2, 5, 7, 1, 64):
+    for plies in (1, 3, 4, 2, 5, 7, 1, 64, 100):
         dev.step_random(SEED ^ 77, plies=plies)
         for _ in range(plies):
             total += orc.step_random(SEED ^ 77, first_game=12345)

@@ -685,8 +685,12 @@ k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __rest
         const uint32_t n0 = play_plies<SINGLE>(g, bottoms, cells, p00, p01, st0, seed, game, count);
         const uint32_t n1 = play_plies<SINGLE>(g, bottoms, cells, p10, p11, st1, seed, game + 1ull, count);
         if (n0 | n1) {
-            reinterpret_cast<ulonglong2*>(planes)[t] = ulonglong2{p00, p10};
-            reinterpret_cast<ulonglong2*>(planes + n)[t] = ulonglong2{p01, p11};
+            // one ply changes only the mover's plane: when neither board of the pair changed plane 0 (or plane 1),
+            // that 16-byte store is skipped -- in lock-step play both boards have the same side to move
+            const bool touch0 = !SINGLE || p00 != a.x || p10 != a.y;
+            const bool touch1 = !SINGLE || p01 != b.x || p11 != b.y;
+            if (touch0) reinterpret_cast<ulonglong2*>(planes)[t] = ulonglong2{p00, p10};
+            if (touch1) reinterpret_cast<ulonglong2*>(planes + n)[t] = ulonglong2{p01, p11};
             if (st0 != was0 || st1 != was1) {
                 reinterpret_cast<uint16_t*>(status)[t] = (uint16_t)(st0 | (st1 << 8));
                 reinterpret_cast<uint32_t*>(reward)[t] = (uint32_t)reward_pair(st0) | ((uint32_t)reward_pair(st1) << 16);

@@ -41,25 +41,32 @@ constexpr size_t kStepBytes = (size_t)BGS_STEP_SHARDS * BGS_STEP_STRIDE * sizeof
 inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-    size_t planes, status, plies, reward, steps, worklist, work_count, staging, total, staging_bytes;
+    size_t planes, status, plies, reward, steps, worklist, work_count, gen_masks, gen_cfg, staging, total, staging_bytes;
 };
 
-Layout layout_for(int planes, int64_t n, int h, int w) {
+// planes > 0: bit-packed boards (planes x uint64 per board); planes == 0: the generic layout, int8[n][h][w] in the same
+// region.  legal_bytes: bytes per board of the legal-move record bgs_transition returns.
+Layout layout_for(int planes, int64_t n, int h, int w, size_t legal_bytes = 0) {
     Layout l;
     size_t off = 0;
-    l.planes = off; off += align_up((size_t)planes * n * 8);
+    size_t board_bytes = (size_t)planes * 8;  // the region must hold whichever form the batch turns out to use
+    if (board_bytes < (size_t)h * w && legal_bytes) board_bytes = (size_t)h * w;
+    l.planes = off; off += align_up(board_bytes * n);
     l.status = off; off += align_up((size_t)n);
     l.plies = off; off += align_up((size_t)n * 2);
     l.reward = off; off += align_up((size_t)n * 2);
     l.steps = off; off += align_up(kStepBytes);
     l.worklist = off; off += align_up((size_t)n * 4);
     l.work_count = off; off += align_up(sizeof(uint32_t) * BGS_BOUNCE_MAX_PASSES);
+    l.gen_masks = off; off += align_up(sizeof(uint64_t) * 4 * (BGS_GENERIC_BOUNCE_MAX_CELLS / 64));
+    l.gen_cfg = off; off += align_up((size_t)h * w);
     size_t per_board = (size_t)h * w;
     if (per_board < (size_t)8 * (w + 1)) per_board = (size_t)8 * (w + 1);
     if (per_board < 16) per_board = 16;
+    if (legal_bytes < per_board) legal_bytes = per_board;
     // unpack / pack scratch for every board, plus bgs_transition's in-block and out-block (object API: <= 4096 boards)
     const size_t small = n < 4096 ? (size_t)n : 4096;
-    l.staging_bytes = (size_t)n * (per_board + 16) + small * (2 * per_board + 96) + 8 * kAlign;
+    l.staging_bytes = (size_t)n * (per_board + 16) + small * (per_board + legal_bytes + 96) + 8 * kAlign;
     l.staging = off; off += align_up(l.staging_bytes);
     l.total = off;
     return l;
@@ -75,32 +82,45 @@ int check_device(int device) {
     return BGS_OK;
 }
 
-int connect_geom(int h, int w, int k, ConnectGeom* cg) {
-    NEED(h >= 1 && h <= BGS_CONNECT_MAX_H, "Connect height %d outside 1..%d", h, BGS_CONNECT_MAX_H);
-    NEED(w >= 1 && w <= BGS_CONNECT_MAX_W, "Connect width %d outside 1..%d", w, BGS_CONNECT_MAX_W);
+bool force_generic() { return getenv("BGS_FORCE_GENERIC") != nullptr; }
+
+// *generic = 1: outside the bit-packed representation's limits (or BGS_FORCE_GENERIC): served by generic_kernels.hip
+int connect_geom(int h, int w, int k, ConnectGeom* cg, int* generic) {
+    NEED(h >= 1 && h <= BGS_GENERIC_CONNECT_MAX_DIM, "Connect height %d outside 1..%d", h, BGS_GENERIC_CONNECT_MAX_DIM);
+    NEED(w >= 1 && w <= BGS_GENERIC_CONNECT_MAX_DIM, "Connect width %d outside 1..%d", w, BGS_GENERIC_CONNECT_MAX_DIM);
     NEED(k >= 1, "Connect count %d must be positive", k);
     const int bits = w * (h + 1);
-    NEED(bits <= 64 * BGS_CONNECT_MAX_WORDS, "Connect board %dx%d needs %d bits per plane (max %d)", h, w, bits,
-         64 * BGS_CONNECT_MAX_WORDS);
-    cg->h = h; cg->w = w; cg->k = k; cg->nw = (bits + 63) / 64;
+    *generic = force_generic() || h > BGS_CONNECT_MAX_H || w > BGS_CONNECT_MAX_W || bits > 64 * BGS_CONNECT_MAX_WORDS;
+    cg->h = h; cg->w = w; cg->k = k; cg->nw = *generic ? 0 : (bits + 63) / 64;
     return BGS_OK;
 }
 
-int bounce_geom(const int8_t* cfg, int h, int w, BounceGeom* bg) {
-    NEED(cfg != nullptr, "Bounce config grid is NULL");
-    NEED(h >= 3 && w >= 1 && h * w <= BGS_BOUNCE_MAX_CELLS, "Bounce board %dx%d unsupported (need height >= 3, cells <= %d)",
-         h, w, BGS_BOUNCE_MAX_CELLS);
+bool bounce_size_ok(int h, int w) {
+    return h >= 3 && w >= 1 && h <= BGS_GENERIC_BOUNCE_MAX_DIM && w <= BGS_GENERIC_BOUNCE_MAX_DIM &&
+           h * w <= BGS_GENERIC_BOUNCE_MAX_CELLS;
+}
+
+// cfg == nullptr: size check only (arena size query; the values decide between packed and generic at create time,
+// the arena size covers both)
+int bounce_geom(const int8_t* cfg, int h, int w, BounceGeom* bg, int* generic) {
+    NEED(bounce_size_ok(h, w), "Bounce board %dx%d unsupported (need height >= 3, sides <= %d, cells <= %d)", h, w,
+         BGS_GENERIC_BOUNCE_MAX_DIM, BGS_GENERIC_BOUNCE_MAX_CELLS);
+    *generic = force_generic() || h * w > BGS_BOUNCE_MAX_CELLS;
     memset(bg, 0, sizeof(*bg));
     bg->h = h; bg->w = w;
+    if (!cfg) return BGS_OK;
+    for (int c = 0; c < h * w; ++c) {
+        NEED(cfg[c] >= 0, "Bounce piece value %d at (%d,%d) is negative", cfg[c], c % w, c / w);
+        NEED(!(cfg[c] > 0 && (c < w || c >= (h - 1) * w)), "Bounce goal rows must be empty (piece at (%d,%d))", c % w, c / w);
+        if (cfg[c] > BGS_BOUNCE_MAX_VALUE) *generic = 1;
+    }
+    if (*generic) return BGS_OK;
     bg->inv_w = (65536u + (uint32_t)w - 1u) / (uint32_t)w;
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             const int c = y * w + x;
             const uint64_t bit = 1ull << c;
             const int v = cfg[c];
-            NEED(v >= 0 && v <= BGS_BOUNCE_MAX_VALUE, "Bounce piece value %d at (%d,%d) outside 0..%d", v, x, y,
-                 BGS_BOUNCE_MAX_VALUE);
-            NEED(!(v > 0 && (y == 0 || y == h - 1)), "Bounce goal rows must be empty (piece at (%d,%d))", x, y);
             bg->all |= bit;
             if (y == 0) bg->goal_bottom |= bit;
             else if (y == h - 1) bg->goal_top |= bit;
@@ -132,6 +152,8 @@ int carve(bgs_batch* b, void* arena, size_t arena_bytes, const Layout& l) {
     b->d_steps = reinterpret_cast<unsigned long long*>(base + l.steps);
     b->d_worklist = reinterpret_cast<uint32_t*>(base + l.worklist);
     b->d_work_count = reinterpret_cast<uint32_t*>(base + l.work_count);
+    b->d_gen_masks = reinterpret_cast<uint64_t*>(base + l.gen_masks);
+    b->d_gen_cfg = reinterpret_cast<int8_t*>(base + l.gen_cfg);
     b->d_staging = base + l.staging;
     b->staging_bytes = l.staging_bytes;
     return BGS_OK;
@@ -307,6 +329,13 @@ k_expand_outcomes(const uint8_t* __restrict__ packed, int64_t n, uint16_t* __res
     }
 }
 
+// bytes per board of the legal-move record bgs_transition returns
+size_t legal_bytes_per_board(const bgs_batch* b) {
+    if (b->game == BGS_GAME_CONNECT) return (size_t)b->cg.w;
+    if (b->generic) return bgs::generic_bounce_legal_bytes(b->gen_h, b->gen_w);
+    return 8 * ((size_t)b->bg.w + 1);
+}
+
 int make_order_event(bgs_batch* b) {
     HIP_TRY(hipEventCreateWithFlags(&b->order_event, hipEventDisableTiming));
     return BGS_OK;
@@ -321,9 +350,40 @@ void discard(bgs_batch* b) {
 
 int reset_impl(bgs_batch* b) {
     HIP_TRY(hipMemsetAsync(b->d_steps, 0, kStepBytes, b->stream));
-    if (b->game == BGS_GAME_CONNECT) bgs::connect_reset(b);
+    if (b->generic) bgs::generic_reset(b);
+    else if (b->game == BGS_GAME_CONNECT) bgs::connect_reset(b);
     else bgs::bounce_reset(b);
     return finish_launch();
+}
+
+// generic Bounce: cell masks and start grid to the device; the device settles a start position without legal moves
+int generic_bounce_setup(bgs_batch* b, const int8_t* cfg) {
+    constexpr int W = BGS_GENERIC_BOUNCE_MAX_CELLS / 64;
+    uint64_t masks[4 * W];
+    memset(masks, 0, sizeof(masks));
+    const int h = b->gen_h, w = b->gen_w;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int c = y * w + x;
+            const uint64_t bit = 1ull << (c & 63);
+            masks[0 * W + (c >> 6)] |= bit;                              // every cell
+            if (y > 0 && y < h - 1) masks[1 * W + (c >> 6)] |= bit;      // interior rows
+            if (x > 0) masks[2 * W + (c >> 6)] |= bit;
+            if (x < w - 1) masks[3 * W + (c >> 6)] |= bit;
+        }
+    HIP_TRY(hipMemcpyAsync(b->d_gen_masks, masks, sizeof(masks), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->d_gen_cfg, cfg, (size_t)h * w, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));  // (masks[] is on this stack frame)
+    // load the start grid as board 0 of a one-board view: the pack kernel settles a blocked start position
+    bgs_batch one = *b;
+    one.n = 1;
+    bgs::generic_pack(&one, b->d_gen_cfg, nullptr, nullptr, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    uint8_t status0 = 0;
+    HIP_TRY(hipMemcpyAsync(&status0, b->d_status, 1, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->gen_init_status = status0;
+    return BGS_OK;
 }
 
 }  // namespace
@@ -351,7 +411,8 @@ int rollout_with_codes(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t 
     NEED(max_plies >= 0, "max_plies must be >= 0");
     NEED(codes_out != nullptr && ((uintptr_t)codes_out % 16) == 0, "codes destination must be 16-byte aligned");
     bool fused = false;
-    if (b->game == BGS_GAME_CONNECT) fused = bgs::connect_rollout(b, seed, max_plies, flags, reinterpret_cast<uint32_t*>(codes_out));
+    if (b->generic) bgs::generic_play(b, seed, (uint32_t)max_plies, 0xFFFFFFFFu, (flags & BGS_ROLLOUT_FROM_INITIAL) != 0);
+    else if (b->game == BGS_GAME_CONNECT) fused = bgs::connect_rollout(b, seed, max_plies, flags, reinterpret_cast<uint32_t*>(codes_out));
     else bgs::bounce_rollout(b, seed, max_plies, flags);
     if (!fused) bgs::pack_outcomes(b, codes_out);
     return finish_launch();
@@ -376,17 +437,22 @@ int bgs_device_count(int* count) {
 
 int bgs_connect_arena_bytes(int height, int width, int count, int64_t n, size_t* bytes) {
     ConnectGeom cg;
-    int rc = connect_geom(height, width, count, &cg);
+    int generic = 0;
+    int rc = connect_geom(height, width, count, &cg, &generic);
     if (rc) return rc;
     NEED(n >= 1 && bytes, "n must be >= 1 and bytes non-NULL");
-    *bytes = layout_for(2 * cg.nw, n, height, width).total;
+    *bytes = layout_for(2 * cg.nw, n, height, width, generic ? (size_t)width : 0).total;
     return BGS_OK;
 }
 
 int bgs_bounce_arena_bytes(int height, int width, int64_t n, size_t* bytes) {
-    NEED(height >= 3 && width >= 1 && height * width <= BGS_BOUNCE_MAX_CELLS, "Bounce board %dx%d unsupported", height, width);
+    BounceGeom bg;
+    int generic = 0;
+    int rc = bounce_geom(nullptr, height, width, &bg, &generic);
+    if (rc) return rc;
     NEED(n >= 1 && bytes, "n must be >= 1 and bytes non-NULL");
-    *bytes = layout_for(4, n, height, width).total;
+    // (whether the batch is packed or generic also depends on the piece values: the arena covers both forms)
+    *bytes = layout_for(generic ? 0 : 4, n, height, width, bgs::generic_bounce_legal_bytes(height, width)).total;
     return BGS_OK;
 }
 
@@ -395,7 +461,8 @@ int bgs_connect_create(int height, int width, int count, int64_t n, int device, 
     NEED(out != nullptr, "out is NULL");
     *out = nullptr;
     ConnectGeom cg;
-    int rc = connect_geom(height, width, count, &cg);
+    int generic = 0;
+    int rc = connect_geom(height, width, count, &cg, &generic);
     if (rc) return rc;
     NEED(n >= 1, "batch size must be >= 1");
     rc = check_device(device);
@@ -409,8 +476,10 @@ int bgs_connect_create(int height, int width, int count, int64_t n, int device, 
     b->n = n;
     b->cg = cg;
     b->planes = 2 * cg.nw;
+    b->generic = generic;
+    b->gen_h = height; b->gen_w = width; b->gen_k = count;
     rc = device_facts(b);
-    if (rc == BGS_OK) rc = carve(b, arena, arena_bytes, layout_for(b->planes, n, height, width));
+    if (rc == BGS_OK) rc = carve(b, arena, arena_bytes, layout_for(b->planes, n, height, width, generic ? (size_t)width : 0));
     if (rc == BGS_OK) rc = make_order_event(b);
     if (rc == BGS_OK) rc = reset_impl(b);
     if (rc != BGS_OK) {
@@ -426,7 +495,9 @@ int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, 
     NEED(out != nullptr, "out is NULL");
     *out = nullptr;
     BounceGeom bg;
-    int rc = bounce_geom(cfg_grid, height, width, &bg);
+    int generic = 0;
+    NEED(cfg_grid != nullptr, "Bounce config grid is NULL");
+    int rc = bounce_geom(cfg_grid, height, width, &bg, &generic);
     if (rc) return rc;
     NEED(n >= 1, "batch size must be >= 1");
     rc = check_device(device);
@@ -439,11 +510,19 @@ int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, 
     b->device = device;
     b->n = n;
     b->bg = bg;
-    b->planes = 4;
+    b->planes = generic ? 0 : 4;
+    b->generic = generic;
+    b->gen_h = height; b->gen_w = width;
     rc = device_facts(b);
-    if (rc == BGS_OK) rc = carve(b, arena, arena_bytes, layout_for(4, n, height, width));
-    if (rc == BGS_OK) rc = make_order_event(b);
     if (rc == BGS_OK) {
+        // the arena is sized for whichever form the values select (bgs_bounce_arena_bytes cannot know them)
+        const int size_generic = height * width > BGS_BOUNCE_MAX_CELLS;
+        rc = carve(b, arena, arena_bytes,
+                   layout_for(size_generic ? 0 : 4, n, height, width, bgs::generic_bounce_legal_bytes(height, width)));
+    }
+    if (rc == BGS_OK) rc = make_order_event(b);
+    if (rc == BGS_OK && generic) rc = generic_bounce_setup(b, cfg_grid);
+    if (rc == BGS_OK && !generic) {
         // a start position whose first player cannot move is already over: let the device settle board 0 once
         // and remember the verdict (the kernels own every rule; the host evaluates none)
         rc = [&]() -> int {
@@ -519,8 +598,19 @@ int bgs_info(const bgs_batch* b, int* game, int* height, int* width, int* count,
     if (height) *height = connect ? b->cg.h : b->bg.h;
     if (width) *width = connect ? b->cg.w : b->bg.w;
     if (count) *count = connect ? b->cg.k : 0;
+    if (b->generic) {
+        if (height) *height = b->gen_h;
+        if (width) *width = b->gen_w;
+    }
     if (n) *n = b->n;
     if (planes) *planes = b->planes;
+    return BGS_OK;
+}
+
+int bgs_legal_bytes(const bgs_batch* b, size_t* bytes, int* generic) {
+    NEED(b != nullptr && bytes != nullptr, "NULL argument");
+    *bytes = legal_bytes_per_board(b);
+    if (generic) *generic = b->generic;
     return BGS_OK;
 }
 
@@ -529,7 +619,10 @@ int bgs_buffer(const bgs_batch* b, int buffer_id, void** device_ptr, size_t* byt
     size_t sz = 0;
     void* p = nullptr;
     switch (buffer_id) {
-        case BGS_BUF_PLANES: p = b->d_planes; sz = (size_t)b->planes * b->n * 8; break;
+        case BGS_BUF_PLANES:  // (generic batches: the int8[n][h][w] grid itself)
+            p = b->d_planes;
+            sz = b->generic ? (size_t)b->n * b->gen_h * b->gen_w : (size_t)b->planes * b->n * 8;
+            break;
         case BGS_BUF_STATUS: p = b->d_status; sz = (size_t)b->n; break;
         case BGS_BUF_PLIES: p = b->d_plies; sz = (size_t)b->n * 2; break;
         case BGS_BUF_REWARD: p = b->d_reward; sz = (size_t)b->n * 2; break;
@@ -553,7 +646,8 @@ int bgs_step_random_n(bgs_batch* b, uint64_t seed, int32_t plies) {
     if (rc) return rc;
     NEED(plies >= 0 && plies <= 4096, "plies must be in 0..4096");
     if (plies == 0) return BGS_OK;
-    if (b->game == BGS_GAME_CONNECT) bgs::connect_step_random(b, seed, (uint32_t)plies);
+    if (b->generic) bgs::generic_play(b, seed, 0xFFFFFFFFu, (uint32_t)plies, false);
+    else if (b->game == BGS_GAME_CONNECT) bgs::connect_step_random(b, seed, (uint32_t)plies);
     else bgs::bounce_step_random(b, seed, (uint32_t)plies);
     return finish_launch();
 }
@@ -576,7 +670,8 @@ int bgs_step_actions(bgs_batch* b, const int32_t* actions, int actions_on_device
         if (rc) return rc;
         d_actions = tmp;
     }
-    if (b->game == BGS_GAME_CONNECT) bgs::connect_step_actions(b, d_actions, d_result);
+    if (b->generic) bgs::generic_step_actions(b, d_actions, d_result);
+    else if (b->game == BGS_GAME_CONNECT) bgs::connect_step_actions(b, d_actions, d_result);
     else bgs::bounce_step_actions(b, d_actions, d_result);
     rc = finish_launch();
     if (rc) return rc;
@@ -589,7 +684,8 @@ int bgs_rollout(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) 
     int rc = enter(b);
     if (rc) return rc;
     NEED(max_plies >= 0, "max_plies must be >= 0");
-    if (b->game == BGS_GAME_CONNECT) (void)bgs::connect_rollout(b, seed, max_plies, flags, nullptr);
+    if (b->generic) bgs::generic_play(b, seed, (uint32_t)max_plies, 0xFFFFFFFFu, (flags & BGS_ROLLOUT_FROM_INITIAL) != 0);
+    else if (b->game == BGS_GAME_CONNECT) (void)bgs::connect_rollout(b, seed, max_plies, flags, nullptr);
     else bgs::bounce_rollout(b, seed, max_plies, flags);
     return finish_launch();
 }
@@ -619,6 +715,8 @@ int bgs_read_grid(bgs_batch* b, int8_t* grid) {
     NEED(grid != nullptr, "grid is NULL");
     const bool connect = b->game == BGS_GAME_CONNECT;
     const size_t cells = (size_t)b->n * (connect ? b->cg.h * b->cg.w : b->bg.h * b->bg.w);
+    if (b->generic)  // the grid is stored in the reference layout already
+        return to_host(b, grid, reinterpret_cast<const int8_t*>(b->d_planes), cells);
     Stage st(b);
     int8_t* d = st.take<int8_t>(cells);
     NEED(d != nullptr, "staging buffer too small");
@@ -638,7 +736,8 @@ static int read_meta(bgs_batch* b, int8_t* player, uint8_t* ended, int8_t* winne
     int8_t* dw = winner ? st.take<int8_t>((size_t)b->n) : nullptr;
     int32_t* dl = plies ? st.take<int32_t>((size_t)b->n) : nullptr;
     NEED((!player || dp) && (!ended || de) && (!winner || dw) && (!plies || dl), "staging buffer too small");
-    if (b->game == BGS_GAME_CONNECT) bgs::connect_meta(b, dp, de, dw, dl);
+    if (b->generic) bgs::generic_meta(b, dp, de, dw, dl);
+    else if (b->game == BGS_GAME_CONNECT) bgs::connect_meta(b, dp, de, dw, dl);
     else bgs::bounce_meta(b, dp, de, dw, dl);
     rc = finish_launch();
     if (rc) return rc;
@@ -685,7 +784,8 @@ int bgs_read_legal(bgs_batch* b, uint8_t* legal) {
     Stage st(b);
     uint8_t* d = st.take<uint8_t>((size_t)b->n * b->cg.w);
     NEED(d != nullptr, "staging buffer too small");
-    bgs::connect_legal(b, d, nullptr);
+    if (b->generic) bgs::generic_connect_legal(b, d, nullptr);
+    else bgs::connect_legal(b, d, nullptr);
     rc = finish_launch();
     if (rc) return rc;
     return to_host(b, legal, d, (size_t)b->n * b->cg.w);
@@ -698,7 +798,9 @@ int bgs_read_action_count(bgs_batch* b, int32_t* count) {
     Stage st(b);
     int32_t* d = st.take<int32_t>((size_t)b->n);
     NEED(d != nullptr, "staging buffer too small");
-    if (b->game == BGS_GAME_CONNECT) bgs::connect_legal(b, nullptr, d);
+    if (b->generic && b->game == BGS_GAME_CONNECT) bgs::generic_connect_legal(b, nullptr, d);
+    else if (b->generic) bgs::generic_bounce_targets(b, nullptr, d);
+    else if (b->game == BGS_GAME_CONNECT) bgs::connect_legal(b, nullptr, d);
     else bgs::bounce_targets(b, nullptr, d);
     rc = finish_launch();
     if (rc) return rc;
@@ -710,6 +812,8 @@ int bgs_bounce_read_targets(bgs_batch* b, uint64_t* targets) {
     if (rc) return rc;
     NEED(targets != nullptr, "targets is NULL");
     NEED(b->game == BGS_GAME_BOUNCE, "bgs_bounce_read_targets needs a Bounce batch");
+    NEED(!b->generic, "this Bounce board does not fit 64-bit target masks (more than 64 cells or values above 15): "
+                      "read its moves through bgs_transition's wide legal record");
     Stage st(b);
     uint64_t* d = st.take<uint64_t>((size_t)b->n * (b->bg.w + 1));
     NEED(d != nullptr, "staging buffer too small");
@@ -726,19 +830,24 @@ int bgs_export_device(bgs_batch* b, int what, void* device_dst) {
     switch (what) {
         case 'g':
             NEED(((uintptr_t)device_dst % 16) == 0, "grid destination must be 16-byte aligned");
-            if (b->game == BGS_GAME_CONNECT) bgs::connect_unpack_grid(b, static_cast<int8_t*>(device_dst));
+            if (b->generic) bgs::generic_unpack_grid(b, static_cast<int8_t*>(device_dst));
+            else if (b->game == BGS_GAME_CONNECT) bgs::connect_unpack_grid(b, static_cast<int8_t*>(device_dst));
             else bgs::bounce_unpack_grid(b, static_cast<int8_t*>(device_dst));
             break;
         case 'l':
             NEED(b->game == BGS_GAME_CONNECT, "'l' (legal mask) is Connect only");
-            bgs::connect_legal(b, static_cast<uint8_t*>(device_dst), nullptr);
+            if (b->generic) bgs::generic_connect_legal(b, static_cast<uint8_t*>(device_dst), nullptr);
+            else bgs::connect_legal(b, static_cast<uint8_t*>(device_dst), nullptr);
             break;
         case 'c':
-            if (b->game == BGS_GAME_CONNECT) bgs::connect_legal(b, nullptr, static_cast<int32_t*>(device_dst));
+            if (b->generic && b->game == BGS_GAME_CONNECT) bgs::generic_connect_legal(b, nullptr, static_cast<int32_t*>(device_dst));
+            else if (b->generic) bgs::generic_bounce_targets(b, nullptr, static_cast<int32_t*>(device_dst));
+            else if (b->game == BGS_GAME_CONNECT) bgs::connect_legal(b, nullptr, static_cast<int32_t*>(device_dst));
             else bgs::bounce_targets(b, nullptr, static_cast<int32_t*>(device_dst));
             break;
         case 't':
             NEED(b->game == BGS_GAME_BOUNCE, "'t' (target masks) is Bounce only");
+            NEED(!b->generic, "'t' needs a board of at most 64 cells with values up to 15 (64-bit target masks)");
             bgs::bounce_targets(b, static_cast<uint64_t*>(device_dst), nullptr);
             break;
         case 'r':
@@ -791,7 +900,8 @@ int bgs_write_state(bgs_batch* b, const int8_t* grid, const int8_t* player, cons
     if (player && (rc = to_device(b, dp, player, (size_t)b->n))) return rc;
     if (winner && (rc = to_device(b, dw, winner, (size_t)b->n))) return rc;
     if (dl && (rc = to_device(b, dl, plies, (size_t)b->n))) return rc;
-    if (connect) bgs::connect_pack(b, dg, dp, dw, dr);
+    if (b->generic) bgs::generic_pack(b, dg, dp, dw, dl, dr);
+    else if (connect) bgs::connect_pack(b, dg, dp, dw, dr);
     else bgs::bounce_pack(b, dg, dp, dw, dl, dr);
     rc = finish_launch();
     if (rc) return rc;
@@ -811,7 +921,7 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
     const size_t n = (size_t)b->n;
     const size_t hw = connect ? (size_t)b->cg.h * b->cg.w : (size_t)b->bg.h * b->bg.w;
     const size_t per_action = connect ? 1 : 4;
-    const size_t legal_bytes = connect ? n * b->cg.w : n * 8 * ((size_t)b->bg.w + 1);
+    const size_t legal_bytes = n * legal_bytes_per_board(b);
     auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
     // in-block: [grid][player][winner][plies][actions]; out-block: [load status][step status][grid][player][winner][plies][legal]
     const size_t in_grid = 0, in_player = up8(n * hw), in_winner = in_player + up8(n), in_plies = in_winner + up8(n),
@@ -831,7 +941,8 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
         HIP_TRY(hipEventCreateWithFlags(&b->pinned_done[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&b->pinned_done[1], hipEventDisableTiming));
     }
-    NEED(in_bytes <= kPinnedChunk && out_bytes <= kPinnedChunk, "batch too large for bgs_transition");
+    NEED(in_bytes <= kPinnedChunk && out_bytes <= kPinnedChunk,
+         "batch too large for bgs_transition (%zu bytes per call): use fewer boards per call", out_bytes);
     uint8_t* h_in = static_cast<uint8_t*>(b->pinned[0]);
     uint8_t* h_out = static_cast<uint8_t*>(b->pinned[1]);
     const bool load = grid != nullptr;
@@ -852,19 +963,26 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
         const int8_t* dp = reinterpret_cast<const int8_t*>(d_in + in_player);
         const int8_t* dw = reinterpret_cast<const int8_t*>(d_in + in_winner);
         const int32_t* dl = plies ? reinterpret_cast<const int32_t*>(d_in + in_plies) : nullptr;
-        if (connect) bgs::connect_pack(b, dg, dp, dw, d_load);
+        if (b->generic) bgs::generic_pack(b, dg, dp, dw, dl, d_load);
+        else if (connect) bgs::connect_pack(b, dg, dp, dw, d_load);
         else bgs::bounce_pack(b, dg, dp, dw, dl, d_load);
     }
     if (actions) {
         const int32_t* da = reinterpret_cast<const int32_t*>(d_in + in_actions);
-        if (connect) bgs::connect_step_actions(b, da, d_step);
+        if (b->generic) bgs::generic_step_actions(b, da, d_step);
+        else if (connect) bgs::connect_step_actions(b, da, d_step);
         else bgs::bounce_step_actions(b, da, d_step);
     }
     int8_t* og = reinterpret_cast<int8_t*>(d_out + out_grid);
     int8_t* op = reinterpret_cast<int8_t*>(d_out + out_player);
     int8_t* ow = reinterpret_cast<int8_t*>(d_out + out_winner);
     int32_t* ol = reinterpret_cast<int32_t*>(d_out + out_plies);
-    if (connect) {
+    if (b->generic) {
+        bgs::generic_unpack_grid(b, og);
+        bgs::generic_meta(b, op, nullptr, ow, ol);
+        if (connect) bgs::generic_connect_legal(b, d_out + out_legal, nullptr);
+        else bgs::generic_bounce_targets(b, d_out + out_legal, nullptr);
+    } else if (connect) {
         bgs::connect_unpack_grid(b, og);
         bgs::connect_meta(b, op, nullptr, ow, ol);
         bgs::connect_legal(b, d_out + out_legal, nullptr);

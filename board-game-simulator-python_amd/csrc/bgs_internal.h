@@ -14,7 +14,11 @@ enum {
     BGS_CONNECT_MAX_W = 16,
     BGS_BOUNCE_MAX_CELLS = 64,   // height * width <= 64: one bit per cell in a uint64
     BGS_BOUNCE_MAX_VALUE = 15,   // 4 value bit-planes
-    BGS_BOUNCE_MAX_PASSES = 8    // passes of the multi-pass Bounce rollout
+    BGS_BOUNCE_MAX_PASSES = 8,   // passes of the multi-pass Bounce rollout
+    // the generic (reference-layout) kernels take over beyond the packed limits
+    BGS_GENERIC_CONNECT_MAX_DIM = 64,      // height, width <= 64 (the oracle's own limit: nothing larger can be checked)
+    BGS_GENERIC_BOUNCE_MAX_CELLS = 1024,   // height * width <= 1024, piece values <= 127 (int8)
+    BGS_GENERIC_BOUNCE_MAX_DIM = 64
 };
 
 struct ConnectGeom {
@@ -36,6 +40,9 @@ struct BounceGeom {
 
 struct bgs_batch {
     int game;
+    int generic;             // 1: the board is an int8 grid in the reference layout, played by generic_kernels.hip
+    int gen_h, gen_w, gen_k;
+    uint32_t gen_init_status;
     int device;
     int64_t n;
     hipStream_t stream;
@@ -62,6 +69,8 @@ struct bgs_batch {
     unsigned long long* d_steps;
     uint8_t* d_staging;
     size_t staging_bytes;
+    uint64_t* d_gen_masks;   // generic Bounce: [4][16] cell masks (all, interior, x > 0, x < w - 1)
+    int8_t* d_gen_cfg;       // generic Bounce: the configured start grid
     uint32_t* d_worklist;    // [n] board indices still to play (Bounce multi-pass rollout)
     uint32_t* d_work_count;  // [BGS_BOUNCE_MAX_PASSES] list lengths, device-resident
     // pinned bounce buffers for large device -> host copies (allocated on first use)
@@ -93,6 +102,18 @@ void bounce_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t*
 void bounce_targets(const bgs_batch* b, uint64_t* d_targets, int32_t* d_count);
 void bounce_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_player, const int8_t* d_winner,
                  const int32_t* d_plies, int32_t* d_status_out);
+
+// ---- any geometry (generic_kernels.hip): the batch's "planes" region holds int8[n][h][w] ----
+size_t generic_bounce_legal_bytes(int h, int w);  // bytes per board of the wide legal-move record
+void generic_reset(const bgs_batch* b);
+void generic_play(const bgs_batch* b, uint64_t seed, uint32_t max_plies, uint32_t count, bool from_initial);
+void generic_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out);
+void generic_unpack_grid(const bgs_batch* b, int8_t* d_grid);
+void generic_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies);
+void generic_connect_legal(const bgs_batch* b, uint8_t* d_legal, int32_t* d_count);
+void generic_bounce_targets(const bgs_batch* b, uint8_t* d_wide, int32_t* d_count);
+void generic_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_player, const int8_t* d_winner,
+                  const int32_t* d_plies, int32_t* d_status_out);
 
 // ---- shared by the C-ABI translation units (bgs_capi.hip, bgs_host.hip) ----
 // status bytes -> 2-bit outcome codes, 4 boards per byte, enqueued on the batch's stream

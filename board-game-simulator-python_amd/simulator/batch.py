@@ -212,6 +212,10 @@ class _Batch:
         return ctypes.c_void_p(self._arena.data_ptr()), nbytes
 
     def _after_create(self):
+        nbytes, generic = ctypes.c_size_t(), ctypes.c_int()
+        _abi.check(_abi.lib().bgs_legal_bytes(self._handle, ctypes.byref(nbytes), ctypes.byref(generic)))
+        self._legal_bytes = nbytes.value   # bytes per board of bgs_transition's legal-move record
+        self.generic = bool(generic.value)  # served by the generic kernels (geometry beyond the bit-packed limits)
         if self._torch is not None:
             self.set_stream(self._torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -574,7 +578,37 @@ class BounceBatch(_Batch):
     _action_width = 4
 
     def _empty_legal(self):
+        if self.generic:  # wide record: int32 active row, then uint8 flags[W][H * W] (include/bgs.h, bgs_legal_bytes)
+            return np.empty((self.n, self._legal_bytes), dtype=np.uint8)
         return np.empty((self.n, self.width + 1), dtype=np.uint64)
+
+    def decode_moves(self, legal_row, winner: int):
+        """One board's legal-move record (either format) -> tuple of ((sx, sy), (tx, ty)) in canonical order."""
+        width, height = self.width, self.height
+        moves = []
+        if winner != -1:
+            return ()
+        if self.generic:
+            row = int(legal_row[:4].view(np.int32)[0])
+            if row < 0:
+                return ()
+            flags = legal_row[4 : 4 + width * height * width].reshape(width, height * width)
+            for x in range(width):
+                for c in np.flatnonzero(flags[x]):
+                    moves.append(((x, row), (int(c) % width, int(c) // width)))
+            return tuple(moves)
+        row = int(legal_row[width])
+        if row >= height:  # all ones: nothing can move
+            return ()
+        for x in range(width):
+            m = int(legal_row[x])
+            c = 0
+            while m:
+                if m & 1:
+                    moves.append(((x, row), (c % width, c // width)))
+                m >>= 1
+                c += 1
+        return tuple(moves)
 
     def __init__(self, grid, n: int, device: int = 0, use_torch: Optional[bool] = None):
         cfg = np.ascontiguousarray(grid)
@@ -605,6 +639,8 @@ class BounceBatch(_Batch):
     def targets(self) -> np.ndarray:
         """uint64[n, W + 1]: entry i < W has bit (y * W + x) set for each legal target of the piece in column i of the
         active row; entry W is the active row's y (all ones when nothing can move)."""
+        if self.generic:
+            raise ValueError("this board does not fit 64-bit target masks: use transition() / decode_moves()")
         out = np.empty((self.n, self.width + 1), dtype=np.uint64)
         _abi.check(_abi.lib().bgs_bounce_read_targets(self._handle, _ptr(out, ctypes.c_uint64)))
         return out

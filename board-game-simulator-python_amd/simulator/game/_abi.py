@@ -57,6 +57,7 @@ SIGNATURES = {
         ctypes.c_int,
         [c_handle] + [ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)],
     ),
+    "bgs_legal_bytes": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]),
     "bgs_buffer": (ctypes.c_int, [c_handle, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]),
     "bgs_reset": (ctypes.c_int, [c_handle]),
     "bgs_step_random": (ctypes.c_int, [c_handle, ctypes.c_uint64]),

@@ -67,19 +67,7 @@ class _Engine:
         if status[0] != 0:
             raise RuntimeError("malformed Bounce state")
         grid_out, player_out, winner_out, plies_out = g[0], int(p[0]), int(w[0]), int(l[0])
-        width = b.width
-        moves: List[Tuple[Cell, Cell]] = []
-        row = int(masks[0, width])
-        if winner_out == -1 and row < b.height:  # the active row, as reported by the device
-            for x in range(width):
-                m = int(masks[0, x])
-                c = 0
-                while m:
-                    if m & 1:
-                        moves.append(((x, row), (c % width, c // width)))
-                    m >>= 1
-                    c += 1
-        return grid_out, player_out, winner_out, plies_out, tuple(moves), reward[0]
+        return grid_out, player_out, winner_out, plies_out, b.decode_moves(masks[0], winner_out), reward[0]
 
     def initial(self):
         with self.lock:

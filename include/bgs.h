@@ -86,6 +86,16 @@ int bgs_set_stream(bgs_batch* b, void* hip_stream);
 int bgs_set_first_game(bgs_batch* b, uint64_t first_game); /* global id of board 0 (sharding across GPUs) */
 int bgs_synchronize(bgs_batch* b);
 int bgs_info(const bgs_batch* b, int* game, int* height, int* width, int* count, int64_t* n, int* planes);
+/* Geometries beyond the bit-packed kernels' limits (Connect: height > 15, width > 16 or width * (height + 1) > 192;
+ * Bounce: more than 64 cells or piece values above 15) are served by the generic kernels: same entry points, same
+ * results, the board held as int8[n][h][w] (BGS_BUF_PLANES is then that grid).  Limits of the generic path: Connect
+ * height, width <= 64; Bounce height, width <= 64, height * width <= 1024, values <= 127.
+ * bgs_legal_bytes: bytes per board of the legal-move record of bgs_transition, and whether the batch is generic:
+ *   Connect           uint8[width] mask;
+ *   Bounce (packed)   uint64[width + 1]: target masks per column of the active row, then the active row's y;
+ *   Bounce (generic)  int32 active row (-1 = none), then uint8 flags[width][height * width] (1 = legal target cell
+ *                     of the piece in that column of the active row), padded to a multiple of 8 bytes. */
+int bgs_legal_bytes(const bgs_batch* b, size_t* bytes, int* generic);
 /* device pointer + size of one of the batch's buffers (zero-copy hand-over to torch / RCCL) */
 int bgs_buffer(const bgs_batch* b, int buffer_id, void** device_ptr, size_t* bytes);
 

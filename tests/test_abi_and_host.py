@@ -47,12 +47,22 @@ def test_geometry_limits_are_checked_on_the_host():
     lib = _abi.lib()
     assert lib.bgs_connect_arena_bytes(6, 7, 4, 1 << 20, ctypes.byref(nbytes)) == 0
     assert nbytes.value >= (1 << 20) * (16 + 1 + 2 + 42)
-    assert lib.bgs_connect_arena_bytes(16, 7, 4, 8, ctypes.byref(nbytes)) == _abi.BGS_ERR_ARG
+    # beyond the bit-packed limits the generic kernels serve the board (int8 grid in the arena) ...
+    assert lib.bgs_connect_arena_bytes(16, 7, 4, 8, ctypes.byref(nbytes)) == 0 and nbytes.value >= 8 * 16 * 7
+    assert lib.bgs_connect_arena_bytes(15, 13, 4, 8, ctypes.byref(nbytes)) == 0
+    assert lib.bgs_connect_arena_bytes(20, 20, 5, 1000, ctypes.byref(nbytes)) == 0 and nbytes.value >= 1000 * 400
+    assert lib.bgs_connect_arena_bytes(64, 64, 5, 8, ctypes.byref(nbytes)) == 0
+    # ... up to the generic path's own limits
+    assert lib.bgs_connect_arena_bytes(65, 7, 4, 8, ctypes.byref(nbytes)) == _abi.BGS_ERR_ARG
     assert b"height" in lib.bgs_last_error()
-    assert lib.bgs_connect_arena_bytes(15, 13, 4, 8, ctypes.byref(nbytes)) == _abi.BGS_ERR_ARG
+    assert lib.bgs_connect_arena_bytes(6, 65, 4, 8, ctypes.byref(nbytes)) == _abi.BGS_ERR_ARG
+    assert lib.bgs_connect_arena_bytes(6, 7, 0, 8, ctypes.byref(nbytes)) == _abi.BGS_ERR_ARG
     assert lib.bgs_bounce_arena_bytes(9, 6, 1 << 18, ctypes.byref(nbytes)) == 0
-    assert lib.bgs_bounce_arena_bytes(9, 8, 8, ctypes.byref(nbytes)) == _abi.BGS_ERR_ARG
+    assert lib.bgs_bounce_arena_bytes(9, 8, 8, ctypes.byref(nbytes)) == 0 and nbytes.value >= 8 * 72
+    assert lib.bgs_bounce_arena_bytes(32, 32, 8, ctypes.byref(nbytes)) == 0
     assert lib.bgs_bounce_arena_bytes(2, 6, 8, ctypes.byref(nbytes)) == _abi.BGS_ERR_ARG
+    assert lib.bgs_bounce_arena_bytes(33, 32, 8, ctypes.byref(nbytes)) == _abi.BGS_ERR_ARG  # more than 1024 cells
+    assert lib.bgs_bounce_arena_bytes(3, 65, 8, ctypes.byref(nbytes)) == _abi.BGS_ERR_ARG
 
 
 def test_connect_host_objects():
@@ -65,8 +75,9 @@ def test_connect_host_objects():
     assert Config.num_players == 2
     with pytest.raises(TypeError):
         Config(2.0, 3, 2)
+    assert Config(40, 40, 4).to_json() == {"height": 40, "width": 40, "count": 4}  # served by the generic kernels
     with pytest.raises(ValueError):
-        Config(40, 40, 4)
+        Config(65, 40, 4)
     with pytest.raises(RuntimeError):
         Config.from_json({"height": 2})
     with pytest.raises(AttributeError):

@@ -168,7 +168,10 @@ def main() -> int:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # BGS_FORCE_DIST=1 takes the N > 1 code path (process group, per-step RCCL gather, rank-0 sink) with whatever world
+    # size the launcher gave, 1 included: the way to run that path over RCCL on a one-GPU box
+    sharded = world > 1 or os.environ.get("BGS_FORCE_DIST") == "1"
+    if sharded:
         import torch.distributed as dist
 
         if backend == "nccl":
@@ -181,11 +184,11 @@ def main() -> int:
     from simulator.sharding import gather_outcomes_to, shard_range, sum_steps
 
     n = args.batch
-    if world > 1 and n % 4:
+    if sharded and n % 4:
         print("bench.py: --batch must be a multiple of 4 when sharded (4 outcome codes per byte)", file=sys.stderr)
         return 2
     handover = args.handover
-    if world > 1 and handover == "pairs":
+    if sharded and handover == "pairs":
         handover = "codes"  # ranks exchange codes; int8 pairs would put 8x the bytes on xGMI and on rank 0's PCIe link
     depth = max(1, args.inflight)
     os.environ.setdefault("BGS_ROLLOUT_WPS", "2")  # waves per SIMD per launch; `depth` launches share the chip
@@ -198,15 +201,15 @@ def main() -> int:
     # One GPU: the hand-over pipeline is deeper than the GPU's (twice as many host arrays / sink slots as streams), so
     # the launching thread waits for the delivery of step i - 2 * depth, not i - depth, before it enqueues step i:
     # waiting on the previous step of the SAME stream would leave the GPU one batch short for the length of the delivery
-    host_slots = 2 * depth if world == 1 else depth
+    host_slots = depth if sharded else 2 * depth
     batches, packed, all_packed, host_rewards, events = [], [], [], [], []
     for s in streams:
         with torch.cuda.stream(s):
             b = ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=local_rank, use_torch=True)  # ordered onto stream s
             b.set_first_game(shard_range(n * world, rank, world)[0])
             batches.append(b)
-            packed.append(torch.empty(code_bytes, dtype=torch.uint8, device=gpu) if world > 1 else None)
-            all_packed.append(torch.empty(world * code_bytes, dtype=torch.uint8, device=gpu) if world > 1 and owner else None)
+            packed.append(torch.empty(code_bytes, dtype=torch.uint8, device=gpu) if sharded else None)
+            all_packed.append(torch.empty(world * code_bytes, dtype=torch.uint8, device=gpu) if sharded and owner else None)
     for _ in range(host_slots):
         if handover == "pairs":
             host_rewards.append(PinnedArray((n, 2), np.int8))
@@ -420,7 +423,7 @@ def main() -> int:
                              "pairs": f"int8[{n}, 2] reward buffer ({2 * n} B per step over PCIe) -> page-locked host array",
                              "none": "rewards stay on the device"}[handover],
                 "sharding": f"game ids split over {world} rank(s); per step {'RCCL' if backend == 'nccl' else backend} gather of "
-                f"2-bit outcome codes ({code_bytes} B per rank) to rank 0" if world > 1 else "single GPU",
+                f"2-bit outcome codes ({code_bytes} B per rank) to rank 0" if sharded else "single GPU",
                 "gathered_rewards_verified": gather_ok,
                 "inflight_batches": depth,
                 "waves_per_simd_per_launch": int(os.environ["BGS_ROLLOUT_WPS"]),

@@ -444,6 +444,20 @@ def test_bench_two_ranks_gloo_rehearsal():
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # only rank 0 prints the line
 
 
+def test_bench_rccl_path_with_one_rank():
+    """The N > 1 loop over the REAL collective backend (nccl = RCCL) with a world of one rank -- what a one-GPU box can
+    run of it: process group on the GPU, per-step dist.gather of the outcome codes, rank-0 sink, verified host array."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               BGS_FORCE_DIST="1")
+    env.pop("BGS_DIST_BACKEND", None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "3",
+                           "--batch", str(1 << 18), "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["gathered_rewards_verified"] is True and "RCCL gather" in d["config"]["sharding"]
+    assert d["config"]["rewards_to_host"] is True and d["value"] > 0
+
+
 def test_bench_single_gpu_line():
     """The default hand-over on one GPU at a small batch: contract fields, host rewards verified against the oracle."""
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--batch",

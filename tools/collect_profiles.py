@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_* (tools/profile_all.sh) -> profiles/r02_*.json, including profiles/r02_rollout_counters.json, the
+per-launch PMC figures of the bench kernel that bench.py quotes when its build id matches the running library."""
+import json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
+OUT = os.path.join(ROOT, "profiles")
+
+
+def summary(tag, want=""):
+    return json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "summarize_profile.py"), tag, want]))
+
+
+def hbm_bytes(k):
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; gfx950 reports HALF the bytes of wide coalesced reads
+    # (MI355X_MICROARCH.md, HBM): FETCH_SIZE is doubled, WRITE_SIZE taken as is
+    return (2 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0)) * 1024.0
+
+
+def main():
+    from simulator.game import _abi
+
+    build = _abi.build_id()
+    method = ("tools/profile_all.sh: rocprofv3 --kernel-trace --stats, then --pmc in separate passes (SQ_*; FETCH_SIZE; "
+              "WRITE_SIZE), per-dispatch means; FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads), KiB -> B")
+    for tag, want, name in (("bench", "k_connect_rollout_aligned", "r02_bench_kernel.json"), ("k1", "step_random", "r02_k1.json"),
+                            ("k2c", "k_connect_rollout_lds", "r02_k2c.json"), ("bounce", "k_bounce_rollout", "r02_bounce.json")):
+        s = summary(tag, want)
+        for k in s.values():
+            k["hbm_bytes_per_launch"] = hbm_bytes(k)
+            if "SQ_THREAD_CYCLES_VALU" in k and k.get("SQ_ACTIVE_INST_VALU"):
+                k["active_lanes_per_valu_instruction"] = k["SQ_THREAD_CYCLES_VALU"] / k["SQ_ACTIVE_INST_VALU"]
+        with open(os.path.join(OUT, name), "w") as fh:
+            json.dump({"build_id": build, "method": method, "kernels": s}, fh, indent=1)
+    misc = summary("misc")
+    with open(os.path.join(OUT, "r02_misc_kernel_stats.json"), "w") as fh:
+        json.dump({"build_id": build, "command": "rocprofv3 --kernel-trace --stats -- python3 tools/measure_all.py", "kernels": misc}, fh, indent=1)
+    mfile = os.path.join(ROOT, "gpurun_out", "measure_all.json")
+    if os.path.exists(mfile) and os.path.getsize(mfile):
+        with open(mfile) as fh, open(os.path.join(OUT, "r02_secondary_measurements.json"), "w") as out:
+            out.write(fh.read())
+    bench = summary("bench", "k_connect_rollout_aligned")
+    k = next(iter(bench.values()))
+    with open(os.path.join(ROOT, "gpurun_out", "valu_mix.json")) as fh:
+        mix = json.load(fh)
+    counters = {
+        "build_id": build,
+        "kernel": next(iter(bench)),
+        "dispatches": k.get("dispatches"),
+        "mean_us": k.get("mean_us"),
+        "valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"],
+        "salu_wave_instructions_per_launch": k["SQ_INSTS_SALU"],
+        "active_lanes_per_valu_instruction": k["SQ_THREAD_CYCLES_VALU"] / k["SQ_ACTIVE_INST_VALU"],
+        "FETCH_SIZE_KiB": k["FETCH_SIZE"],
+        "WRITE_SIZE_KiB": k["WRITE_SIZE"],
+        "hbm_bytes_per_launch": hbm_bytes(k),
+        "mix_cycles_per_instruction": mix["mix_cycles_per_instruction"],
+        "mix": mix,
+        "method": method + "; command: python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-device-resident; "
+        "mix_cycles_per_instruction from tools/valu_mix.py",
+    }
+    with open(os.path.join(OUT, "r02_rollout_counters.json"), "w") as fh:
+        json.dump(counters, fh, indent=1)
+    print(json.dumps({kk: counters[kk] for kk in ("build_id", "valu_wave_instructions_per_launch", "hbm_bytes_per_launch",
+                                                  "active_lanes_per_valu_instruction", "mean_us")}))
+
+
+if __name__ == "__main__":
+    main()

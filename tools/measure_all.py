@@ -37,13 +37,14 @@ for lg in (20, 24):
         g = torch.empty((n, 6, 7), dtype=torch.int8, device="cuda")
         t = timed(lambda i: b.grid_tensor(g), 10)
         out["connect_unpack_n2^20"] = {"s_per_launch": t, "out_GBps": n * 42 / t / 1e9}
-        # host hand-over: rollout + rewards into a host array (PCIe inclusive)
+        # host hand-over, synchronous form: rollout + bgs_read_reward into a pageable host array (PCIe inclusive); the
+        # asynchronous form is what bench.py times
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(10):
             b.rollout(SEED + i, from_initial=True)
             r = b.reward
         dt = (time.perf_counter() - t0) / 10
-        out["connect_rollout_plus_reward_to_host_n2^20"] = {"s_per_step": dt, "env_steps_per_s": 22.35e6 / dt}
+        out["connect_rollout_plus_sync_reward_read_n2^20"] = {"s_per_step": dt, "env_steps_per_s": 22.35e6 / dt}
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(3):
             b.rollout(SEED + i, from_initial=True)

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-2 profiles of every kernel of the path, one command (on the GPU box):  bash tools/profile_all.sh
+# Each kernel gets rocprofv3 --kernel-trace --stats, an SQ counter pass and separate FETCH_SIZE / WRITE_SIZE passes
+# (tools/profile_kernel.sh: the program directly after "--"); tools/collect_profiles.py turns the CSVs into
+# profiles/r02_*.json and the counters file bench.py reads (keyed by the library's build id).
+set -e
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+# K2a: the bench itself (hand-over included), 12 timed launches in the counter passes
+bash tools/profile_kernel.sh bench python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-device-resident
+# K1s: the HBM-bound per-ply kernel at 2^24 boards
+bash tools/profile_kernel.sh k1 python3 tools/k1_steps.py
+# K2c: Connect(12,13,5), 2^18 boards
+bash tools/profile_kernel.sh k2c python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9
+# K3: Bounce 9x6, 2^18 boards, max_plies 4096
+bash tools/profile_kernel.sh bounce python3 tools/rollout_rate.py bounce --depth 1 --reps 6
+# K4 and the rest (reset, unpack, legal, ...): kernel stats only
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT}
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_misc_stats -- python3 $R/tools/measure_all.py > $R/gpurun_out/measure_all.json 2> $R/gpurun_out/measure_all.err
+cd $R
+python3 tools/valu_mix.py > gpurun_out/valu_mix.json
+python3 tools/collect_profiles.py

@@ -108,6 +108,11 @@ SIGNATURES = {
         [c_handle, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
     ),
     "bgs_sink_wait": (ctypes.c_int, [c_handle, ctypes.c_int64]),
+    "bgs_multi_connect_rollout": (
+        ctypes.c_int,
+        [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,
+         ctypes.c_void_p, _u64p],
+    ),
     "bgs_write_state": (ctypes.c_int, [c_handle, _i8p, _i8p, _i8p, _i32p, _i32p]),
 }
 

@@ -66,3 +66,25 @@ def sum_steps(dist, local_steps: int, device) -> int:
     t = torch.tensor([int(local_steps)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def multi_device_rollout(devices, height: int, width: int, count: int, n_per_device: int, seed: int):
+    """Connect rollouts sharded over several GPUs of this node from ONE process, without torch.distributed:
+    `bgs_multi_connect_rollout` (RCCL point-to-point gather of the outcome codes to devices[0], one copy to the host).
+    Returns (reward int8[len(devices) * n_per_device, 2] in global game order, env-steps)."""
+    import ctypes
+
+    import numpy as np
+
+    from .game import _abi
+
+    devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+    reward = np.empty((len(devices) * n_per_device, 2), dtype=np.int8)
+    steps = ctypes.c_uint64(0)
+    _abi.check(
+        _abi.lib().bgs_multi_connect_rollout(
+            devs, len(devices), height, width, count, n_per_device, ctypes.c_uint64(seed), ctypes.c_void_p(reward.ctypes.data),
+            ctypes.byref(steps),
+        )
+    )
+    return reward, steps.value

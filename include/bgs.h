@@ -194,6 +194,16 @@ int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* dev
                            int8_t* host_reward, int64_t* ticket);
 int bgs_sink_wait(bgs_reward_sink* s, int64_t ticket); /* until that submission's rewards are in its host array */
 
+/* ---- several GPUs of one node from one host process (no torch.distributed needed) ------------------------------
+ * Device devices[r] plays Connect games with global ids [r * n_per_device, (r + 1) * n_per_device) from
+ * Config::sample_initial_state() to the end (bgs_rollout), the devices' outcome codes are gathered on devices[0] with
+ * RCCL point-to-point calls over xGMI, copied to the host once and expanded into host_reward
+ * int8[n_devices * n_per_device][2] in global game order; *steps = env-steps of all devices.  The result equals
+ * one batch of n_devices * n_per_device boards on one device.  n_per_device must be a multiple of 4.  One-shot: batches,
+ * streams and communicators live for the call.  RCCL is loaded on first use (dlopen "librccl.so.1"). */
+int bgs_multi_connect_rollout(const int* devices, int n_devices, int height, int width, int count, int64_t n_per_device,
+                              uint64_t seed, int8_t* host_reward, uint64_t* steps);
+
 /* ---- loading boards (State::from_json, connect.cpp:46 / bounce.cpp:45; policy-driven stepping) ---- */
 /* grid int8[n][h][w]; player int8[n] (Connect: may be NULL, derived from the stone counts); winner int8[n]
  * (NULL = all running; Connect re-derives wins and draws from the grid when NULL); plies int32[n] (Bounce; NULL =

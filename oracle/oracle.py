@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# BGS_ORACLE_LIBRARY: another build of the same source, e.g. oracle/liboracle_asan.so (tools/oracle_asan.sh)
+_LIB_PATH = os.environ.get("BGS_ORACLE_LIBRARY", os.path.join(_HERE, "liboracle.so"))
 
 _i8p = ctypes.POINTER(ctypes.c_int8)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -27,6 +28,8 @@ def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (plain C + OpenMP)."""
     src = os.path.join(_HERE, "bgs_oracle.c")
     hdr = os.path.join(_HERE, "bgs_oracle.h")
+    if "BGS_ORACLE_LIBRARY" in os.environ:
+        return _LIB_PATH
     stale = (
         force
         or not os.path.exists(_LIB_PATH)

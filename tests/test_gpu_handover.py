@@ -171,6 +171,37 @@ def test_reward_sink_takes_gathered_codes(bm, torch_mod):
     sink.close()
 
 
+MULTI_CHILD = """
+import sys
+sys.path[:0] = [{root!r}, {pkg!r}]
+import numpy as np
+from oracle import oracle
+from simulator.game import _abi
+from simulator.sharding import multi_device_rollout
+devices = list(range(min(_abi.device_count(), 2)))
+n, seed = 40000, 0x0123456789ABCDEF + 5
+reward, steps = multi_device_rollout(devices, 6, 7, 4, n, seed)
+whole = oracle.ConnectOracle(6, 7, 4, n * len(devices))
+assert whole.rollout(seed) == steps, (steps,)
+assert np.array_equal(reward, whole.reward)
+try:
+    multi_device_rollout(devices, 6, 7, 4, 1001, seed)
+    raise SystemExit("n_per_device = 1001 was accepted")
+except ValueError:
+    pass
+print("MULTI_OK", len(devices), steps)
+"""
+
+
+def test_multi_device_entry_point_over_rccl():
+    """bgs_multi_connect_rollout (one process, RCCL send/recv gather) on the devices this box has: the host array must
+    equal the unsharded oracle run.  With one GPU the gather is a self send/recv -- the RCCL call sequence still runs.
+    (In a child process under `timeout`: a collective that does not complete must not take the test session along.)"""
+    code = MULTI_CHILD.format(root=ROOT, pkg=os.path.join(ROOT, "board-game-simulator-python_amd"))
+    proc = subprocess.run(["timeout", "-k", "10", "240", sys.executable, "-c", code], capture_output=True, text=True)
+    assert proc.returncode == 0 and "MULTI_OK" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-3000:]
+
+
 def test_batch_created_under_a_side_stream_is_ordered(bm, torch_mod):
     """A batch created inside `with torch.cuda.stream(s)` resets itself on the stream it is created on and is then
     re-bound to s: the first work on s must see the reset boards (stream-ordering race)."""

@@ -238,12 +238,24 @@ def test_connect_large_board_full_size(batch_mod):
 
 
 def test_unsupported_geometry_is_an_error(batch_mod):
+    """Beyond the bit-packed limits the generic kernels take over (tests/test_gpu_generic.py); beyond THEIR limits the
+    library refuses, loudly and before touching the GPU."""
+    assert batch_mod.ConnectBatch(16, 7, 4, 8).generic
+    assert batch_mod.ConnectBatch(15, 13, 4, 8).generic  # 208 bits per plane
+    assert batch_mod.BounceBatch(np.zeros((9, 8), dtype=np.int8), 8).generic  # 72 cells
+    assert not batch_mod.ConnectBatch(15, 12, 4, 8).generic
     with pytest.raises(ValueError):
-        batch_mod.ConnectBatch(16, 7, 4, 8)
+        batch_mod.ConnectBatch(65, 7, 4, 8)
     with pytest.raises(ValueError):
-        batch_mod.ConnectBatch(15, 13, 4, 8)  # 208 bits
+        batch_mod.ConnectBatch(6, 7, 0, 8)
     with pytest.raises(ValueError):
-        batch_mod.BounceBatch(np.zeros((9, 8), dtype=np.int8), 8)  # 72 cells
+        batch_mod.BounceBatch(np.zeros((33, 32), dtype=np.int8), 8)  # more than 1024 cells
+    with pytest.raises(ValueError):
+        batch_mod.BounceBatch(np.zeros((2, 6), dtype=np.int8), 8)   # no interior row
+    bad = np.zeros((9, 6), dtype=np.int8)
+    bad[0, 2] = 1
+    with pytest.raises(ValueError):
+        batch_mod.BounceBatch(bad, 8)  # piece in a goal row
 
 
 # ------------------------------------------------------------------------------------------------ Bounce

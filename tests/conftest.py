@@ -14,6 +14,11 @@ for p in (ROOT, PKG):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The oracle's OpenMP regions are tiny in most tests: on a 256-core GPU box a thread team of 256 costs ~0.1 s per call
+# (hundreds of calls per lock-step test).  A small team keeps the suite in minutes; an explicit setting wins.
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")

@@ -49,6 +49,7 @@ const ExpandTable g_expand;
 // 8 code bytes (32 games) -> 64 reward bytes per iteration with AVX2: every code byte is replicated to the four byte
 // positions of its games, the 2-bit field of each position is isolated in place, and "field == 1" / "field == 2"
 // compares (0 / -1 per byte) give r0 = is2 - is1 and r1 = is1 - is2, interleaved into (r0, r1) pairs.
+template <bool STREAM>
 __attribute__((target("avx2"))) int64_t expand_avx2(const uint8_t* src, int64_t code_bytes, int8_t* dst) {
     const __m256i spread = _mm256_setr_epi8(0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3,
                                             4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7);
@@ -64,13 +65,23 @@ __attribute__((target("avx2"))) int64_t expand_avx2(const uint8_t* src, int64_t 
         const __m256i is1 = _mm256_cmpeq_epi8(f, one), is2 = _mm256_cmpeq_epi8(f, two);
         const __m256i r0 = _mm256_sub_epi8(is2, is1), r1 = _mm256_sub_epi8(is1, is2);
         const __m256i lo = _mm256_unpacklo_epi8(r0, r1), hi = _mm256_unpackhi_epi8(r0, r1);
-        _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + 8 * i), _mm256_permute2x128_si256(lo, hi, 0x20));
-        _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + 8 * i + 32), _mm256_permute2x128_si256(lo, hi, 0x31));
+        const __m256i first = _mm256_permute2x128_si256(lo, hi, 0x20), second = _mm256_permute2x128_si256(lo, hi, 0x31);
+        if (STREAM) {
+            // non-temporal stores: the rewards are written once and read later by somebody else; skipping the
+            // read-for-ownership of every destination line doubles what a memory-bound expansion can deliver
+            _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + 8 * i), first);
+            _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + 8 * i + 32), second);
+        } else {
+            _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + 8 * i), first);
+            _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + 8 * i + 32), second);
+        }
     }
+    if (STREAM) _mm_sfence();
     return i;  // code bytes consumed
 }
 
 const bool g_have_avx2 = __builtin_cpu_supports("avx2");
+const bool g_stream_stores = getenv("BGS_NO_STREAM_STORES") == nullptr;
 
 void expand_range(const uint8_t* packed, int64_t first, int64_t count, int8_t* reward) {
     // whole code bytes: AVX2 where the CPU has it, the 256-entry table otherwise and for the last few bytes; a ragged
@@ -79,7 +90,11 @@ void expand_range(const uint8_t* packed, int64_t first, int64_t count, int8_t* r
     const uint8_t* src = packed + first / 4;
     int8_t* out = reward + 2 * first;
     int64_t i0 = 0;
-    if (g_have_avx2) i0 = expand_avx2(src, whole, out);
+    if (g_have_avx2) {
+        // streaming stores need a 32-byte aligned destination and pay off on large shares only
+        const bool stream = (reinterpret_cast<uintptr_t>(out) & 31u) == 0 && whole >= (1 << 14) && g_stream_stores;
+        i0 = stream ? expand_avx2<true>(src, whole, out) : expand_avx2<false>(src, whole, out);
+    }
     for (int64_t i = i0; i < whole; ++i) memcpy(out + 8 * i, &g_expand.pairs[src[i]], 8);
     for (int64_t g = first + whole * 4; g < first + count; ++g) {
         const uint16_t pair = bgs::reward_pair((uint32_t)(packed[g / 4] >> (2 * (g & 3))) & 3u);

@@ -141,7 +141,9 @@ def main() -> int:
                     "rollout, its copy to the host and (N > 1) its reward gather overlap the next rollouts (default 3)")
     ap.add_argument("--handover", choices=("codes", "pairs", "none"), default="codes",
                     help="how a step's rewards reach the host array (see the module docstring)")
-    ap.add_argument("--host-threads", type=int, default=3, help="worker threads of the reward sink (--handover codes)")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="worker threads of the reward sink (--handover codes); 0 = 3 on one GPU, min(12, 2 + 2 N) on N "
+                    "(rank 0 expands N x 2 MiB of rewards per step: tools/sink_rate.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-resident", action="store_true",
                     help="skip the extra, separately timed pass without hand-over that fills `device_resident`")
@@ -183,6 +185,8 @@ def main() -> int:
     from simulator.game import _abi
     from simulator.sharding import gather_outcomes_to, shard_range, sum_steps
 
+    if args.host_threads <= 0:
+        args.host_threads = 3 if world == 1 else min(12, 2 + 2 * world)
     n = args.batch
     if sharded and n % 4:
         print("bench.py: --batch must be a multiple of 4 when sharded (4 outcome codes per byte)", file=sys.stderr)

@@ -250,6 +250,8 @@ int device_facts(bgs_batch* b) {
     b->rollout_no_lds = getenv("BGS_ROLLOUT_NO_LDS") != nullptr;
     b->bounce_group = 8;
     if (const char* env = getenv("BGS_BOUNCE_GROUP")) b->bounce_group = atoi(env) == 1 ? 1 : 8;
+    b->bounce_flat = 1;
+    if (const char* env = getenv("BGS_BOUNCE_FLAT")) b->bounce_flat = atoi(env) != 0;
     // multi-pass Bounce rollout (bounce_kernels.hip, bounce_rollout): "cap:lanes,..."; the last entry's cap is the
     // caller's max_plies whatever it says; "single" = one launch that plays every game to the end
     {

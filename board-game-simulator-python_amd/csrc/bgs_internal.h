@@ -53,6 +53,7 @@ struct bgs_batch {
     int num_cus;             // compute units of the device
     int rollout_wps;         // waves per SIMD the fused rollout is sized for
     int bounce_group;        // lanes per board of a single-launch Bounce rollout: 8 (default) or 1 (BGS_BOUNCE_GROUP)
+    int bounce_flat;         // 1: one-lane-per-board Bounce rollouts use the flattened search (BGS_BOUNCE_FLAT=0: nested loops)
     int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board
     uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];
     int bounce_pass_group[BGS_BOUNCE_MAX_PASSES];

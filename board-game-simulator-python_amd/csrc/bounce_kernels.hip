@@ -445,6 +445,213 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
     add_steps(steps, stepped);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3f: the fused rollout, flattened.  One lane per board as in GL = 1 -- but the move search of a ply is not run as
+// nested loops (for every column: while cells are pending: for every step), whose trip counts differ from lane to
+// lane so that a wave executes the SUM over columns of the per-column maxima.  It is ONE loop per wave in which every
+// lane expands one cell of its own work queue per iteration -- the queue runs through the lane's sources one after
+// the other and through each source's pending bounce cells -- so a wave executes the maximum over its lanes of the
+// number of cells, and all lanes run the same instructions on different cells (measured before: 12.7 of 64 lanes
+// active per VALU instruction in lane-group mode, 8.4 with one lane per board).
+// Per-source target masks go to a per-lane dword column of LDS ([dword][lane]: the bank is the lane, dynamic indices
+// never conflict); per-source counts are packed 8 bits each (a source has at most 64 targets: 0..64 needs 7 bits).
+// ------------------------------------------------------------------------------------------------
+struct FlatMoves {
+    uint64_t counts;     // byte x = number of targets of the piece in column x of the active row
+    uint32_t n;          // number of actions
+    uint32_t row_base;   // cell index of column 0 of the active row
+};
+
+// the action list of `player` for the lanes with `want` set; the other lanes idle through the loop
+__device__ __forceinline__ void enumerate_flat(const BounceGeom& g, const Board& b, uint64_t occ, uint32_t player, bool want,
+                                               uint32_t* column, FlatMoves& m) {
+    const uint64_t empty_interior = ~occ & g.interior;
+    const uint64_t landing = empty_interior | (player ? g.goal_bottom : g.goal_top);
+    const uint64_t bounce_on = occ & g.interior;
+    const uint32_t up = player ? 0u : (uint32_t)g.w, down = player ? (uint32_t)g.w : 0u;
+    uint64_t rem = want ? movable(g, occ, player) : 0ull;   // sources still to search
+    const int first = rem ? __ffsll((unsigned long long)rem) - 1 : 0;
+    m.row_base = (uint32_t)((int)(((uint32_t)first * g.inv_w) >> 16) * g.w);
+    m.counts = 0;
+    m.n = 0;
+    uint64_t pending = 0, done = 0, targets = 0;
+    uint32_t x = 0;
+    bool open_source = false;  // a source is being searched and has not been booked yet
+    while (__builtin_amdgcn_ballot_w64(rem != 0 || pending != 0 || open_source)) {
+        if (pending == 0) {
+            if (open_source) {  // the source's closure is complete: book it
+                const uint32_t cnt = (uint32_t)__popcll(targets);
+                m.counts |= (uint64_t)cnt << (8u * x);
+                m.n += cnt;
+                column[(2u * x) * BGS_BLOCK] = (uint32_t)targets;
+                column[(2u * x + 1u) * BGS_BLOCK] = (uint32_t)(targets >> 32);
+                open_source = false;
+            }
+            if (rem) {  // next source
+                const int cell = __ffsll((unsigned long long)rem) - 1;
+                rem &= rem - 1;
+                x = (uint32_t)cell - m.row_base;
+                pending = 1ull << cell;
+                done = 0;
+                targets = 0;
+                open_source = true;
+            }
+        }
+        if (pending) {  // expand one cell: a segment of value(cell) steps
+            const int c = __ffsll((unsigned long long)pending) - 1;
+            pending &= pending - 1;
+            done |= 1ull << c;
+            const uint32_t v = value_at(b, c);
+            uint64_t a0 = 1ull << c, al = 0, ar = 0, land = 0;
+            for (uint32_t s = 1; s <= v; ++s) {
+                const uint64_t via_left = a0 | al, via_right = a0 | ar;
+                const uint64_t nf = ((via_left | ar) << up) >> down;
+                const uint64_t nl = (via_left & g.not_col0) >> 1;
+                const uint64_t nr = (via_right & g.not_collast) << 1;
+                if (s < v) {
+                    a0 = nf & empty_interior;
+                    al = nl & empty_interior;
+                    ar = nr & empty_interior;
+                    if (!(a0 | al | ar)) break;
+                } else {
+                    land = nf | nl | nr;
+                }
+            }
+            targets |= land & landing;
+            pending |= land & bounce_on & ~done;
+        }
+    }
+}
+
+// the idx-th action of the canonical list from the packed counts and the LDS column
+__device__ __forceinline__ void pick_flat(const FlatMoves& m, const uint32_t* column, uint32_t idx, int& src_cell, int& dst_cell) {
+    uint32_t col = 0;
+    bool found = false;
+#pragma unroll
+    for (int x = 0; x < kMaxTrackedColumns; ++x) {
+        const uint32_t cnt = (uint32_t)(m.counts >> (8 * x)) & 255u;
+        const bool here = !found && idx < cnt;
+        col = here ? (uint32_t)x : col;
+        idx = (found || here) ? idx : idx - cnt;
+        found = found || here;
+    }
+    const uint64_t chosen = ((uint64_t)column[(2u * col + 1u) * BGS_BLOCK] << 32) | column[(2u * col) * BGS_BLOCK];
+    src_cell = (int)(m.row_base + col);
+    dst_cell = (int)select_bit64(chosen, idx);
+}
+
+template <bool FROM_INITIAL>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+                      uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
+                      unsigned long long* __restrict__ steps, uint32_t games_per_wave, const uint32_t* __restrict__ worklist,
+                      const uint32_t* __restrict__ work_count) {
+    extern __shared__ uint32_t target_tile[];             // [2 * kMaxTrackedColumns dwords][256 lanes]
+    uint32_t* const column = target_tile + threadIdx.x;   // this lane's dword column
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
+    const int64_t total = worklist ? (int64_t)*work_count : n;
+    const int64_t begin = (int64_t)wave * games_per_wave;
+    const int64_t end = begin + games_per_wave < total ? begin + games_per_wave : total;
+    const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
+    if (avail == 0u) return;
+    uint32_t taken = 0;
+
+    Board b;
+    b.v[0] = b.v[1] = b.v[2] = b.v[3] = 0;
+    FlatMoves mv;
+    mv.counts = 0;
+    mv.n = 0;
+    mv.row_base = 0;
+    uint32_t st = 0, plies = 0, first_ply = 0, game = 0, stepped = 0;
+    bool has = false;      // this lane holds a board
+    bool dirty = false;    // ... that differs from what memory holds
+    bool search = false;   // ... whose side to move has no action list yet
+    Philox4 blk;
+    blk.v[0] = blk.v[1] = blk.v[2] = blk.v[3] = 0;
+    bool have_block = false;
+
+    for (;;) {
+        // ---- refill: free lanes take the next boards of the chunk
+        const uint64_t need = __builtin_amdgcn_ballot_w64(!has);
+        if (need && taken < avail) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (!has && taken + rank < avail) {
+                game = worklist ? worklist[begin + taken + rank] : (uint32_t)(begin + taken + rank);
+                const int64_t i = game;
+                if (FROM_INITIAL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b.v[j] = g.init[j];
+                    st = g.init_status;
+                    plies = 0;
+                } else {
+                    b = load_board(planes, n, i);
+                    st = status[i];
+                    plies = plies_buf[i];
+                }
+                first_ply = plies;
+                has = true;
+                dirty = FROM_INITIAL;
+                have_block = false;
+                search = st == BGS_ST_RUNNING;
+            }
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            taken = avail - taken < wanted ? avail : taken + wanted;
+        }
+
+        // ---- the action lists of the boards that need one (new boards, boards that have just moved); a board whose
+        // side to move has no action is settled here, also at the ply cap (the transition that blocked it counts)
+        if (__builtin_amdgcn_ballot_w64(search)) {
+            const uint64_t occ = occupancy(b);
+            enumerate_flat(g, b, occ, plies & 1u, search, column, mv);
+            const bool blocked = search && mv.n == 0u;
+            if (__builtin_amdgcn_ballot_w64(blocked)) {
+                // the other side wins if IT could move, else a draw (Appendix B rule 7; a loaded or start position
+                // without moves is settled the same way)
+                FlatMoves other;
+                enumerate_flat(g, b, occ, 1u - (plies & 1u), blocked, column, other);
+                if (blocked) {
+                    st = other.n ? (1u - (plies & 1u)) + 1u : BGS_ST_DRAW;
+                    dirty = true;
+                }
+            }
+            search = false;
+        }
+        const bool run = has && st == BGS_ST_RUNNING && plies < max_plies;
+
+        // ---- boards that stopped go to memory and free their lane
+        if (has && !run) {
+            if (dirty) {
+                const int64_t i = game;
+                store_board(planes, n, i, b);
+                status[i] = (uint8_t)st;
+                plies_buf[i] = (uint16_t)plies;
+                reward[i] = reward_pair(st);
+                stepped += plies - first_ply;
+            }
+            has = false;
+            dirty = false;
+        }
+        if (!__builtin_amdgcn_ballot_w64(has) && taken >= avail) break;
+
+        // ---- one ply on every running board
+        if (run) {
+            if (!have_block || (plies & 3u) == 0u) {
+                blk = philox4x32_10(seed, first_game + (uint64_t)game, plies >> 2);
+                have_block = true;
+            }
+            const uint32_t mover = plies & 1u;
+            int s, t;
+            pick_flat(mv, column, sample_index(philox_word(blk, plies), mv.n), s, t);
+            move_piece(b, s, t);
+            ++plies;
+            dirty = true;
+            if ((1ull << t) & (g.goal_top | g.goal_bottom)) st = mover + 1u;  // (stored and freed next iteration)
+            else search = true;
+        }
+    }
+    add_steps(steps, stepped);
+}
+
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_step_actions(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
                       uint16_t* __restrict__ plies_buf, uint16_t* __restrict__ reward, int64_t n,
@@ -634,8 +841,16 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
                            b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap,
                            b->d_steps, (uint32_t)per_wave, worklist, work_count);
     };
+    auto launch_flat = [&](auto initial_tag) {
+        constexpr bool INITIAL = decltype(initial_tag)::value;
+        const size_t tile = (size_t)2 * kMaxTrackedColumns * BGS_BLOCK * sizeof(uint32_t);
+        hipLaunchKernelGGL((k_bounce_rollout_flat<INITIAL>), dim3(blocks), dim3(BGS_BLOCK), tile, b->stream, b->bg, b->d_planes,
+                           b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap,
+                           b->d_steps, (uint32_t)per_wave, worklist, work_count);
+    };
     auto with_group = [&](auto initial_tag) {
-        if (group == 1) launch(initial_tag, std::integral_constant<int, 1>{});
+        if (group == 1 && b->bounce_flat) launch_flat(initial_tag);   // one lane per board, flattened search
+        else if (group == 1) launch(initial_tag, std::integral_constant<int, 1>{});
         else launch(initial_tag, std::integral_constant<int, 8>{});
     };
     if (from_initial) with_group(std::true_type{});

@@ -57,7 +57,7 @@ Layout layout_for(int planes, int64_t n, int h, int w, size_t legal_bytes = 0) {
     l.reward = off; off += align_up((size_t)n * 2);
     l.steps = off; off += align_up(kStepBytes);
     l.worklist = off; off += align_up((size_t)n * 4);
-    l.work_count = off; off += align_up(sizeof(uint32_t) * BGS_BOUNCE_MAX_PASSES);
+    l.work_count = off; off += align_up(sizeof(uint32_t) * 2 * BGS_BOUNCE_MAX_PASSES);
     l.gen_masks = off; off += align_up(sizeof(uint64_t) * 4 * (BGS_GENERIC_BOUNCE_MAX_CELLS / 64));
     l.gen_cfg = off; off += align_up((size_t)h * w);
     size_t per_board = (size_t)h * w;
@@ -252,6 +252,16 @@ int device_facts(bgs_batch* b) {
     if (const char* env = getenv("BGS_BOUNCE_GROUP")) b->bounce_group = atoi(env) == 1 ? 1 : 8;
     b->bounce_flat = 1;
     if (const char* env = getenv("BGS_BOUNCE_FLAT")) b->bounce_flat = atoi(env) != 0;
+    b->bounce_flat_chunk = 32;
+    if (const char* env = getenv("BGS_BOUNCE_CHUNK")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 4096) b->bounce_flat_chunk = v;
+    }
+    b->bounce_flat_wps = 2;
+    if (const char* env = getenv("BGS_BOUNCE_FLAT_WPS")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 8) b->bounce_flat_wps = v;
+    }
     // multi-pass Bounce rollout (bounce_kernels.hip, bounce_rollout): "cap:lanes,..."; the last entry's cap is the
     // caller's max_plies whatever it says; "single" = one launch that plays every game to the end
     {

@@ -54,6 +54,8 @@ struct bgs_batch {
     int rollout_wps;         // waves per SIMD the fused rollout is sized for
     int bounce_group;        // lanes per board of a single-launch Bounce rollout: 8 (default) or 1 (BGS_BOUNCE_GROUP)
     int bounce_flat;         // 1: one-lane-per-board Bounce rollouts use the flattened search (BGS_BOUNCE_FLAT=0: nested loops)
+    int bounce_flat_wps;     // waves per SIMD of a flat Bounce rollout launch (BGS_BOUNCE_FLAT_WPS)
+    int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (BGS_BOUNCE_CHUNK)
     int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board
     uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];
     int bounce_pass_group[BGS_BOUNCE_MAX_PASSES];
@@ -73,7 +75,7 @@ struct bgs_batch {
     uint64_t* d_gen_masks;   // generic Bounce: [4][16] cell masks (all, interior, x > 0, x < w - 1)
     int8_t* d_gen_cfg;       // generic Bounce: the configured start grid
     uint32_t* d_worklist;    // [n] board indices still to play (Bounce multi-pass rollout)
-    uint32_t* d_work_count;  // [BGS_BOUNCE_MAX_PASSES] list lengths, device-resident
+    uint32_t* d_work_count;  // [2 * BGS_BOUNCE_MAX_PASSES] list lengths, then work-queue heads; device-resident
     // pinned bounce buffers for large device -> host copies (allocated on first use)
     void* pinned[2];
     hipEvent_t pinned_done[2];

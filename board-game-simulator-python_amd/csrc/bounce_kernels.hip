@@ -544,17 +544,17 @@ template <bool FROM_INITIAL>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                       uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
-                      unsigned long long* __restrict__ steps, uint32_t games_per_wave, const uint32_t* __restrict__ worklist,
-                      const uint32_t* __restrict__ work_count) {
+                      unsigned long long* __restrict__ steps, uint32_t chunk, const uint32_t* __restrict__ worklist,
+                      const uint32_t* __restrict__ work_count, uint32_t* __restrict__ queue) {
     extern __shared__ uint32_t target_tile[];             // [2 * kMaxTrackedColumns dwords][256 lanes]
     uint32_t* const column = target_tile + threadIdx.x;   // this lane's dword column
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
-    const int64_t total = worklist ? (int64_t)*work_count : n;
-    const int64_t begin = (int64_t)wave * games_per_wave;
-    const int64_t end = begin + games_per_wave < total ? begin + games_per_wave : total;
-    const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
-    if (avail == 0u) return;
-    uint32_t taken = 0;
+    const uint32_t total = worklist ? *work_count : (uint32_t)n;
+    // Work is handed out dynamically: a wave draws chunks of `chunk` boards from a device-wide counter (zeroed before
+    // the launch) whenever its lanes run out.  Game lengths are heavy-tailed, so with static chunks a wave lives as
+    // long as its unluckiest lane while the others idle; with the shared queue every lane is refilled until the
+    // whole batch is handed out, and a wave that holds a long game simply stops drawing.
+    uint32_t begin = 0, avail = 0, taken = 0;   // the wave's current chunk: boards begin + [taken, avail)
+    bool dry = false;                             // the queue has nothing left
 
     Board b;
     b.v[0] = b.v[1] = b.v[2] = b.v[3] = 0;
@@ -571,12 +571,20 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
     bool have_block = false;
 
     for (;;) {
-        // ---- refill: free lanes take the next boards of the chunk
+        // ---- refill: free lanes take the next boards of the wave's chunk; an empty chunk is replaced from the queue
         const uint64_t need = __builtin_amdgcn_ballot_w64(!has);
+        if (need && taken >= avail && !dry) {
+            uint32_t next = 0;
+            if ((threadIdx.x & 63u) == 0u) next = atomicAdd(queue, chunk);
+            begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+            taken = 0;
+            avail = begin < total ? (total - begin < chunk ? total - begin : chunk) : 0u;
+            dry = avail == 0u;
+        }
         if (need && taken < avail) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (!has && taken + rank < avail) {
-                game = worklist ? worklist[begin + taken + rank] : (uint32_t)(begin + taken + rank);
+                game = worklist ? worklist[begin + taken + rank] : begin + taken + rank;
                 const int64_t i = game;
                 if (FROM_INITIAL) {
 #pragma unroll
@@ -631,7 +639,7 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             has = false;
             dirty = false;
         }
-        if (!__builtin_amdgcn_ballot_w64(has) && taken >= avail) break;
+        if (!__builtin_amdgcn_ballot_w64(has) && taken >= avail && dry) break;
 
         // ---- one ply on every running board
         if (run) {
@@ -819,7 +827,7 @@ void bounce_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
 // One launch of the fused rollout: over the whole batch (worklist == nullptr) or over a work list.
 // group = lanes per board (1 or 8), wps = waves per SIMD the grid is sized for.
 static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool from_initial, int group, int wps,
-                           const uint32_t* worklist, const uint32_t* work_count) {
+                           const uint32_t* worklist, const uint32_t* work_count, uint32_t* queue) {
     const int64_t slots_per_wave = BGS_WAVE / group;
     int64_t per_wave, waves;
     if (worklist) {
@@ -844,9 +852,15 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
     auto launch_flat = [&](auto initial_tag) {
         constexpr bool INITIAL = decltype(initial_tag)::value;
         const size_t tile = (size_t)2 * kMaxTrackedColumns * BGS_BLOCK * sizeof(uint32_t);
-        hipLaunchKernelGGL((k_bounce_rollout_flat<INITIAL>), dim3(blocks), dim3(BGS_BLOCK), tile, b->stream, b->bg, b->d_planes,
-                           b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap,
-                           b->d_steps, (uint32_t)per_wave, worklist, work_count);
+        // a grid that fills the chip (flat_wps waves per SIMD, never more waves than 64-board chunks); every wave
+        // draws its boards from the shared queue
+        const uint32_t chunk = (uint32_t)b->bounce_flat_chunk;
+        int64_t flat_waves = (int64_t)b->num_cus * 4 * b->bounce_flat_wps;
+        const int64_t most = (b->n + 255) / 256;  // a wave should see several refills' worth of boards
+        if (flat_waves > most) flat_waves = most;
+        hipLaunchKernelGGL((k_bounce_rollout_flat<INITIAL>), dim3((unsigned)((flat_waves + 3) / 4)), dim3(BGS_BLOCK), tile,
+                           b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
+                           seed, b->first_game, cap, b->d_steps, chunk, worklist, work_count, queue);
     };
     auto with_group = [&](auto initial_tag) {
         if (group == 1 && b->bounce_flat) launch_flat(initial_tag);   // one lane per board, flattened search
@@ -871,24 +885,27 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
     if (cap > kMaxPlies) cap = kMaxPlies;  // plies are stored as uint16
     const bool from_initial = (flags & 1u) != 0u;
     if (b->bg.w <= kMaxTrackedColumns && !b->rollout_generic) {
-        if (b->bounce_passes <= 1) {  // single launch (BGS_BOUNCE_PLAN=single, or a plan with one entry)
-            launch_rollout(b, seed, cap, from_initial, b->bounce_group, b->bounce_group == 1 ? b->rollout_wps : 8, nullptr, nullptr);
-            return;
-        }
+        // [0, MAX_PASSES): list lengths; [MAX_PASSES, 2 * MAX_PASSES): the passes' work queues (flat kernel)
         uint32_t* list = b->d_worklist;
         uint32_t* counts = b->d_work_count;
-        (void)hipMemsetAsync(counts, 0, sizeof(uint32_t) * BGS_BOUNCE_MAX_PASSES, b->stream);
+        uint32_t* queues = b->d_work_count + BGS_BOUNCE_MAX_PASSES;
+        (void)hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * BGS_BOUNCE_MAX_PASSES, b->stream);
+        if (b->bounce_passes <= 1) {  // single launch (BGS_BOUNCE_PLAN=single, or a plan with one entry)
+            launch_rollout(b, seed, cap, from_initial, b->bounce_group, b->bounce_group == 1 ? b->rollout_wps : 8, nullptr, nullptr,
+                           queues);
+            return;
+        }
         for (int pass = 0; pass < b->bounce_passes; ++pass) {
             const bool last = pass + 1 == b->bounce_passes;
             const uint32_t pass_cap = (last || b->bounce_pass_cap[pass] > cap) ? cap : b->bounce_pass_cap[pass];
             const int group = b->bounce_pass_group[pass];
             if (pass == 0) {
-                launch_rollout(b, seed, pass_cap, from_initial, group, group == 1 ? b->rollout_wps : 8, nullptr, nullptr);
+                launch_rollout(b, seed, pass_cap, from_initial, group, group == 1 ? b->rollout_wps : 8, nullptr, nullptr, queues);
             } else {
                 // boards still running below the final cap after the previous pass -> this pass's list
                 hipLaunchKernelGGL(k_bounce_compact, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->d_status, b->d_plies,
                                    b->n, cap, list, counts + pass);
-                launch_rollout(b, seed, pass_cap, false, group, 0, list, counts + pass);
+                launch_rollout(b, seed, pass_cap, false, group, 0, list, counts + pass, queues + pass);
             }
             if (pass_cap >= cap) break;  // nothing can be left for a later pass
         }

@@ -856,7 +856,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         // draws its boards from the shared queue
         const uint32_t chunk = (uint32_t)b->bounce_flat_chunk;
         int64_t flat_waves = (int64_t)b->num_cus * 4 * b->bounce_flat_wps;
-        const int64_t most = (b->n + 255) / 256;  // a wave should see several refills' worth of boards
+        const int64_t most = (b->n + 63) / 64;    // (never more waves than 64-board loads)
         if (flat_waves > most) flat_waves = most;
         hipLaunchKernelGGL((k_bounce_rollout_flat<INITIAL>), dim3((unsigned)((flat_waves + 3) / 4)), dim3(BGS_BLOCK), tile,
                            b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,

@@ -237,6 +237,49 @@ def test_connect_large_board_full_size(batch_mod):
     np.testing.assert_array_equal(dev.plies, orc.plies)
 
 
+@pytest.mark.parametrize("mode", ["1", "8", "1:nested", "passes"])
+def test_bounce_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
+    """Every fused Bounce rollout kernel on the same mid-size batch: one lane per board with the flattened search and
+    the work queue (default for large batches), 8 lanes per board (default for small ones), the nested-loop kernel and
+    the multi-pass plan (flat passes, then a lane-group pass over the compacted work list)."""
+    import os
+
+    env = {"1": {"BGS_BOUNCE_GROUP": "1"}, "8": {"BGS_BOUNCE_GROUP": "8"},
+           "1:nested": {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_FLAT": "0"},
+           "passes": {"BGS_BOUNCE_PLAN": "16:1,64:1,0:8", "BGS_BOUNCE_CHUNK": "8"}}[mode]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        n = 9000
+        dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+        orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+        dev.set_first_game(31)
+        dev.rollout(SEED ^ 4, max_plies=700, from_initial=True)
+        total = orc.rollout(SEED ^ 4, first_game=31, max_plies=700)
+        assert_same(dev, orc, f"mode {mode}, from the initial state")
+        assert dev.steps == total
+        dev.reset()
+        orc.reset()
+        dev.reset_steps()
+        dev.step_random(SEED ^ 5, plies=3)
+        for _ in range(3):
+            orc.step_random(SEED ^ 5, first_game=31)
+        dev.rollout(SEED ^ 5, max_plies=40)
+        orc.rollout(SEED ^ 5, first_game=31, max_plies=40)
+        assert_same(dev, orc, f"mode {mode}, resumed and capped")
+        dev.rollout(SEED ^ 5, max_plies=2000)
+        orc.rollout(SEED ^ 5, first_game=31, max_plies=2000)
+        assert_same(dev, orc, f"mode {mode}, finished")
+        assert dev.steps == int(orc.plies.sum())
+        dev.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
 def test_unsupported_geometry_is_an_error(batch_mod):
     """Beyond the bit-packed limits the generic kernels take over (tests/test_gpu_generic.py); beyond THEIR limits the
     library refuses, loudly and before touching the GPU."""

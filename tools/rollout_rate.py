@@ -5,6 +5,12 @@ flight on D streams (throughput), env-steps counted on the device.
     python tools/rollout_rate.py connect6x7 | connect12x13 | bounce  [--depth D] [--reps R] [--batch N]
 Prints one JSON object."""
 import argparse, json, os, sys, time
+_depth = 3
+if "--depth" in sys.argv:
+    _depth = int(sys.argv[sys.argv.index("--depth") + 1])
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): more batches in
+# flight than queues do not overlap.  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(_depth, 16))))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
 import numpy as np
@@ -52,5 +58,5 @@ for b in batches:
 torch.cuda.synchronize()
 out = {"config": args.config, "batch": batches[0].n, "one_launch_at_a_time": run(1, max(4, args.reps // 3)),
        f"{args.depth}_in_flight": run(args.depth, args.reps),
-       "env": {k: v for k, v in os.environ.items() if k.startswith("BGS_")}}
+       "env": {k: v for k, v in os.environ.items() if k.startswith("BGS_") or k == "GPU_MAX_HW_QUEUES"}}
 print(json.dumps(out))

@@ -142,7 +142,7 @@ def main() -> int:
     ap.add_argument("--handover", choices=("codes", "pairs", "none"), default="codes",
                     help="how a step's rewards reach the host array (see the module docstring)")
     ap.add_argument("--host-threads", type=int, default=0,
-                    help="worker threads of the reward sink (--handover codes); 0 = 3 on one GPU, min(12, 2 + 2 N) on N "
+                    help="worker threads of the reward sink (--handover codes); 0 = 6 on one GPU, min(12, 4 + 2 N) on N "
                     "(rank 0 expands N x 2 MiB of rewards per step: tools/sink_rate.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-resident", action="store_true",
@@ -186,7 +186,7 @@ def main() -> int:
     from simulator.sharding import gather_outcomes_to, shard_range, sum_steps
 
     if args.host_threads <= 0:
-        args.host_threads = 3 if world == 1 else min(12, 2 + 2 * world)
+        args.host_threads = 6 if world == 1 else min(12, 4 + 2 * world)
     n = args.batch
     if sharded and n % 4:
         print("bench.py: --batch must be a multiple of 4 when sharded (4 outcome codes per byte)", file=sys.stderr)

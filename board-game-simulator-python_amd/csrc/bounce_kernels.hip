@@ -448,18 +448,80 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
 // ------------------------------------------------------------------------------------------------
 // K3f: the fused rollout, flattened.  One lane per board as in GL = 1 -- but the move search of a ply is not run as
 // nested loops (for every column: while cells are pending: for every step), whose trip counts differ from lane to
-// lane so that a wave executes the SUM over columns of the per-column maxima (measured: 12.7 of 64 lanes active per
-// VALU instruction in lane-group mode, 8.4 with one lane per board).  The search is cut into uniform STEPS -- "expand
-// one cell of the lane's own work queue" (the queue runs through the lane's sources one after the other and through
-// each source's pending bounce cells) -- and all lanes run the same step on different cells.
+// lane so that a wave executes the SUM over columns of the per-column maxima.  It is ONE loop per wave in which every
+// lane expands one cell of its own work queue per iteration -- the queue runs through the lane's sources one after
+// the other and through each source's pending bounce cells -- so a wave executes the maximum over its lanes of the
+// number of cells, and all lanes run the same instructions on different cells (measured before: 12.7 of 64 lanes
+// active per VALU instruction in lane-group mode, 8.4 with one lane per board).
 // Per-source target masks go to a per-lane dword column of LDS ([dword][lane]: the bank is the lane, dynamic indices
-// never conflict); per-source counts are packed 8 bits each (a source has at most 64 targets).
+// never conflict); per-source counts are packed 8 bits each (a source has at most 64 targets: 0..64 needs 7 bits).
 // ------------------------------------------------------------------------------------------------
 struct FlatMoves {
     uint64_t counts;     // byte x = number of targets of the piece in column x of the active row
     uint32_t n;          // number of actions
     uint32_t row_base;   // cell index of column 0 of the active row
 };
+
+// the action list of `player` for the lanes with `want` set; the other lanes idle through the loop
+__device__ __forceinline__ void enumerate_flat(const BounceGeom& g, const Board& b, uint64_t occ, uint32_t player, bool want,
+                                               uint32_t* column, FlatMoves& m) {
+    const uint64_t empty_interior = ~occ & g.interior;
+    const uint64_t landing = empty_interior | (player ? g.goal_bottom : g.goal_top);
+    const uint64_t bounce_on = occ & g.interior;
+    const uint32_t up = player ? 0u : (uint32_t)g.w, down = player ? (uint32_t)g.w : 0u;
+    uint64_t rem = want ? movable(g, occ, player) : 0ull;   // sources still to search
+    const int first = rem ? __ffsll((unsigned long long)rem) - 1 : 0;
+    m.row_base = (uint32_t)((int)(((uint32_t)first * g.inv_w) >> 16) * g.w);
+    m.counts = 0;
+    m.n = 0;
+    uint64_t pending = 0, done = 0, targets = 0;
+    uint32_t x = 0;
+    bool open_source = false;  // a source is being searched and has not been booked yet
+    while (__builtin_amdgcn_ballot_w64(rem != 0 || pending != 0 || open_source)) {
+        if (pending == 0) {
+            if (open_source) {  // the source's closure is complete: book it
+                const uint32_t cnt = (uint32_t)__popcll(targets);
+                m.counts |= (uint64_t)cnt << (8u * x);
+                m.n += cnt;
+                column[(2u * x) * BGS_BLOCK] = (uint32_t)targets;
+                column[(2u * x + 1u) * BGS_BLOCK] = (uint32_t)(targets >> 32);
+                open_source = false;
+            }
+            if (rem) {  // next source
+                const int cell = __ffsll((unsigned long long)rem) - 1;
+                rem &= rem - 1;
+                x = (uint32_t)cell - m.row_base;
+                pending = 1ull << cell;
+                done = 0;
+                targets = 0;
+                open_source = true;
+            }
+        }
+        if (pending) {  // expand one cell: a segment of value(cell) steps
+            const int c = __ffsll((unsigned long long)pending) - 1;
+            pending &= pending - 1;
+            done |= 1ull << c;
+            const uint32_t v = value_at(b, c);
+            uint64_t a0 = 1ull << c, al = 0, ar = 0, land = 0;
+            for (uint32_t s = 1; s <= v; ++s) {
+                const uint64_t via_left = a0 | al, via_right = a0 | ar;
+                const uint64_t nf = ((via_left | ar) << up) >> down;
+                const uint64_t nl = (via_left & g.not_col0) >> 1;
+                const uint64_t nr = (via_right & g.not_collast) << 1;
+                if (s < v) {
+                    a0 = nf & empty_interior;
+                    al = nl & empty_interior;
+                    ar = nr & empty_interior;
+                    if (!(a0 | al | ar)) break;
+                } else {
+                    land = nf | nl | nr;
+                }
+            }
+            targets |= land & landing;
+            pending |= land & bounce_on & ~done;
+        }
+    }
+}
 
 // the idx-th action of the canonical list from the packed counts and the LDS column
 __device__ __forceinline__ void pick_flat(const FlatMoves& m, const uint32_t* column, uint32_t idx, int& src_cell, int& dst_cell) {
@@ -476,88 +538,6 @@ __device__ __forceinline__ void pick_flat(const FlatMoves& m, const uint32_t* co
     const uint64_t chosen = ((uint64_t)column[(2u * col + 1u) * BGS_BLOCK] << 32) | column[(2u * col) * BGS_BLOCK];
     src_cell = (int)(m.row_base + col);
     dst_cell = (int)select_bit64(chosen, idx);
-}
-
-// The rollout kernel around it does not keep its lanes in step at the PLY level either: a lane is a small state machine
-//   SEARCH (expanding the cells of its action list, one per wave iteration) -> READY (list complete: pick a move, play
-//   it, or stop) -> SEARCH for the other side ...
-// and every wave iteration runs one search step on the lanes that are searching and one move on the lanes that are
-// ready.  A wave therefore spends the MEAN number of search steps per ply, not the maximum over its 64 boards, and a
-// lane with a large action list delays nobody.  Results cannot depend on the interleaving: every board's RNG stream is
-// keyed by its game id and ply.
-enum : uint32_t { kIdle = 0, kSearch = 1, kSearchOther = 2, kReady = 3 };
-
-struct Search {
-    uint64_t rem, pending, done, targets;   // sources left, cells queued / expanded, targets of the open source
-    uint64_t empty_interior, landing, bounce_on;
-    uint32_t x, side;
-    bool open_source;
-};
-
-__device__ __forceinline__ void begin_search(const BounceGeom& g, const Board& b, uint32_t side, Search& q, FlatMoves& m) {
-    const uint64_t occ = occupancy(b);
-    q.empty_interior = ~occ & g.interior;
-    q.landing = q.empty_interior | (side ? g.goal_bottom : g.goal_top);
-    q.bounce_on = occ & g.interior;
-    q.rem = movable(g, occ, side);
-    const int first = q.rem ? __ffsll((unsigned long long)q.rem) - 1 : 0;
-    m.row_base = (uint32_t)((int)(((uint32_t)first * g.inv_w) >> 16) * g.w);
-    m.counts = 0;
-    m.n = 0;
-    q.pending = 0;
-    q.done = 0;
-    q.targets = 0;
-    q.x = 0;
-    q.side = side;
-    q.open_source = false;
-}
-
-// one step: book a finished source, open the next one, expand one cell; returns true when the list is complete
-__device__ __forceinline__ bool search_step(const BounceGeom& g, const Board& b, Search& q, FlatMoves& m, uint32_t* column) {
-    if (q.pending == 0) {
-        if (q.open_source) {
-            const uint32_t cnt = (uint32_t)__popcll(q.targets);
-            m.counts |= (uint64_t)cnt << (8u * q.x);
-            m.n += cnt;
-            column[(2u * q.x) * BGS_BLOCK] = (uint32_t)q.targets;
-            column[(2u * q.x + 1u) * BGS_BLOCK] = (uint32_t)(q.targets >> 32);
-            q.open_source = false;
-        }
-        if (q.rem) {
-            const int cell = __ffsll((unsigned long long)q.rem) - 1;
-            q.rem &= q.rem - 1;
-            q.x = (uint32_t)cell - m.row_base;
-            q.pending = 1ull << cell;
-            q.done = 0;
-            q.targets = 0;
-            q.open_source = true;
-        }
-    }
-    if (q.pending) {
-        const uint32_t up = q.side ? 0u : (uint32_t)g.w, down = q.side ? (uint32_t)g.w : 0u;
-        const int c = __ffsll((unsigned long long)q.pending) - 1;
-        q.pending &= q.pending - 1;
-        q.done |= 1ull << c;
-        const uint32_t v = value_at(b, c);
-        uint64_t a0 = 1ull << c, al = 0, ar = 0, land = 0;
-        for (uint32_t s = 1; s <= v; ++s) {
-            const uint64_t via_left = a0 | al, via_right = a0 | ar;
-            const uint64_t nf = ((via_left | ar) << up) >> down;
-            const uint64_t nl = (via_left & g.not_col0) >> 1;
-            const uint64_t nr = (via_right & g.not_collast) << 1;
-            if (s < v) {
-                a0 = nf & q.empty_interior;
-                al = nl & q.empty_interior;
-                ar = nr & q.empty_interior;
-                if (!(a0 | al | ar)) break;
-            } else {
-                land = nf | nl | nr;
-            }
-        }
-        q.targets |= land & q.landing;
-        q.pending |= land & q.bounce_on & ~q.done;
-    }
-    return q.rem == 0 && q.pending == 0 && !q.open_source;
 }
 
 template <bool FROM_INITIAL>
@@ -582,20 +562,17 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
     mv.counts = 0;
     mv.n = 0;
     mv.row_base = 0;
-    Search q;
-    q.rem = q.pending = q.done = q.targets = q.empty_interior = q.landing = q.bounce_on = 0;
-    q.x = q.side = 0;
-    q.open_source = false;
-    uint32_t phase = kIdle;
     uint32_t st = 0, plies = 0, first_ply = 0, game = 0, stepped = 0;
-    bool dirty = false;    // the board differs from what memory holds
+    bool has = false;      // this lane holds a board
+    bool dirty = false;    // ... that differs from what memory holds
+    bool search = false;   // ... whose side to move has no action list yet
     Philox4 blk;
     blk.v[0] = blk.v[1] = blk.v[2] = blk.v[3] = 0;
     bool have_block = false;
 
     for (;;) {
-        // ---- refill: idle lanes take the next boards of the wave's chunk; an empty chunk is replaced from the queue
-        const uint64_t need = __builtin_amdgcn_ballot_w64(phase == kIdle);
+        // ---- refill: free lanes take the next boards of the wave's chunk; an empty chunk is replaced from the queue
+        const uint64_t need = __builtin_amdgcn_ballot_w64(!has);
         if (need && taken >= avail && !dry) {
             uint32_t next = 0;
             if ((threadIdx.x & 63u) == 0u) next = atomicAdd(queue, chunk);
@@ -606,7 +583,7 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
         }
         if (need && taken < avail) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            if (phase == kIdle && taken + rank < avail) {
+            if (!has && taken + rank < avail) {
                 game = worklist ? worklist[begin + taken + rank] : begin + taken + rank;
                 const int64_t i = game;
                 if (FROM_INITIAL) {
@@ -620,73 +597,64 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
                     plies = plies_buf[i];
                 }
                 first_ply = plies;
+                has = true;
                 dirty = FROM_INITIAL;
                 have_block = false;
-                if (st == BGS_ST_RUNNING) {
-                    begin_search(g, b, plies & 1u, q, mv);
-                    phase = kSearch;
-                } else {
-                    phase = kReady;  // (nothing to play: the move stage below stores it if need be and frees the lane)
-                }
+                search = st == BGS_ST_RUNNING;
             }
             const uint32_t wanted = (uint32_t)__popcll(need);
             taken = avail - taken < wanted ? avail : taken + wanted;
         }
-        if (!__builtin_amdgcn_ballot_w64(phase != kIdle)) {
-            if (taken >= avail && dry) break;
-            continue;
-        }
 
-        // ---- search stage: one step on every lane that is building an action list
-        if (phase == kSearch || phase == kSearchOther) {
-            if (search_step(g, b, q, mv, column)) {
-                if (phase == kSearch) {
-                    if (mv.n != 0u) {
-                        phase = kReady;
-                    } else {
-                        // nobody to move for the side to move: the other side wins if IT could move, else a draw
-                        // (Appendix B rule 7; a loaded or start position without moves is settled the same way)
-                        begin_search(g, b, 1u - (plies & 1u), q, mv);
-                        phase = kSearchOther;
-                    }
-                } else {
-                    st = mv.n ? (1u - (plies & 1u)) + 1u : BGS_ST_DRAW;
-                    mv.n = 0;
+        // ---- the action lists of the boards that need one (new boards, boards that have just moved); a board whose
+        // side to move has no action is settled here, also at the ply cap (the transition that blocked it counts)
+        if (__builtin_amdgcn_ballot_w64(search)) {
+            const uint64_t occ = occupancy(b);
+            enumerate_flat(g, b, occ, plies & 1u, search, column, mv);
+            const bool blocked = search && mv.n == 0u;
+            if (__builtin_amdgcn_ballot_w64(blocked)) {
+                // the other side wins if IT could move, else a draw (Appendix B rule 7; a loaded or start position
+                // without moves is settled the same way)
+                FlatMoves other;
+                enumerate_flat(g, b, occ, 1u - (plies & 1u), blocked, column, other);
+                if (blocked) {
+                    st = other.n ? (1u - (plies & 1u)) + 1u : BGS_ST_DRAW;
                     dirty = true;
-                    phase = kReady;
                 }
             }
-        } else if (phase == kReady) {
-            // ---- move stage: the list of the side to move is complete (or the board is over)
-            if (st == BGS_ST_RUNNING && plies < max_plies) {
-                if (!have_block || (plies & 3u) == 0u) {
-                    blk = philox4x32_10(seed, first_game + (uint64_t)game, plies >> 2);
-                    have_block = true;
-                }
-                const uint32_t mover = plies & 1u;
-                int s, t;
-                pick_flat(mv, column, sample_index(philox_word(blk, plies), mv.n), s, t);
-                move_piece(b, s, t);
-                ++plies;
-                dirty = true;
-                if ((1ull << t) & (g.goal_top | g.goal_bottom)) {
-                    st = mover + 1u;  // (stays ready: stored and freed by this stage in the next iteration)
-                } else {
-                    begin_search(g, b, 1u - mover, q, mv);  // also at the ply cap: the move may have blocked the game
-                    phase = kSearch;
-                }
-            } else {
-                if (dirty) {
-                    const int64_t i = game;
-                    store_board(planes, n, i, b);
-                    status[i] = (uint8_t)st;
-                    plies_buf[i] = (uint16_t)plies;
-                    reward[i] = reward_pair(st);
-                    stepped += plies - first_ply;
-                    dirty = false;
-                }
-                phase = kIdle;
+            search = false;
+        }
+        const bool run = has && st == BGS_ST_RUNNING && plies < max_plies;
+
+        // ---- boards that stopped go to memory and free their lane
+        if (has && !run) {
+            if (dirty) {
+                const int64_t i = game;
+                store_board(planes, n, i, b);
+                status[i] = (uint8_t)st;
+                plies_buf[i] = (uint16_t)plies;
+                reward[i] = reward_pair(st);
+                stepped += plies - first_ply;
             }
+            has = false;
+            dirty = false;
+        }
+        if (!__builtin_amdgcn_ballot_w64(has) && taken >= avail && dry) break;
+
+        // ---- one ply on every running board
+        if (run) {
+            if (!have_block || (plies & 3u) == 0u) {
+                blk = philox4x32_10(seed, first_game + (uint64_t)game, plies >> 2);
+                have_block = true;
+            }
+            const uint32_t mover = plies & 1u;
+            int s, t;
+            pick_flat(mv, column, sample_index(philox_word(blk, plies), mv.n), s, t);
+            move_piece(b, s, t);
+            ++plies;
+            dirty = true;
+            if ((1ull << t) & (g.goal_top | g.goal_bottom)) st = mover + 1u;  // (stored and freed next iteration)
+            else search = true;
         }
     }
     add_steps(steps, stepped);

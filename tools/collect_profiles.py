@@ -25,7 +25,8 @@ def main():
     method = ("tools/profile_all.sh: rocprofv3 --kernel-trace --stats, then --pmc in separate passes (SQ_*; FETCH_SIZE; "
               "WRITE_SIZE), per-dispatch means; FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads), KiB -> B")
     for tag, want, name in (("bench", "k_connect_rollout_aligned", "r02_bench_kernel.json"), ("k1", "step_random", "r02_k1.json"),
-                            ("k2c", "k_connect_rollout_lds", "r02_k2c.json"), ("bounce", "k_bounce_rollout", "r02_bounce.json")):
+                            ("k2c", "k_connect_rollout_lds", "r02_k2c.json"), ("k2b", "k_connect_rollout_aligned_wide", "r02_k2b.json"),
+                            ("bounce", "k_bounce_rollout", "r02_bounce.json"), ("bounce8", "k_bounce_rollout", "r02_bounce_lane_groups.json")):
         s = summary(tag, want)
         for k in s.values():
             k["hbm_bytes_per_launch"] = hbm_bytes(k)

@@ -11,8 +11,11 @@ bash tools/profile_kernel.sh bench python3 bench.py --steps 10 --warmup 2 --no-c
 bash tools/profile_kernel.sh k1 python3 tools/k1_steps.py
 # K2c: Connect(12,13,5), 2^18 boards
 bash tools/profile_kernel.sh k2c python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9
-# K3: Bounce 9x6, 2^18 boards, max_plies 4096
+# K3: Bounce 9x6, 2^18 boards, max_plies 4096: the flat kernel (default at this size) and lane-group mode
 bash tools/profile_kernel.sh bounce python3 tools/rollout_rate.py bounce --depth 1 --reps 6
+BGS_BOUNCE_GROUP=8 bash tools/profile_kernel.sh bounce8 python3 tools/rollout_rate.py bounce --depth 1 --reps 6
+# K2b: the register kernel K2c replaced on 12x13x5, for the instruction-count comparison
+BGS_ROLLOUT_NO_LDS=1 bash tools/profile_kernel.sh k2b python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9
 # K4 and the rest (reset, unpack, legal, ...): kernel stats only
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT}

@@ -6,6 +6,7 @@ set -e
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/prof_${tag}_stats $R/gpurun_out/prof_${tag}_sq $R/gpurun_out/prof_${tag}_fetch $R/gpurun_out/prof_${tag}_write
 prog=$1; shift
 args=()
 for a in "$@"; do case "$a" in /*) args+=("$a");; tools/*|bench.py) args+=("$R/$a");; *) args+=("$a");; esac; done

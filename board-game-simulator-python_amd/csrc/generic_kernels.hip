@@ -112,16 +112,20 @@ g_connect_play(GConnect c, int8_t* __restrict__ grid, uint8_t* __restrict__ stat
         while (st == BGS_ST_RUNNING && plies < max_plies && stepped < count) {
             const uint32_t idx = sample_index(draws.at(seed, first_game + (uint64_t)i, plies), (uint32_t)gc_legal_count(c, g));
             int x = 0;
-            for (uint32_t seen = 0;; ++x) {
+            for (uint32_t seen = 0; x < c.w; ++x) {
                 if (g[(c.h - 1) * c.w + x] == -1) {
                     if (seen == idx) break;
                     ++seen;
                 }
             }
+            if (x >= c.w) {  // no open column on a board that claims to be running (cannot arise from validated loads)
+                st = BGS_ST_DRAW;
+                break;
+            }
             st = gc_drop(c, g, x, plies);
             ++stepped;
         }
-        if (from_initial || stepped) {
+        if (from_initial || stepped || st != status[i]) {
             status[i] = (uint8_t)st;
             plies_buf[i] = (uint16_t)plies;
             reward[i] = reward_pair(st);
@@ -473,6 +477,10 @@ g_bounce_play(GBounce b, const int8_t* __restrict__ cfg, int8_t* __restrict__ gr
                 const int idx = (int)sample_index(draws.at(seed, first_game + (uint64_t)i, plies), (uint32_t)n_act);
                 int s, d;
                 gb_pick(b, g, bd, mover, idx, s, d);
+                if (s < 0 || d < 0) {  // (cannot arise: idx < n_act, both computed by the same search)
+                    st = BGS_ST_DRAW;
+                    break;
+                }
                 gb_move(b, g, bd, s, d);
                 ++plies;
                 ++stepped;

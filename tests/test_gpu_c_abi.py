@@ -1,0 +1,33 @@
+"""The drop-in boundary is a C ABI: a plain C99 program (tests/c/abi_smoke.c, gcc, no Python, no torch) links libbgs.so,
+plays a batch and receives the rewards in host memory; its counts must equal the oracle's."""
+
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "board-game-simulator-python_amd")
+
+
+def test_c_host_program(tmp_path):
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", PKG, "-lbgs",
+                           f"-Wl,-rpath,{PKG}", "-Wl,-rpath,/opt/rocm/lib"])
+    n = 100000
+    proc = subprocess.run(["timeout", "-k", "10", "300", exe, str(n)], capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    m = re.search(r"C_ABI n=(\d+) steps=(\d+) wins0=(\d+) wins1=(\d+) draws=(\d+) mismatches=(\d+)", proc.stdout)
+    assert m, proc.stdout
+    got = [int(v) for v in m.groups()]
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    steps = orc.rollout(0x0123456789ABCDEF, first_game=1000)
+    want = [n, steps, int((orc.winner == 0).sum()), int((orc.winner == 1).sum()), int((orc.winner == 2).sum()), 0]
+    assert got == want

@@ -58,7 +58,7 @@ Layout layout_for(int planes, int64_t n, int h, int w, size_t legal_bytes = 0) {
     l.steps = off; off += align_up(kStepBytes);
     l.worklist = off; off += align_up((size_t)n * 4);
     l.work_count = off; off += align_up(sizeof(uint32_t) * 2 * BGS_BOUNCE_MAX_PASSES);
-    l.gen_masks = off; off += align_up(sizeof(uint64_t) * 4 * (BGS_GENERIC_BOUNCE_MAX_CELLS / 64));
+    l.gen_masks = off; off += align_up(sizeof(uint64_t) * 6 * (BGS_GENERIC_BOUNCE_MAX_CELLS / 64));
     l.gen_cfg = off; off += align_up((size_t)h * w);
     size_t per_board = (size_t)h * w;
     if (per_board < (size_t)8 * (w + 1)) per_board = (size_t)8 * (w + 1);
@@ -373,7 +373,7 @@ int reset_impl(bgs_batch* b) {
 // generic Bounce: cell masks and start grid to the device; the device settles a start position without legal moves
 int generic_bounce_setup(bgs_batch* b, const int8_t* cfg) {
     constexpr int W = BGS_GENERIC_BOUNCE_MAX_CELLS / 64;
-    uint64_t masks[4 * W];
+    uint64_t masks[6 * W];
     memset(masks, 0, sizeof(masks));
     const int h = b->gen_h, w = b->gen_w;
     for (int y = 0; y < h; ++y)
@@ -384,6 +384,8 @@ int generic_bounce_setup(bgs_batch* b, const int8_t* cfg) {
             if (y > 0 && y < h - 1) masks[1 * W + (c >> 6)] |= bit;      // interior rows
             if (x > 0) masks[2 * W + (c >> 6)] |= bit;
             if (x < w - 1) masks[3 * W + (c >> 6)] |= bit;
+            if (y == h - 1) masks[4 * W + (c >> 6)] |= bit;               // player 0's goal row
+            if (y == 0) masks[5 * W + (c >> 6)] |= bit;                   // player 1's goal row
         }
     HIP_TRY(hipMemcpyAsync(b->d_gen_masks, masks, sizeof(masks), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(b->d_gen_cfg, cfg, (size_t)h * w, hipMemcpyHostToDevice, b->stream));

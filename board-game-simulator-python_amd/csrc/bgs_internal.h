@@ -72,7 +72,7 @@ struct bgs_batch {
     unsigned long long* d_steps;
     uint8_t* d_staging;
     size_t staging_bytes;
-    uint64_t* d_gen_masks;   // generic Bounce: [4][16] cell masks (all, interior, x > 0, x < w - 1)
+    uint64_t* d_gen_masks;   // generic Bounce: [6][16] cell masks (all, interior, x > 0, x < w - 1, top row, bottom row)
     int8_t* d_gen_cfg;       // generic Bounce: the configured start grid
     uint32_t* d_worklist;    // [n] board indices still to play (Bounce multi-pass rollout)
     uint32_t* d_work_count;  // [2 * BGS_BOUNCE_MAX_PASSES] list lengths, then work-queue heads; device-resident

@@ -9,6 +9,8 @@
 // move search runs on multi-word cell masks kept in per-lane scratch.  Same rules, same RNG contract, same canonical
 // action order as the packed kernels (connect_kernels.hip, bounce_kernels.hip); parity-tested against the oracle
 // and, on geometries both paths cover, against the packed kernels (BGS_FORCE_GENERIC=1).
+#include <type_traits>
+
 #include "bgs_common.h"
 #include "bgs_internal.h"
 
@@ -244,130 +246,142 @@ g_connect_pack(GConnect c, int8_t* __restrict__ grid, uint8_t* __restrict__ stat
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaskWords = BGS_GENERIC_BOUNCE_MAX_CELLS / 64;
 
+// NW = 64-bit words per cell mask, a compile-time choice (1, 2, 4, 8 or 16 by board size): with static trip counts the
+// masks of small boards live in registers instead of scratch
+template <int NW>
 struct Mask {
-    uint64_t w[kMaskWords];
+    uint64_t w[NW];
 };
 
 struct GBounce {
-    int h, w, nw;               // nw = words in use
-    const uint64_t* masks;      // device: [5][kMaskWords] all, interior, not_col0, not_collast, (unused)
+    int h, w;
+    const uint64_t* masks;      // device: [6][kMaskWords] all, interior, x > 0, x < w - 1, top row, bottom row
     uint32_t init_status;
 };
 
-__device__ __forceinline__ void m_zero(Mask& a, int nw) { for (int i = 0; i < nw; ++i) a.w[i] = 0; }
-__device__ __forceinline__ bool m_any(const Mask& a, int nw) { uint64_t t = 0; for (int i = 0; i < nw; ++i) t |= a.w[i]; return t != 0; }
-__device__ __forceinline__ bool m_test(const Mask& a, int c) { return (a.w[c >> 6] >> (c & 63)) & 1ull; }
-__device__ __forceinline__ void m_set(Mask& a, int c) { a.w[c >> 6] |= 1ull << (c & 63); }
-__device__ __forceinline__ void m_clear(Mask& a, int c) { a.w[c >> 6] &= ~(1ull << (c & 63)); }
-__device__ __forceinline__ int m_count(const Mask& a, int nw) { int t = 0; for (int i = 0; i < nw; ++i) t += __popcll(a.w[i]); return t; }
-__device__ __forceinline__ int m_first(const Mask& a, int nw) {
-    for (int i = 0; i < nw; ++i) if (a.w[i]) return i * 64 + __ffsll((unsigned long long)a.w[i]) - 1;
-    return -1;
+#define FOR_WORDS _Pragma("unroll") for (int i = 0; i < NW; ++i)
+template <int NW> __device__ __forceinline__ void m_zero(Mask<NW>& a) { FOR_WORDS a.w[i] = 0; }
+// bit c of the mask; the word is picked with selects, never with a dynamically indexed register array
+template <int NW> __device__ __forceinline__ bool m_test(const Mask<NW>& a, int c) {
+    uint64_t word = 0;
+    FOR_WORDS word = (c >> 6) == i ? a.w[i] : word;
+    return (word >> (c & 63)) & 1ull;
+}
+template <int NW> __device__ __forceinline__ void m_set(Mask<NW>& a, int c) {
+    const uint64_t bit = 1ull << (c & 63);
+    FOR_WORDS a.w[i] |= (c >> 6) == i ? bit : 0ull;
+}
+template <int NW> __device__ __forceinline__ void m_clear(Mask<NW>& a, int c) {
+    const uint64_t bit = 1ull << (c & 63);
+    FOR_WORDS a.w[i] &= (c >> 6) == i ? ~bit : ~0ull;
+}
+template <int NW> __device__ __forceinline__ int m_count(const Mask<NW>& a) { int t = 0; FOR_WORDS t += __popcll(a.w[i]); return t; }
+template <int NW> __device__ __forceinline__ int m_first(const Mask<NW>& a) {
+    int found = -1;
+    FOR_WORDS if (found < 0 && a.w[i]) found = i * 64 + __ffsll((unsigned long long)a.w[i]) - 1;
+    return found;
 }
 // the k-th set bit (k < count)
-__device__ __forceinline__ int m_select(const Mask& a, int nw, int k) {
-    for (int i = 0; i < nw; ++i) {
+template <int NW> __device__ __forceinline__ int m_select(const Mask<NW>& a, int k) {
+    int found = -1;
+    FOR_WORDS {
         const int cnt = __popcll(a.w[i]);
-        if (k < cnt) {
+        if (found < 0 && k < cnt) {
             uint64_t t = a.w[i];
             for (int j = 0; j < k; ++j) t &= t - 1;
-            return i * 64 + __ffsll((unsigned long long)t) - 1;
+            found = i * 64 + __ffsll((unsigned long long)t) - 1;
         }
-        k -= cnt;
+        k -= found < 0 ? cnt : 0;
     }
-    return -1;
+    return found;
 }
-// dst = src shifted towards higher cell indices by s bits (s >= 0), within nw words
-__device__ void m_shl(Mask& dst, const Mask& src, int s, int nw) {
-    const int ws = s >> 6, bs = s & 63;
-    for (int i = nw - 1; i >= 0; --i) {
-        uint64_t v = 0;
-        if (i - ws >= 0) {
-            v = src.w[i - ws] << bs;
-            if (bs && i - ws - 1 >= 0) v |= src.w[i - ws - 1] >> (64 - bs);
-        }
-        dst.w[i] = v;
+// dst = src shifted towards higher cell indices by s bits, 1 <= s <= 64 (a board is at most 64 cells wide): the word
+// offset is 0 or 1, so every source word is a static register
+template <int NW> __device__ __forceinline__ void m_shl(Mask<NW>& dst, const Mask<NW>& src, int s) {
+    const bool whole = s == 64;
+    const int bs = s & 63;
+    FOR_WORDS {
+        const uint64_t here = src.w[i], below = i > 0 ? src.w[i > 0 ? i - 1 : 0] : 0ull;
+        dst.w[i] = whole ? below : ((here << bs) | (below >> (64 - bs)));
     }
 }
-__device__ void m_shr(Mask& dst, const Mask& src, int s, int nw) {
-    const int ws = s >> 6, bs = s & 63;
-    for (int i = 0; i < nw; ++i) {
-        uint64_t v = 0;
-        if (i + ws < nw) {
-            v = src.w[i + ws] >> bs;
-            if (bs && i + ws + 1 < nw) v |= src.w[i + ws + 1] << (64 - bs);
-        }
-        dst.w[i] = v;
+template <int NW> __device__ __forceinline__ void m_shr(Mask<NW>& dst, const Mask<NW>& src, int s) {
+    const bool whole = s == 64;
+    const int bs = s & 63;
+    FOR_WORDS {
+        const uint64_t here = src.w[i], above = i + 1 < NW ? src.w[i + 1 < NW ? i + 1 : 0] : 0ull;
+        dst.w[i] = whole ? above : ((here >> bs) | (above << (64 - bs)));
     }
 }
 
 // board-level masks of one lane's board, rebuilt from the grid when a kernel picks the board up and kept up to date by
 // gb_move
+template <int NW>
 struct GBoard {
-    Mask occ;
+    Mask<NW> occ;
 };
 
-__device__ void gb_load(const GBounce& b, const int8_t* g, GBoard& bd) {
-    m_zero(bd.occ, b.nw);
+template <int NW>
+__device__ void gb_load(const GBounce& b, const int8_t* g, GBoard<NW>& bd) {
+    m_zero(bd.occ);
     for (int c = 0; c < b.h * b.w; ++c)
         if (g[c] > 0) m_set(bd.occ, c);
 }
 
 // every legal landing cell of the piece on cell `src` for `player` (SURVEY Appendix B rules 4-5; the multi-word twin
 // of reach() in bounce_kernels.hip)
-__device__ void gb_reach(const GBounce& b, const int8_t* g, const GBoard& bd, uint32_t player, int src, Mask& targets) {
-    const int nw = b.nw;
+template <int NW>
+__device__ void gb_reach(const GBounce& b, const int8_t* g, const GBoard<NW>& bd, uint32_t player, int src, Mask<NW>& targets) {
     const uint64_t* all = b.masks;
     const uint64_t* interior = b.masks + kMaskWords;
     const uint64_t* not_col0 = b.masks + 2 * kMaskWords;
     const uint64_t* not_collast = b.masks + 3 * kMaskWords;
-    Mask pending, done, a0, al, ar, t1, t2, nf, nl, nr, land;
-    m_zero(pending, nw);
-    m_zero(done, nw);
-    m_zero(targets, nw);
+    Mask<NW> pending, done, a0, al, ar, t1, t2, nf, nl, nr, land;
+    m_zero(pending);
+    m_zero(done);
+    m_zero(targets);
     m_set(pending, src);
-    const int goal_lo = player ? 0 : (b.h - 1) * b.w, goal_hi = goal_lo + b.w;  // the mover's goal row: cells [lo, hi)
-    for (int c = m_first(pending, nw); c >= 0; c = m_first(pending, nw)) {
+    const uint64_t* goal = b.masks + (player ? 5 : 4) * kMaskWords;  // the mover's goal row
+    for (int c = m_first(pending); c >= 0; c = m_first(pending)) {
         m_clear(pending, c);
         m_set(done, c);
         const int v = g[c];
-        m_zero(a0, nw);
-        m_zero(al, nw);
-        m_zero(ar, nw);
-        m_zero(land, nw);
+        m_zero(a0);
+        m_zero(al);
+        m_zero(ar);
+        m_zero(land);
         m_set(a0, c);
         for (int s = 1; s <= v; ++s) {
-            for (int i = 0; i < nw; ++i) {
+            FOR_WORDS {
                 t1.w[i] = a0.w[i] | al.w[i];                 // may go on left (and forward)
                 t2.w[i] = (a0.w[i] | ar.w[i]);               // may go on right (and forward)
                 land.w[i] = t1.w[i] | ar.w[i];               // (scratch: everybody may go forward)
             }
-            if (player) m_shr(nf, land, b.w, nw); else m_shl(nf, land, b.w, nw);
-            for (int i = 0; i < nw; ++i) { t1.w[i] &= not_col0[i]; t2.w[i] &= not_collast[i]; }
-            m_shr(nl, t1, 1, nw);
-            m_shl(nr, t2, 1, nw);
+            if (player) m_shr(nf, land, b.w); else m_shl(nf, land, b.w);
+            FOR_WORDS { t1.w[i] &= not_col0[i]; t2.w[i] &= not_collast[i]; }
+            m_shr(nl, t1, 1);
+            m_shl(nr, t2, 1);
             if (s < v) {
                 uint64_t left = 0;
-                for (int i = 0; i < nw; ++i) {
+                FOR_WORDS {
                     const uint64_t free_i = ~bd.occ.w[i] & interior[i];
                     a0.w[i] = nf.w[i] & free_i;
                     al.w[i] = nl.w[i] & free_i;
                     ar.w[i] = nr.w[i] & free_i;
                     left |= a0.w[i] | al.w[i] | ar.w[i];
                 }
-                m_zero(land, nw);
+                m_zero(land);
                 if (!left) break;
             } else {
-                for (int i = 0; i < nw; ++i) land.w[i] = (nf.w[i] | nl.w[i] | nr.w[i]) & all[i];
+                FOR_WORDS land.w[i] = (nf.w[i] | nl.w[i] | nr.w[i]) & all[i];
             }
         }
-        for (int i = 0; i < nw; ++i) {
+        FOR_WORDS {
             const uint64_t free_i = ~bd.occ.w[i] & interior[i];
             targets.w[i] |= land.w[i] & free_i;
             pending.w[i] |= land.w[i] & bd.occ.w[i] & interior[i] & ~done.w[i];
         }
-        for (int t = goal_lo; t < goal_hi; ++t)  // the goal row is a legal landing too
-            if (m_test(land, t)) m_set(targets, t);
+        FOR_WORDS targets.w[i] |= land.w[i] & goal[i];  // the mover's goal row is a legal landing too
     }
 }
 
@@ -385,38 +399,41 @@ __device__ int gb_active_row(const GBounce& b, const int8_t* g, uint32_t player)
     return -1;
 }
 
-__device__ int gb_count_actions(const GBounce& b, const int8_t* g, const GBoard& bd, uint32_t player) {
+template <int NW>
+__device__ int gb_count_actions(const GBounce& b, const int8_t* g, const GBoard<NW>& bd, uint32_t player) {
     const int row = gb_active_row(b, g, player);
     if (row < 0) return 0;
     int total = 0;
-    Mask t;
+    Mask<NW> t;
     for (int x = 0; x < b.w; ++x)
         if (g[row * b.w + x] > 0) {
             gb_reach(b, g, bd, player, row * b.w + x, t);
-            total += m_count(t, b.nw);
+            total += m_count(t);
         }
     return total;
 }
 
 // the idx-th action of the canonical list: sources by ascending x, targets by ascending cell index
-__device__ void gb_pick(const GBounce& b, const int8_t* g, const GBoard& bd, uint32_t player, int idx, int& s, int& d) {
+template <int NW>
+__device__ void gb_pick(const GBounce& b, const int8_t* g, const GBoard<NW>& bd, uint32_t player, int idx, int& s, int& d) {
     const int row = gb_active_row(b, g, player);
     s = d = -1;
-    Mask t;
+    Mask<NW> t;
     for (int x = 0; x < b.w && row >= 0; ++x)
         if (g[row * b.w + x] > 0) {
             gb_reach(b, g, bd, player, row * b.w + x, t);
-            const int cnt = m_count(t, b.nw);
+            const int cnt = m_count(t);
             if (idx < cnt) {
                 s = row * b.w + x;
-                d = m_select(t, b.nw, idx);
+                d = m_select(t, idx);
                 return;
             }
             idx -= cnt;
         }
 }
 
-__device__ void gb_move(const GBounce& b, int8_t* g, GBoard& bd, int s, int d) {
+template <int NW>
+__device__ void gb_move(const GBounce& b, int8_t* g, GBoard<NW>& bd, int s, int d) {
     g[d] = g[s];
     g[s] = 0;
     m_clear(bd.occ, s);
@@ -424,7 +441,8 @@ __device__ void gb_move(const GBounce& b, int8_t* g, GBoard& bd, int s, int d) {
 }
 
 // status after `mover` moved to cell d (Appendix B rule 7); n_next = action count of the next player
-__device__ uint32_t gb_settle(const GBounce& b, const int8_t* g, const GBoard& bd, uint32_t mover, int d, int& n_next) {
+template <int NW>
+__device__ uint32_t gb_settle(const GBounce& b, const int8_t* g, const GBoard<NW>& bd, uint32_t mover, int d, int& n_next) {
     const int y = d / b.w;
     n_next = 0;
     if (y == 0 || y == b.h - 1) return mover + 1u;
@@ -445,6 +463,7 @@ g_bounce_reset(GBounce b, const int8_t* __restrict__ cfg, int8_t* __restrict__ g
     reward[i] = reward_pair(b.init_status);
 }
 
+template <int NW>
 __global__ void __launch_bounds__(kBlock)
 g_bounce_play(GBounce b, const int8_t* __restrict__ cfg, int8_t* __restrict__ grid, uint8_t* __restrict__ status,
               uint16_t* __restrict__ plies_buf, uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game,
@@ -464,7 +483,7 @@ g_bounce_play(GBounce b, const int8_t* __restrict__ cfg, int8_t* __restrict__ gr
         }
         const uint32_t st_in = st;
         if (st == BGS_ST_RUNNING) {
-            GBoard bd;
+            GBoard<NW> bd;
             gb_load(b, g, bd);
             Draws draws;
             draws.have = 0;
@@ -496,6 +515,7 @@ g_bounce_play(GBounce b, const int8_t* __restrict__ cfg, int8_t* __restrict__ gr
     add_steps(steps, stepped);
 }
 
+template <int NW>
 __global__ void __launch_bounds__(kBlock)
 g_bounce_step_actions(GBounce b, int8_t* __restrict__ grid, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                       uint16_t* __restrict__ reward, int64_t n, const int32_t* __restrict__ moves, int32_t* __restrict__ result,
@@ -514,9 +534,9 @@ g_bounce_step_actions(GBounce b, int8_t* __restrict__ grid, uint8_t* __restrict_
                 const uint32_t mover = plies & 1u;
                 const int s = sy * b.w + sx, d = ty * b.w + tx;
                 if (g[s] > 0 && sy == gb_active_row(b, g, mover)) {
-                    GBoard bd;
+                    GBoard<NW> bd;
                     gb_load(b, g, bd);
-                    Mask t;
+                    Mask<NW> t;
                     gb_reach(b, g, bd, mover, s, t);
                     if (m_test(t, d)) {
                         gb_move(b, g, bd, s, d);
@@ -542,6 +562,7 @@ g_bounce_step_actions(GBounce b, int8_t* __restrict__ grid, uint8_t* __restrict_
 // legal moves of the side to move: count[n]; wide[n] = { int32 active row (-1: none), uint8 flags[W][H * W] } where
 // flags[x][c] = 1 when cell c is a legal target of the piece in column x of the active row (stride: see
 // generic_bounce_legal_bytes)
+template <int NW>
 __global__ void __launch_bounds__(kBlock)
 g_bounce_targets(GBounce b, const int8_t* __restrict__ grid, const uint8_t* __restrict__ status,
                  const uint16_t* __restrict__ plies_buf, int64_t n, uint8_t* __restrict__ wide, int64_t stride,
@@ -560,13 +581,13 @@ g_bounce_targets(GBounce b, const int8_t* __restrict__ grid, const uint8_t* __re
     }
     int total = 0;
     if (row >= 0) {
-        GBoard bd;
+        GBoard<NW> bd;
         gb_load(b, g, bd);
-        Mask t;
+        Mask<NW> t;
         for (int x = 0; x < b.w; ++x)
             if (g[row * b.w + x] > 0) {
                 gb_reach(b, g, bd, player, row * b.w + x, t);
-                total += m_count(t, b.nw);
+                total += m_count(t);
                 if (out)
                     for (int c = 0; c < cells; ++c) out[4 + x * cells + c] = (uint8_t)m_test(t, c);
             }
@@ -574,6 +595,7 @@ g_bounce_targets(GBounce b, const int8_t* __restrict__ grid, const uint8_t* __re
     if (count) count[i] = total;
 }
 
+template <int NW>
 __global__ void __launch_bounds__(kBlock)
 g_bounce_pack(GBounce b, int8_t* __restrict__ grid, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
               uint16_t* __restrict__ reward, int64_t n, const int8_t* __restrict__ src, const int8_t* __restrict__ player,
@@ -599,7 +621,7 @@ g_bounce_pack(GBounce b, int8_t* __restrict__ grid, uint8_t* __restrict__ status
         int8_t* g = grid + i * hw;
         for (int t = 0; t < hw; ++t) g[t] = s[t];
         if (st == BGS_ST_RUNNING) {
-            GBoard bd;
+            GBoard<NW> bd;
             gb_load(b, g, bd);
             if (gb_count_actions(b, g, bd, (uint32_t)pl) == 0)
                 st = gb_count_actions(b, g, bd, 1u - (uint32_t)pl) ? (1u - (uint32_t)pl) + 1u : BGS_ST_DRAW;
@@ -625,8 +647,17 @@ g_meta(const uint8_t* __restrict__ status, const uint16_t* __restrict__ plies_bu
 }
 
 GConnect gconnect(const bgs_batch* b) { return GConnect{b->gen_h, b->gen_w, b->gen_k}; }
-GBounce gbounce(const bgs_batch* b) {
-    return GBounce{b->gen_h, b->gen_w, (b->gen_h * b->gen_w + 63) / 64, b->d_gen_masks, b->gen_init_status};
+GBounce gbounce(const bgs_batch* b) { return GBounce{b->gen_h, b->gen_w, b->d_gen_masks, b->gen_init_status}; }
+
+// mask words by board size: the smallest of 1, 2, 4, 8, 16 that holds height * width cells
+template <class F>
+void with_words(const bgs_batch* b, F&& f) {
+    const int words = (b->gen_h * b->gen_w + 63) / 64;
+    if (words <= 1) f(std::integral_constant<int, 1>{});
+    else if (words <= 2) f(std::integral_constant<int, 2>{});
+    else if (words <= 4) f(std::integral_constant<int, 4>{});
+    else if (words <= 8) f(std::integral_constant<int, 8>{});
+    else f(std::integral_constant<int, 16>{});
 }
 int8_t* cells(const bgs_batch* b) { return reinterpret_cast<int8_t*>(b->d_planes); }
 uint16_t* rewards(const bgs_batch* b) { return reinterpret_cast<uint16_t*>(b->d_reward); }
@@ -651,9 +682,11 @@ void generic_play(const bgs_batch* b, uint64_t seed, uint32_t max_plies, uint32_
         hipLaunchKernelGGL(g_connect_play, dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream, gconnect(b), cells(b), b->d_status,
                            b->d_plies, rewards(b), b->n, seed, b->first_game, max_plies, count, from_initial ? 1 : 0, b->d_steps);
     else
-        hipLaunchKernelGGL(g_bounce_play, dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream, gbounce(b), b->d_gen_cfg, cells(b),
-                           b->d_status, b->d_plies, rewards(b), b->n, seed, b->first_game, max_plies, count, from_initial ? 1 : 0,
-                           b->d_steps);
+        with_words(b, [&](auto words) {
+            hipLaunchKernelGGL((g_bounce_play<decltype(words)::value>), dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream,
+                               gbounce(b), b->d_gen_cfg, cells(b), b->d_status, b->d_plies, rewards(b), b->n, seed, b->first_game,
+                               max_plies, count, from_initial ? 1 : 0, b->d_steps);
+        });
 }
 
 void generic_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out) {
@@ -661,8 +694,10 @@ void generic_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t*
         hipLaunchKernelGGL(g_connect_step_actions, dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream, gconnect(b), cells(b),
                            b->d_status, b->d_plies, rewards(b), b->n, d_actions, d_status_out, b->d_steps);
     else
-        hipLaunchKernelGGL(g_bounce_step_actions, dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream, gbounce(b), cells(b),
-                           b->d_status, b->d_plies, rewards(b), b->n, d_actions, d_status_out, b->d_steps);
+        with_words(b, [&](auto words) {
+            hipLaunchKernelGGL((g_bounce_step_actions<decltype(words)::value>), dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream,
+                               gbounce(b), cells(b), b->d_status, b->d_plies, rewards(b), b->n, d_actions, d_status_out, b->d_steps);
+        });
 }
 
 void generic_unpack_grid(const bgs_batch* b, int8_t* d_grid) {
@@ -680,8 +715,11 @@ void generic_connect_legal(const bgs_batch* b, uint8_t* d_legal, int32_t* d_coun
 }
 
 void generic_bounce_targets(const bgs_batch* b, uint8_t* d_wide, int32_t* d_count) {
-    hipLaunchKernelGGL(g_bounce_targets, dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream, gbounce(b), cells(b), b->d_status,
-                       b->d_plies, b->n, d_wide, (int64_t)generic_bounce_legal_bytes(b->gen_h, b->gen_w), d_count);
+    with_words(b, [&](auto words) {
+        hipLaunchKernelGGL((g_bounce_targets<decltype(words)::value>), dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream,
+                           gbounce(b), cells(b), b->d_status, b->d_plies, b->n, d_wide,
+                           (int64_t)generic_bounce_legal_bytes(b->gen_h, b->gen_w), d_count);
+    });
 }
 
 void generic_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_player, const int8_t* d_winner,
@@ -690,8 +728,11 @@ void generic_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_play
         hipLaunchKernelGGL(g_connect_pack, dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream, gconnect(b), cells(b), b->d_status,
                            b->d_plies, rewards(b), b->n, d_grid, d_player, d_winner, d_status_out);
     else
-        hipLaunchKernelGGL(g_bounce_pack, dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream, gbounce(b), cells(b), b->d_status,
-                           b->d_plies, rewards(b), b->n, d_grid, d_player, d_winner, d_plies, d_status_out);
+        with_words(b, [&](auto words) {
+            hipLaunchKernelGGL((g_bounce_pack<decltype(words)::value>), dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream,
+                               gbounce(b), cells(b), b->d_status, b->d_plies, rewards(b), b->n, d_grid, d_player, d_winner, d_plies,
+                               d_status_out);
+        });
 }
 
 }  // namespace bgs

@@ -3,7 +3,7 @@
 # Each kernel gets rocprofv3 --kernel-trace --stats, an SQ counter pass and separate FETCH_SIZE / WRITE_SIZE passes
 # (tools/profile_kernel.sh: the program directly after "--"); tools/collect_profiles.py turns the CSVs into
 # profiles/r02_*.json and the counters file bench.py reads (keyed by the library's build id).
-set -e
+set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 # K2a: the bench itself (hand-over included), 12 timed launches in the counter passes
 bash tools/profile_kernel.sh bench python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-device-resident

@@ -206,13 +206,14 @@ def main() -> int:
     # the launching thread waits for the delivery of step i - 2 * depth, not i - depth, before it enqueues step i:
     # waiting on the previous step of the SAME stream would leave the GPU one batch short for the length of the delivery
     host_slots = depth if sharded else 2 * depth
-    batches, packed, all_packed, host_rewards, events = [], [], [], [], []
+    batches, packed, packed_buf, all_packed, host_rewards, events = [], [], [], [], [], []
     for s in streams:
         with torch.cuda.stream(s):
             b = ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=local_rank, use_torch=True)  # ordered onto stream s
             b.set_first_game(shard_range(n * world, rank, world)[0])
             batches.append(b)
-            packed.append(torch.empty(code_bytes, dtype=torch.uint8, device=gpu) if sharded else None)
+            packed_buf.append(torch.zeros((n + 63) // 64 * 16, dtype=torch.uint8, device=gpu) if sharded else None)
+            packed.append(packed_buf[-1][:code_bytes] if sharded else None)
             all_packed.append(torch.empty(world * code_bytes, dtype=torch.uint8, device=gpu) if sharded and owner else None)
     for _ in range(host_slots):
         if handover == "pairs":
@@ -288,14 +289,17 @@ def main() -> int:
                 settle(k)
             if ev is not None:
                 ev[0].record(streams[k])
-            b.rollout(SEED + i, from_initial=True)
-            if ev is not None:
-                ev[1].record(streams[k])
             if not with_handover or handover == "none":
+                b.rollout(SEED + i, from_initial=True)
+                if ev is not None:
+                    ev[1].record(streams[k])
                 return
             # N > 1: the path's only exchange -- every rank's outcome codes to rank 0 (RCCL over xGMI), asynchronous, so
-            # the stream goes straight on to its next rollout; rank 0's sink takes the codes to the host one turn later
-            b.outcomes_tensor(packed[k])
+            # the stream goes straight on to its next rollout; rank 0's sink takes the codes to the host one turn later.
+            # The rollout kernel writes the codes into the send buffer itself (bgs_rollout_pack)
+            b.rollout_outcomes_tensor(packed_buf[k], SEED + i, from_initial=True)
+            if ev is not None:
+                ev[1].record(streams[k])
             if backend == "nccl":
                 pending[k] = gather_outcomes_to(dist, packed[k], all_packed[k] if owner else None, dst=0, async_op=True)
             else:

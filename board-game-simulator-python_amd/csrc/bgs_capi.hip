@@ -883,6 +883,11 @@ int bgs_pack_outcomes(bgs_batch* b, void* device_dst) {
     return finish_launch();
 }
 
+int bgs_rollout_pack(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, void* device_dst) {
+    NEED(b != nullptr, "batch handle is NULL");
+    return bgs::rollout_with_codes(b, seed, max_plies, flags, static_cast<uint8_t*>(device_dst));
+}
+
 int bgs_expand_outcomes(int device, void* hip_stream, const void* device_packed, int64_t n, int8_t* device_reward) {
     NEED(device_packed != nullptr && device_reward != nullptr && n >= 0, "bad argument");
     int rc = check_device(device);

@@ -458,6 +458,16 @@ class _Batch:
         _abi.check(_abi.lib().bgs_pack_outcomes(self._handle, ctypes.c_void_p(out.data_ptr())))
         return out
 
+    def rollout_outcomes_tensor(self, out, seed: int = DEFAULT_SEED, max_plies: int = 2**31 - 1, from_initial: bool = False):
+        """`rollout` + `outcomes_tensor(out)` in one library call (bgs_rollout_pack): the rollout kernel writes the codes
+        itself where it can.  `out`: CUDA uint8 tensor of ((n + 63) // 64) * 16 bytes."""
+        if out.numel() < (self.n + 63) // 64 * 16 or not out.is_cuda or not out.is_contiguous():
+            raise TypeError("outcome buffer must be a contiguous CUDA uint8 tensor of ((n + 63) // 64) * 16 bytes")
+        flags = _abi.ROLLOUT_FROM_INITIAL if from_initial else 0
+        _abi.check(_abi.lib().bgs_rollout_pack(self._handle, ctypes.c_uint64(seed), ctypes.c_int32(max_plies),
+                                               ctypes.c_uint32(flags), ctypes.c_void_p(out.data_ptr())))
+        return out
+
     def grid_tensor(self, out=None):
         """Observation tensor int8[n, H, W] on the device (no host round trip), e.g. as policy-network input."""
         t = self._torch

@@ -146,6 +146,10 @@ int bgs_export_device(bgs_batch* b, int what, void* device_dst);
  * device_dst uint8[(n + 3) / 4].  A reward pair (State::get_reward, connect.cpp:41 / bounce.cpp:38) is a function of
  * this code, so ranks exchange 0.25 B per game over xGMI instead of 2 B and expand after the gather. */
 int bgs_pack_outcomes(bgs_batch* b, void* device_dst);
+/* bgs_rollout followed by bgs_pack_outcomes in one call; kernels that can (one-word Connect boards, compile-time
+ * multi-word geometries) write the codes themselves, so no second launch follows the rollout.  device_dst: 16-byte
+ * aligned, ((n + 63) / 64) * 16 bytes -- what a rank hands to the RCCL gather. */
+int bgs_rollout_pack(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, void* device_dst);
 /* inverse, batch-independent: packed codes of n boards -> reward int8[n][2] (8-byte aligned), on `device` / stream */
 int bgs_expand_outcomes(int device, void* hip_stream, const void* device_packed, int64_t n, int8_t* device_reward);
 

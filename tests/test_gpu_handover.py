@@ -143,6 +143,28 @@ def test_sink_rollout_fused_codes_all_entry_states(bm, h, w, k, n):
     dev.close()
 
 
+@pytest.mark.parametrize("case", ["connect6x7", "connect4x5", "connect12x13", "connect8x9", "bounce"])
+def test_rollout_pack_equals_rollout_then_pack(bm, torch_mod, case):
+    """bgs_rollout_pack (what a rank hands to the RCCL gather): the codes the rollout kernels write themselves, or the
+    pack kernel behind the others, equal bgs_rollout + bgs_pack_outcomes and the oracle's winners."""
+    torch = torch_mod
+    n = 50001
+    if case == "bounce":
+        dev, orc, kw = bm.BounceBatch(DEFAULT_BOUNCE, n, use_torch=True), oracle.BounceOracle(DEFAULT_BOUNCE, n), {"max_plies": 200}
+    else:
+        h, w, k = {"connect6x7": (6, 7, 4), "connect4x5": (4, 5, 3), "connect12x13": (12, 13, 5), "connect8x9": (8, 9, 4)}[case]
+        dev, orc, kw = bm.ConnectBatch(h, w, k, n, use_torch=True), oracle.ConnectOracle(h, w, k, n), {}
+    buf = torch.full(((n + 63) // 64 * 16,), 0xAA, dtype=torch.uint8, device="cuda")
+    dev.rollout_outcomes_tensor(buf, SEED + 9, from_initial=True, **kw)
+    want = dev.outcomes_tensor()
+    torch.cuda.synchronize()
+    nbytes = (n + 3) // 4
+    assert torch.equal(buf[:nbytes], want[:nbytes])
+    orc.rollout(SEED + 9, **kw)
+    np.testing.assert_array_equal(bm.expand_outcomes_host(buf[:nbytes].cpu().numpy(), n), orc.reward)
+    dev.close()
+
+
 def test_reward_sink_takes_gathered_codes(bm, torch_mod):
     """Rank 0's side of the multi-GPU gather: codes of several shards, already on the device, to one host array."""
     torch = torch_mod

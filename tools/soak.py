@@ -10,9 +10,13 @@ from simulator.batch import BounceBatch, ConnectBatch, HostEvent, PinnedArray, R
 
 SEED = 0x0123456789ABCDEF
 g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]
-free0 = torch.cuda.mem_get_info()[0]
 t0 = time.perf_counter()
-for it in range(150):
+free0, marks = None, []
+for it in range(160):
+    if it in (10, 60, 110):  # the first iterations load code objects and grow the runtime's own pools
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        marks.append(torch.cuda.mem_get_info()[0])
+        free0 = free0 or marks[-1]
     n = 1000 + 37 * it
     c = ConnectBatch(6, 7, 4, n, use_torch=bool(it & 1))
     b = BounceBatch(g, 200 + it, use_torch=bool(it & 2))
@@ -27,9 +31,11 @@ for it in range(150):
     for obj in (sink, ev, pin, c, b):
         obj.close()
 torch.cuda.synchronize()
+torch.cuda.empty_cache()  # use_torch batches live in torch's caching allocator
 free1 = torch.cuda.mem_get_info()[0]
-print(f"150 create/destroy cycles in {time.perf_counter() - t0:.1f} s; device memory free before/after: {free0 >> 20} / {free1 >> 20} MiB")
-assert free0 - free1 < (64 << 20), "device memory leaked"
+marks.append(free1)
+print(f"160 create/destroy cycles in {time.perf_counter() - t0:.1f} s; device memory free after 10/60/110/160: {[m >> 20 for m in marks]} MiB")
+assert free0 - free1 < (64 << 20), f"device memory leaked: {(free0 - free1) >> 20} MiB"
 
 # long loop: 20000 steps over 3 batches and a sink; seeds repeat with period 50, results must repeat bit for bit
 N, D, H = 1 << 18, 3, 6

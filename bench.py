@@ -4,7 +4,7 @@ to a HOST array.
 
 One "step" = one pass of the hot path over one batch: every board of the batch is played from
 Config.sample_initial_state() to its terminal state with uniformly sampled actions (enumerate -> sample ->
-transition -> k-in-a-row / draw -> reward), fused in one HIP launch (k_connect_rollout_aligned), and the step's
+transition -> k-in-a-row / draw -> reward), fused in one HIP launch (k_connect_rollout_opened), and the step's
 rewards int8[batch, 2] are handed over to a host array (SURVEY.md 8d: "... to rewards resident in one host array";
 the reference returns `reward` as a host ndarray, connect.cpp:41).  env-steps are the transitions applied to running
 boards (masked no-ops are not counted); they are counted on the device.
@@ -439,7 +439,7 @@ def main() -> int:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_connect_rollout_aligned",
+                "kernel": "k_connect_rollout_opened",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -60,6 +60,8 @@ struct bgs_batch {
     uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];
     int bounce_pass_group[BGS_BOUNCE_MAX_PASSES];
     int rollout_generic;     // 1: never take the block-aligned from-initial kernel (A/B timing, BGS_ROLLOUT_GENERIC)
+    int rollout_chunk;       // games per wave of the fused rollout, 0 = derived from rollout_wps (BGS_ROLLOUT_CHUNK)
+    int rollout_opening;     // opening blocks of the from-initial one-word rollout: 0 = K2a, 1..4, default 3 (BGS_ROLLOUT_OPENING)
     int rollout_no_lds;      // 1: large boards stay in registers (K2b) instead of the LDS-staged kernel (BGS_ROLLOUT_NO_LDS)
     // device buffers (inside the arena)
     void* arena;

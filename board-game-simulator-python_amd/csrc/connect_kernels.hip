@@ -877,6 +877,220 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
     add_steps(steps, stepped);
 }
 
+// K2o: K2a with an opening stage.  Two things cost K2a more than the plies themselves:
+//   * every ply pays for a run test and for the search of the idx-th open column.  Neither is needed at the start of
+//     a game: in the first four plies (OPEN_BLOCKS >= 1; needs H >= 4, K >= 3, W >= 2) nobody can win, no column can
+//     fill and the board cannot fill, so a ply is "column = floor(draw * W / 2^32), drop" -- ten instructions; with
+//     K >= 4 and H >= 6 (OPEN_BLOCKS >= 2) the same holds for plies 4 and 5, and plies 6 and 7 are full plies.
+//   * the lane-refill loop carries ~45 instructions of refill / store code around every 4-ply block.  The wave
+//     therefore opens 64 games AT ONCE, all lanes busy and no refill code, whenever its pool of opened boards runs
+//     dry, and parks them in a wave-private ring in LDS (128 slots of planes + column nibbles); idle lanes refill from
+//     the ring and join the main loop at block OPEN_BLOCKS (blocks 2.. of the opening are full blocks in lock step).
+//     A game that ends inside the opening is stored by the opening stage and parked as a dead slot (column word 0).
+// Status and reward are not stored per game either: the 2-bit outcome codes of the wave's chunk accumulate in LDS (they
+// are needed for the hand-over anyway) and are expanded into the status / reward arrays, four games per lane and
+// coalesced, when the chunk is done.  Results are those of K2a bit for bit: the draws are keyed by (game, block).
+//
+// (Tried and measured, not kept: sharing the drain inside a workgroup -- a wave whose chunk is exhausted parks its last
+// <= 32 boards in LDS for the waves still running and leaves.  It cut another 6 % of the instructions and made the
+// kernel slower, alone and three in flight: the adopted boards lengthen ONE wave per workgroup, i.e. one SIMD of the
+// CU, and with two workgroups per CU that imbalance is not averaged out.)
+struct OpenedPool {  // per wave
+    static constexpr uint32_t SLOTS = 128;
+    uint64_t plane[2][SLOTS];
+    uint64_t cols[SLOTS];  // low word: column nibbles, 0 = dead slot
+};
+
+template <class G, int OPEN_BLOCKS, bool CODES>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
+                         int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps,
+                         uint32_t games_per_wave, uint32_t* __restrict__ codes_out) {
+    extern __shared__ uint32_t code_lds[];  // games_per_wave / 16 dwords per wave (also when the codes stay on the device)
+    __shared__ OpenedPool pools[BGS_BLOCK / BGS_WAVE];
+    constexpr uint32_t ONES = 0x11111111u;
+    const uint32_t top = (uint32_t)g.h() + 7u;
+    const uint32_t columns = g.w() >= 8 ? ONES : (ONES & ((1u << (4 * g.w())) - 1u));
+    const uint32_t stride = (uint32_t)g.h() + 1u;
+    const uint32_t column_top = 8u * columns;
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t begin = (int64_t)wave * games_per_wave;
+    const int64_t end = begin + games_per_wave < n ? begin + games_per_wave : n;
+    const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
+    uint32_t taken = 0;    // games handed to lanes
+    uint32_t opened = 0;   // games whose opening has been played (a multiple of 64)
+    uint64_t* __restrict__ const plane0 = planes + begin;
+    uint64_t* __restrict__ const plane1 = planes + n + begin;
+    OpenedPool& pool = pools[threadIdx.x >> 6];
+
+    uint64_t p[2] = {0, 0};
+    uint32_t hts = 0, blk = 0, live = 0, st = 0, game = 0, stepped = 0;
+
+    if (avail == 0u) return;
+    WaveCodes codes;
+    codes.init(code_lds, games_per_wave, avail);
+
+    // one full ply of sub-step J on (q, h4, op, alive, won_by); the body of K2a's block
+    auto full_ply = [&](auto j_tag, uint32_t draw, uint64_t (&q)[2], uint32_t& h4, uint32_t& op, uint32_t& alive,
+                        uint32_t& won_by) {
+        constexpr uint32_t J = decltype(j_tag)::value;
+        const uint32_t cnt = (uint32_t)__popc(op);
+        const uint32_t idx = sample_index(draw, cnt);
+        const uint32_t cmp = (uint32_t)((uint64_t)(idx - op) * ONES + 0x88888888ull);
+        uint32_t col = (uint32_t)__popc(cmp & column_top);
+        if (g.w() >= 8) col &= 7u;
+        const uint32_t sh = col * 4u;
+        const uint32_t v = (h4 >> sh) & 15u;
+        uint32_t base = col * stride + top;
+        asm("" : "+v"(base));
+        uint32_t pos = base - v;
+        if ((uint32_t)g.w() * stride + top > 63u) pos &= 63u;
+        const uint32_t act = alive;
+        uint64_t& mine = q[J & 1u];
+        const uint64_t bit = 1ull << pos;
+        mine = ((uint64_t)and_or((uint32_t)(bit >> 32), act, (uint32_t)(mine >> 32)) << 32) |
+               and_or((uint32_t)bit, act, (uint32_t)mine);
+        h4 += act << sh;
+        op = (h4 >> 3) & ONES;
+        bool won;
+        if (g.k() == 4) {
+            won = four_in_a_row_at(mine, g.h(), pos);
+        } else {
+            Bits<1> b;
+            b.w[0] = mine;
+            won = has_run(g, b);
+        }
+        stepped -= act;
+        won_by = won ? (J & 1u) + 1u : won_by;
+        alive = (won || op == 0u) ? 0u : alive;
+    };
+    // one opening ply: every column is open and nobody can win yet
+    auto cheap_ply = [&](uint32_t j, uint32_t draw, uint64_t (&q)[2], uint32_t& h4) {
+        const uint32_t col = sample_index(draw, (uint32_t)g.w());
+        const uint32_t sh = col * 4u;
+        const uint32_t v = (h4 >> sh) & 15u;
+        const uint32_t pos = col * stride + top - v;
+        q[j & 1u] |= 1ull << pos;
+        h4 -= 1u << sh;
+    };
+    // one philox block of four plies on this lane's board, then boards that ended go to memory (their status and
+    // reward follow from the codes)
+    auto play_block = [&]() {
+        const uint32_t was_live = live;
+        const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk);
+        uint32_t open = (hts >> 3) & ONES;
+        full_ply(std::integral_constant<uint32_t, 0>{}, draws.v[0], p, hts, open, live, st);
+        full_ply(std::integral_constant<uint32_t, 1>{}, draws.v[1], p, hts, open, live, st);
+        full_ply(std::integral_constant<uint32_t, 2>{}, draws.v[2], p, hts, open, live, st);
+        full_ply(std::integral_constant<uint32_t, 3>{}, draws.v[3], p, hts, open, live, st);
+        blk += 1u;
+        if (was_live != 0 && live == 0) {
+            *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane0) + (game * 8u)) = p[0];
+            *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane1) + (game * 8u)) = p[1];
+            codes.add(game, st ? st : BGS_ST_DRAW);  // no cap: a board that stopped without a winner is full
+        }
+    };
+
+    // ---- the chunk: idle lanes take the next opened games
+    while (taken < avail) {
+        const uint64_t need = __builtin_amdgcn_ballot_w64(live == 0);
+        if (need) {
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            if (taken + wanted > opened && opened < avail) {
+                // ---- the pool runs dry: all 64 lanes open the chunk's next 64 games
+                const uint32_t og = opened + lane;
+                const uint64_t id = first_game + (uint64_t)(begin + og);
+                uint64_t q[2] = {0, 0};
+                uint32_t h4 = top * columns, alive = ~0u, won_by = 0, op = columns;
+                {
+                    const Philox4 d = philox4x32_10(seed, id, 0u);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) cheap_ply(j, d.v[j], q, h4);
+                }
+                const uint32_t before = stepped;
+                if (OPEN_BLOCKS >= 2) {
+                    const Philox4 d = philox4x32_10(seed, id, 1u);
+                    cheap_ply(0u, d.v[0], q, h4);
+                    cheap_ply(1u, d.v[1], q, h4);
+                    op = (h4 >> 3) & ONES;
+                    full_ply(std::integral_constant<uint32_t, 2>{}, d.v[2], q, h4, op, alive, won_by);
+                    full_ply(std::integral_constant<uint32_t, 3>{}, d.v[3], q, h4, op, alive, won_by);
+                }
+#pragma unroll
+                for (uint32_t ob = 2; ob < (uint32_t)OPEN_BLOCKS; ++ob) {  // further blocks in lock step
+                    const Philox4 d = philox4x32_10(seed, id, ob);
+                    full_ply(std::integral_constant<uint32_t, 0>{}, d.v[0], q, h4, op, alive, won_by);
+                    full_ply(std::integral_constant<uint32_t, 1>{}, d.v[1], q, h4, op, alive, won_by);
+                    full_ply(std::integral_constant<uint32_t, 2>{}, d.v[2], q, h4, op, alive, won_by);
+                    full_ply(std::integral_constant<uint32_t, 3>{}, d.v[3], q, h4, op, alive, won_by);
+                }
+                if (og < avail) {
+                    stepped += OPEN_BLOCKS >= 2 ? 6u : 4u;
+                    if (OPEN_BLOCKS >= 2 && alive == 0) {  // ended inside the opening: a win, or a small board is full
+                        plane0[og] = q[0];
+                        plane1[og] = q[1];
+                        codes.add(og, won_by ? won_by : BGS_ST_DRAW);
+                    }
+                } else {
+                    stepped = before;  // a lane past the end of the chunk played for nobody
+                }
+                const uint32_t slot = og & (OpenedPool::SLOTS - 1u);
+                pool.plane[0][slot] = q[0];
+                pool.plane[1][slot] = q[1];
+                pool.cols[slot] = alive ? h4 : 0u;
+                opened += 64u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (live == 0 && taken + rank < avail) {
+                game = taken + rank;
+                const uint32_t slot = game & (OpenedPool::SLOTS - 1u);
+                p[0] = pool.plane[0][slot];
+                p[1] = pool.plane[1][slot];
+                hts = (uint32_t)pool.cols[slot];
+                st = 0;
+                blk = (uint32_t)OPEN_BLOCKS;
+                live = hts != 0u ? ~0u : 0u;  // (a dead slot: the opening stage has stored that game)
+            }
+            taken = avail - taken < wanted ? avail : taken + wanted;
+        }
+        play_block();
+    }
+    // ---- the drain: no games left to hand out, the boards in flight play to their end
+    while (__builtin_amdgcn_ballot_w64(live != 0)) play_block();
+
+    // ---- the chunk is done: its codes go out, and status / reward are expanded from them, 4 games per lane
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the ds_or of every lane before the reads below
+    __builtin_amdgcn_wave_barrier();
+    if (CODES) {
+        uint32_t* dst = codes_out + (begin >> 4);
+        for (uint32_t i = lane; i < codes.words; i += BGS_WAVE) dst[i] = codes.slice[i];
+    }
+    uint8_t* __restrict__ const status_out = status + begin;
+    uint16_t* __restrict__ const reward_out = reward + begin;
+    for (uint32_t g4 = lane * 4u; g4 < avail; g4 += BGS_WAVE * 4u) {
+        const uint32_t c = (codes.slice[g4 >> 4] >> (2u * (g4 & 15u))) & 255u;
+        if (g4 + 4u <= avail) {
+            const uint32_t c0 = c & 3u, c1 = (c >> 2) & 3u, c2 = (c >> 4) & 3u, c3 = c >> 6;
+            *reinterpret_cast<uint32_t*>(status_out + g4) = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+            uint2 r;
+            r.x = (uint32_t)reward_pair(c0) | ((uint32_t)reward_pair(c1) << 16);
+            r.y = (uint32_t)reward_pair(c2) | ((uint32_t)reward_pair(c3) << 16);
+            *reinterpret_cast<uint2*>(reward_out + g4) = r;
+        } else {
+            for (uint32_t k = 0; g4 + k < avail; ++k) {
+                const uint32_t ck = (c >> (2u * k)) & 3u;
+                status_out[g4 + k] = (uint8_t)ck;
+                reward_out[g4 + k] = reward_pair(ck);
+            }
+        }
+    }
+    add_steps(steps, stepped);
+}
+
 // K2b: the block-aligned, branch-free rollout for every other geometry (multi-word planes, up to 16 columns, up to 15
 // rows).  Same structure as K2a; column state is a nibble of height per column (64 bits) plus "column open" flags
 // kept nibble-spread in two 32-bit halves (columns 0-7 and 8-15), so the idx-th open column is one SWAR select inside
@@ -1351,7 +1565,7 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
     // resident waves: CUs x 4 SIMDs x waves per SIMD; every wave gets an equal contiguous chunk of games, a multiple
     // of 64 (whole dwords of outcome codes per wave, whole refill rounds)
     const int64_t resident = (int64_t)b->num_cus * 4 * b->rollout_wps;
-    int64_t per_wave = (b->n + resident - 1) / resident;
+    int64_t per_wave = b->rollout_chunk > 0 ? b->rollout_chunk : (b->n + resident - 1) / resident;
     per_wave = (per_wave + BGS_WAVE - 1) / BGS_WAVE * BGS_WAVE;
     const int64_t waves = (b->n + per_wave - 1) / per_wave;
     // the wave-private LDS slices of the fused codes: 4 waves x per_wave / 16 dwords per workgroup
@@ -1399,6 +1613,31 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
                                            b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr);
                     }
                 };
+                if ((flags & 1u) && !capped && b->rollout_opening && b->cg.h >= 4 && b->cg.w >= 2 && b->cg.k >= 3 &&
+                    code_lds <= (32u << 10)) {
+                    // from the initial state, no cap: the kernel with the lock-step opening stage (K2o)
+                    auto launch_opened = [&](auto blocks_tag, auto codes_tag) {
+                        constexpr int OPEN_BLOCKS = decltype(blocks_tag)::value;
+                        constexpr bool CODES = decltype(codes_tag)::value;
+                        hipLaunchKernelGGL((k_connect_rollout_opened<G, OPEN_BLOCKS, CODES>), dim3(blocks), dim3(BGS_BLOCK),
+                                           code_lds, b->stream, g, b->d_planes, b->d_status,
+                                           reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, b->d_steps,
+                                           (uint32_t)per_wave, CODES ? codes_out : nullptr);
+                        fused = CODES;
+                    };
+                    const bool deep = b->cg.k >= 4 && b->cg.h >= 6;
+                    auto with_blocks = [&](auto blocks_tag) {
+                        if (fuse_codes) launch_opened(blocks_tag, std::true_type{});
+                        else launch_opened(blocks_tag, std::false_type{});
+                    };
+                    switch (deep ? b->rollout_opening : 1) {
+                        case 1: with_blocks(std::integral_constant<int, 1>{}); break;
+                        case 2: with_blocks(std::integral_constant<int, 2>{}); break;
+                        case 3: with_blocks(std::integral_constant<int, 3>{}); break;
+                        default: with_blocks(std::integral_constant<int, 4>{}); break;
+                    }
+                    return;
+                }
                 if (flags & 1u) {
                     if (capped) launch_aligned(std::true_type{}, std::true_type{});
                     else launch_aligned(std::false_type{}, std::true_type{});

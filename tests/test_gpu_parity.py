@@ -237,6 +237,50 @@ def test_connect_large_board_full_size(batch_mod):
     np.testing.assert_array_equal(dev.plies, orc.plies)
 
 
+@pytest.mark.parametrize("mode", ["opening0", "opening1", "opening2", "opening3", "opening4", "generic"])
+def test_connect_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
+    """Every from-the-initial-state rollout kernel for one-word boards on the same batches: K2a (no opening stage), K2o
+    with one and with two opening blocks, and the any-geometry kernel -- boards, rewards, step count and the fused
+    outcome codes.  Geometries on both sides of the opening stage's conditions (H >= 4, W >= 2, K >= 3; two blocks need
+    K >= 4 and H >= 6), ragged sizes, a chunk that ends inside a round of 64."""
+    import os
+
+    env = {"opening0": {"BGS_ROLLOUT_OPENING": "0"}, "opening1": {"BGS_ROLLOUT_OPENING": "1"},
+           "opening2": {"BGS_ROLLOUT_OPENING": "2"}, "opening3": {"BGS_ROLLOUT_OPENING": "3"},
+           "opening4": {"BGS_ROLLOUT_OPENING": "4"}, "generic": {"BGS_ROLLOUT_GENERIC": "1"}}[mode]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for (h, w, k), n in [((6, 7, 4), 70001), ((6, 7, 4), 63), ((4, 2, 3), 5000), ((5, 5, 3), 4097), ((8, 8, 4), 9999),
+                             ((6, 2, 4), 3000), ((7, 8, 5), 8191), ((3, 7, 3), 2000), ((6, 1, 4), 500), ((6, 7, 2), 1000),
+                             ((8, 3, 4), 2222)]:
+            dev = batch_mod.ConnectBatch(h, w, k, n)
+            orc = oracle.ConnectOracle(h, w, k, n)
+            dev.set_first_game(1 << 33)
+            dev.rollout(SEED ^ 9, from_initial=True)
+            total = orc.rollout(SEED ^ 9, first_game=1 << 33)
+            assert_same(dev, orc, f"{mode} {h}x{w}x{k} n={n}")
+            assert dev.steps == total
+            # the same launch with the outcome codes delivered by the kernel
+            import torch
+
+            packed = torch.zeros((n + 63) // 64 * 16, dtype=torch.uint8, device="cuda")
+            dev.reset()
+            dev.rollout_outcomes_tensor(packed, SEED ^ 10, from_initial=True)
+            orc.reset()
+            orc.rollout(SEED ^ 10, first_game=1 << 33)
+            host = batch_mod.expand_outcomes_host(packed.cpu().numpy(), n)
+            np.testing.assert_array_equal(host, orc.reward)
+            assert_same(dev, orc, f"{mode} {h}x{w}x{k} n={n} with codes")
+            dev.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("mode", ["1", "8", "1:nested", "passes"])
 def test_bounce_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
     """Every fused Bounce rollout kernel on the same mid-size batch: one lane per board with the flattened search and

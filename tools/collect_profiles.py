@@ -24,7 +24,7 @@ def main():
     build = _abi.build_id()
     method = ("tools/profile_all.sh: rocprofv3 --kernel-trace --stats, then --pmc in separate passes (SQ_*; FETCH_SIZE; "
               "WRITE_SIZE), per-dispatch means; FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads), KiB -> B")
-    for tag, want, name in (("bench", "k_connect_rollout_aligned", "r02_bench_kernel.json"), ("k1", "step_random", "r02_k1.json"),
+    for tag, want, name in (("bench", "k_connect_rollout_opened", "r02_bench_kernel.json"), ("k1", "step_random", "r02_k1.json"),
                             ("k2c", "k_connect_rollout_lds", "r02_k2c.json"), ("k2b", "k_connect_rollout_aligned_wide", "r02_k2b.json"),
                             ("bounce", "k_bounce_rollout", "r02_bounce.json"), ("bounce8", "k_bounce_rollout", "r02_bounce_lane_groups.json")):
         s = summary(tag, want)
@@ -41,10 +41,17 @@ def main():
     if os.path.exists(mfile) and os.path.getsize(mfile):
         with open(mfile) as fh, open(os.path.join(OUT, "r02_secondary_measurements.json"), "w") as out:
             out.write(fh.read())
-    bench = summary("bench", "k_connect_rollout_aligned")
+    bench = summary("bench", "k_connect_rollout_opened")
     k = next(iter(bench.values()))
     with open(os.path.join(ROOT, "gpurun_out", "valu_mix.json")) as fh:
         mix = json.load(fh)
+    # dynamic mix: the opening block runs once per 64 games, the loop body makes up the rest of the VALU instructions
+    openings = (1 << 20) / 64.0
+    n_open = openings * mix["opening_block"]["valu_instructions"]
+    n_loop = max(k["SQ_INSTS_VALU"] - n_open, 0.0)
+    mix_cpi = (n_open * mix["opening_block"]["mix_cycles_per_instruction"] +
+               n_loop * mix["loop_body"]["mix_cycles_per_instruction"]) / (n_open + n_loop)
+    mix["weights"] = {"opening_block_instructions_per_launch": n_open, "loop_and_other_instructions_per_launch": n_loop}
     counters = {
         "build_id": build,
         "kernel": next(iter(bench)),
@@ -56,7 +63,7 @@ def main():
         "FETCH_SIZE_KiB": k["FETCH_SIZE"],
         "WRITE_SIZE_KiB": k["WRITE_SIZE"],
         "hbm_bytes_per_launch": hbm_bytes(k),
-        "mix_cycles_per_instruction": mix["mix_cycles_per_instruction"],
+        "mix_cycles_per_instruction": mix_cpi,
         "mix": mix,
         "method": method + "; command: python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-device-resident; "
         "mix_cycles_per_instruction from tools/valu_mix.py",

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Issue cost of a kernel's instruction mix: the VALU instructions of its hottest basic block (the rollout loop body)
-weighted by the per-instruction issue costs measured on gfx950 with tools/ubench.hip (4 waves per SIMD; committed as
+"""Issue cost of a kernel's instruction mix: the VALU instructions of its two hot basic blocks (the opening stage and the
+rollout loop body of K2o; tools/collect_profiles.py weights them by how often each runs) weighted by the per-instruction issue costs measured on gfx950 with tools/ubench.hip (4 waves per SIMD; committed as
 profiles/r01_ubench_valu_issue.txt).  mix_cycles_per_instruction feeds bench.py's `valu_issue.mix_ceiling`: the rate
 the VALU could sustain on THIS mix, as opposed to the guide's 2-cycle SIMD-32 peak that only plain VOP2 streams reach.
 
@@ -28,17 +28,27 @@ CMP_COST = 3.5  # v_cmp_* (+ its v_cndmask partner: 7.09 per pair measured)
 DEFAULT = 4.4   # unlisted VOP3
 
 
-def mix(path, sym):
-    best = max(blocks(path, sym), key=lambda nb: len(nb[1]))[1]
+def block_mix(body):
     ops = Counter()
-    for line in best:
+    for line in body:
         op = line.split()[0]
         if op.startswith("v_"):
             ops[re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)] += 1
     total = sum(ops.values())
     cycles = sum(n * (CMP_COST if op.startswith("v_cmp") else COST.get(op, DEFAULT)) for op, n in ops.items())
-    return {"valu_instructions_in_loop_body": total, "mix_cycles_per_instruction": cycles / total,
-            "top_opcodes": dict(ops.most_common(12))}
+    return {"valu_instructions": total, "mix_cycles_per_instruction": cycles / total, "top_opcodes": dict(ops.most_common(12))}
+
+
+def mix(path, sym):
+    """The two big basic blocks of K2o: the opening stage (run once per 64 games) and the 4-ply loop body."""
+    big = sorted(blocks(path, sym), key=lambda nb: -len(nb[1]))[:2]
+    opening, loop = (block_mix(big[0][1]), block_mix(big[1][1]))
+    if opening["valu_instructions"] < loop["valu_instructions"]:
+        opening, loop = loop, opening
+    return {"opening_block": opening, "loop_body": loop,
+            # (kept for readers of round-2 files: the loop body's figures under the old names)
+            "valu_instructions_in_loop_body": loop["valu_instructions"],
+            "mix_cycles_per_instruction": loop["mix_cycles_per_instruction"]}
 
 
 if __name__ == "__main__":
@@ -48,6 +58,6 @@ if __name__ == "__main__":
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
                                os.path.join(csrc, "connect_kernels.hip"), "-o", out, "-Wno-unused-function"],
                               stderr=subprocess.DEVNULL)
-        # the bench kernel: Connect4(6,7,4), uncapped, from the initial state, outcome codes fused
-        sym = "_ZN3bgs12_GLOBAL__N_125k_connect_rollout_alignedINS0_3GeoILi1ELi6ELi7ELi4EEELb0ELb1ELb1EEE"
+        # the bench kernel: Connect4(6,7,4), uncapped, from the initial state, 3 opening blocks, outcome codes fused
+        sym = "_ZN3bgs12_GLOBAL__N_124k_connect_rollout_openedINS0_3GeoILi1ELi6ELi7ELi4EEELi3ELb1EEE"
         print(json.dumps(mix(out, sym), indent=1))

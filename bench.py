@@ -323,10 +323,15 @@ def main() -> int:
             if stride and i % stride == 0:
                 ev = evs[i] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             one_step(first_step + i, with_handover, ev)
+        t_enqueued = time.perf_counter()
         if with_handover:
             drain()  # every step's rewards are in their host array before the clock stops
+        t_drained = time.perf_counter()
         barrier()
         dt = time.perf_counter() - t0
+        if os.environ.get("BGS_BENCH_TRACE"):
+            print(f"[trace] {count} steps, handover={with_handover}: enqueued at {(t_enqueued - t0) * 1e3:.3f} ms, "
+                  f"rewards on the host at {(t_drained - t0) * 1e3:.3f} ms, device idle at {dt * 1e3:.3f} ms", file=sys.stderr)
         steps_local = sum(b.steps for b in batches)
         kernel_ms = sum(s.elapsed_time(e) for s, e in evs.values()) / max(len(evs), 1) if evs else None
         return dt, steps_local, kernel_ms

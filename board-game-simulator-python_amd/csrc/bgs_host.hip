@@ -12,6 +12,7 @@
 #include <immintrin.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -138,6 +139,28 @@ struct bgs_reward_sink {
     bool failed = false;
     bool poll = false;                   // worker 0 polls the slot's event instead of sleeping on it (BGS_SINK_POLL=1)
     std::vector<std::thread> workers;
+    // Lock-free mirrors of the three counters: a waiter may spin on them for up to spin_us microseconds before it
+    // sleeps on the condition variable (BGS_SINK_SPIN_US; default 0 = sleep at once).  Measured on the bench, spinning
+    // buys nothing -- with 2 x depth slots the pipeline has enough slack to hide a sleeper's wake-up, and at the end of
+    // a run the tail is the last kernels and hipDeviceSynchronize, not the wake-ups -- so the default leaves the cores
+    // alone; the knob stays for callers with one batch in flight.  The counters themselves stay under mu.
+    std::atomic<int64_t> a_submitted{0}, a_landed{0}, a_completed{0};
+    std::atomic<bool> a_stop{false};
+    int spin_us = 0;
+
+    // true once counter > ticket (or stop); false when the spin budget ran out
+    bool spin_for(const std::atomic<int64_t>& counter, int64_t ticket) const {
+        if (counter.load(std::memory_order_acquire) > ticket) return true;
+        if (spin_us <= 0) return false;
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
+        for (;;) {
+            for (int i = 0; i < 64; ++i) {
+                if (counter.load(std::memory_order_acquire) > ticket || a_stop.load(std::memory_order_relaxed)) return true;
+                _mm_pause();
+            }
+            if (std::chrono::steady_clock::now() >= until) return false;
+        }
+    }
 
     // Worker 0 is the only thread that waits in the HIP runtime: it sleeps until a job is published, waits for the
     // slot's event, then releases the others.  (Every worker waiting on the event itself kept several cores spinning
@@ -149,6 +172,7 @@ struct bgs_reward_sink {
             Job job;
             bool ok = true;
             if (t == 0) {
+                spin_for(a_submitted, ticket);
                 {
                     std::unique_lock<std::mutex> lock(mu);
                     cv_submit.wait(lock, [&] { return stop || submitted > ticket; });
@@ -168,19 +192,27 @@ struct bgs_reward_sink {
                     std::lock_guard<std::mutex> lock(mu);
                     if (!ok) failed = true;
                     landed_upto = ticket + 1;
+                    a_landed.store(ticket + 1, std::memory_order_release);
                 }
                 cv_landed.notify_all();
             } else {
+                spin_for(a_landed, ticket);
                 std::unique_lock<std::mutex> lock(mu);
                 cv_landed.wait(lock, [&] { return stop || landed_upto > ticket; });
                 if (landed_upto <= ticket) return;  // stop, nothing left
                 job = jobs[slot];  // published before its event could complete, and not reused before this job is done
                 ok = !failed;
             }
+            // With more than one thread, worker 0 only waits and releases: while the others expand job k it is already
+            // in the runtime waiting for job k + 1, so the event latency of a job overlaps the expansion of the one
+            // before it (and at the end of a run the last few jobs, whose kernels finish together, are released at once)
+            const int expanders = threads > 1 ? threads - 1 : 1;
+            const int share = threads > 1 ? t - 1 : 0;
+            if (threads > 1 && t == 0) continue;
             if (ok) {
                 // shares are multiples of 4 games (one code byte), so threads never touch the same output word
                 const int64_t bytes = (job.n_games + 3) / 4;
-                const int64_t b0 = bytes * t / threads, b1 = bytes * (t + 1) / threads;
+                const int64_t b0 = bytes * share / expanders, b1 = bytes * (share + 1) / expanders;
                 const int64_t first = b0 * 4;
                 int64_t count = b1 * 4 - first;
                 if (first + count > job.n_games) count = job.n_games - first;
@@ -188,9 +220,10 @@ struct bgs_reward_sink {
             }
             {
                 std::lock_guard<std::mutex> lock(mu);
-                if (++parts_done[slot] == threads) {
+                if (++parts_done[slot] == expanders) {
                     parts_done[slot] = 0;
                     ++completed;  // jobs complete in ticket order: every worker walks the tickets in order
+                    a_completed.store(completed, std::memory_order_release);
                     cv_done.notify_all();
                 }
             }
@@ -202,6 +235,7 @@ namespace {
 
 // claim the next ticket's slot, waiting while the ring is full; returns the slot
 int64_t claim(bgs_reward_sink* s) {
+    s->spin_for(s->a_completed, s->a_submitted.load(std::memory_order_relaxed) - s->slots);
     std::unique_lock<std::mutex> lock(s->mu);
     s->cv_done.wait(lock, [&] { return s->submitted - s->completed < s->slots; });
     return s->submitted;
@@ -213,6 +247,7 @@ void publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_r
         s->jobs[ticket % s->slots].n_games = n_games;
         s->jobs[ticket % s->slots].host_reward = host_reward;
         s->submitted = ticket + 1;
+        s->a_submitted.store(ticket + 1, std::memory_order_release);
     }
     s->cv_submit.notify_one();  // only worker 0 waits here
 }
@@ -328,6 +363,10 @@ int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_r
     s->threads = threads;
     s->jobs.resize(slots);
     if (const char* env = getenv("BGS_SINK_POLL")) s->poll = atoi(env) != 0;
+    if (const char* env = getenv("BGS_SINK_SPIN_US")) {
+        const int v = atoi(env);
+        if (v >= 0 && v <= 1000000) s->spin_us = v;
+    }
     s->parts_done.assign(slots, 0);
     const size_t bytes = (size_t)(max_games + 63) / 64 * 16;  // whole 16-byte units: kernels store codes dword- / uint4-wise
     hipError_t err = hipSuccess;
@@ -359,6 +398,7 @@ int bgs_sink_destroy(bgs_reward_sink* s) {
         std::unique_lock<std::mutex> lock(s->mu);
         s->cv_done.wait(lock, [&] { return s->completed == s->submitted; });  // let published jobs finish
         s->stop = true;
+        s->a_stop.store(true, std::memory_order_release);
     }
     s->cv_submit.notify_all();
     s->cv_landed.notify_all();
@@ -422,8 +462,9 @@ int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* dev
 
 int bgs_sink_wait(bgs_reward_sink* s, int64_t ticket) {
     NEED(s != nullptr, "sink is NULL");
+    NEED(ticket >= 0 && ticket < s->a_submitted.load(std::memory_order_acquire), "unknown ticket %lld", (long long)ticket);
+    s->spin_for(s->a_completed, ticket);
     std::unique_lock<std::mutex> lock(s->mu);
-    NEED(ticket >= 0 && ticket < s->submitted, "unknown ticket %lld", (long long)ticket);
     s->cv_done.wait(lock, [&] { return s->completed > ticket; });
     if (s->failed) return fail(BGS_ERR_RUNTIME, "a reward copy failed (hipEventSynchronize)");
     return BGS_OK;

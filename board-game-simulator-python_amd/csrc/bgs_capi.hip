@@ -239,7 +239,7 @@ int device_facts(bgs_batch* b) {
     // waves for latency hiding.
     {
         const int64_t lanes_per_wps = (int64_t)b->num_cus * 4 * BGS_WAVE;
-        const int64_t games_per_lane = (b->game == BGS_GAME_CONNECT && b->cg.nw == 1) ? 8 : 4;
+        const int64_t games_per_lane = (b->game == BGS_GAME_CONNECT && b->cg.nw == 1) ? kGamesPerLaneOneWord : kGamesPerLane;
         int64_t wps = b->n / (lanes_per_wps * games_per_lane);
         const int64_t floor_wps = (b->game == BGS_GAME_CONNECT && b->cg.nw == 1) ? 2 : 1;
         if (wps < floor_wps) wps = floor_wps;
@@ -257,7 +257,7 @@ int device_facts(bgs_batch* b) {
     }
     b->rollout_generic = getenv("BGS_ROLLOUT_GENERIC") != nullptr;
     b->rollout_no_lds = getenv("BGS_ROLLOUT_NO_LDS") != nullptr;
-    b->rollout_opening = 3;
+    b->rollout_opening = kRolloutOpeningBlocks;
     if (const char* e = getenv("BGS_ROLLOUT_OPENING")) {
         const int v = atoi(e);
         if (v >= 0 && v <= 4) b->rollout_opening = v;

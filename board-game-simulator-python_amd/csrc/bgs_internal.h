@@ -38,6 +38,12 @@ struct BounceGeom {
     uint32_t init_status;    // 0, or the terminal code of a start position without legal moves
 };
 
+// Launch tuning of the fused rollouts.  These live here (a header the build id hashes) and not in bgs_capi.hip because
+// they change what a launch executes: counters taken under one setting must not be quoted for another.
+constexpr int kRolloutOpeningBlocks = 3;    // K2o: 4-ply blocks played in lock step before a board joins the refill loop
+constexpr int kGamesPerLaneOneWord = 8;     // one-word Connect boards: games per lane a launch aims for (512 per wave at 2^20)
+constexpr int kGamesPerLane = 4;            // every other rollout
+
 struct bgs_batch {
     int game;
     int generic;             // 1: the board is an int8 grid in the reference layout, played by generic_kernels.hip

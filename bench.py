@@ -22,10 +22,12 @@ Hand-over (`--handover`):
   none   rewards stay on the device (the round-1 measurement; reported as `device_resident` beside `value` otherwise).
 
 N > 1: one process per GPU, rank r owns global game ids [r * 2^20, (r+1) * 2^20) (RNG streams are keyed by global
-game id, so the shards reproduce the unsharded run); the only collective per step is the reward gather: RCCL gather of
-the ranks' 2-bit outcome codes to rank 0 (256 KiB per rank over xGMI), whose sink copies them to the host and expands
-them into THE one array int8[N * 2^20, 2]; plus one all-reduce of the step counters after the timed region.  Weak
-scaling.
+game id, so the shards reproduce the unsharded run).  The only exchange is the hand-over into THE one host array
+int8[N * 2^20, 2] (`--gather`): by default that array lives in shared memory mapped by every rank of the node and each
+rank's own sink delivers its rows -- the one-GPU loop on every rank, every GPU on its own PCIe link, no collective in the
+data path (simulator/sharding.py: SharedRewardRing); `--gather rccl` gathers the ranks' 2-bit outcome codes to rank 0's
+GPU over RCCL (256 KiB per rank over xGMI), whose sink copies them to the host and expands them all.  Plus one
+all-reduce of the step counters after the timed region.  Weak scaling.
 
 Steps run on `--inflight` batches / HIP streams in rotation: a rollout is bound by VALU instruction issue, its drain
 (the last game of every lane) leaves SIMDs idle that the next launch fills, and the copy engine and the host workers
@@ -144,10 +146,17 @@ def main() -> int:
     ap.add_argument("--host-threads", type=int, default=0,
                     help="worker threads of the reward sink (--handover codes); 0 = 6 on one GPU, min(12, 4 + 2 N) on N "
                     "(rank 0 expands N x 2 MiB of rewards per step: tools/sink_rate.py)")
+    ap.add_argument("--gather", default="shm",
+                    help="N > 1: how the ranks' rewards reach the one host array. shm (default): the array is in shared "
+                         "memory and every rank's own sink delivers its rows (no collective, every GPU uses its own PCIe "
+                         "link); rccl: outcome codes gathered to rank 0's GPU over RCCL, rank 0's sink expands them all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-resident", action="store_true",
                     help="skip the extra, separately timed pass without hand-over that fills `device_resident`")
     args = ap.parse_args()
+    if args.gather not in ("shm", "rccl"):
+        print("bench.py: --gather must be shm or rccl", file=sys.stderr)
+        return 2
 
     import numpy as np
     import torch
@@ -170,7 +179,7 @@ def main() -> int:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
-    # BGS_FORCE_DIST=1 takes the N > 1 code path (process group, per-step RCCL gather, rank-0 sink) with whatever world
+    # BGS_FORCE_DIST=1 takes the N > 1 code path (process group; shared host array or per-step RCCL gather) with whatever world
     # size the launcher gave, 1 included: the way to run that path over RCCL on a one-GPU box
     sharded = world > 1 or os.environ.get("BGS_FORCE_DIST") == "1"
     if sharded:
@@ -183,10 +192,12 @@ def main() -> int:
 
     from simulator.batch import ConnectBatch, HostEvent, PinnedArray, RewardSink, expand_outcomes_host
     from simulator.game import _abi
-    from simulator.sharding import gather_outcomes_to, shard_range, sum_steps
+    from simulator.sharding import SharedRewardRing, gather_outcomes_to, shard_range, sum_steps
 
+    # N > 1, default: one host array in shared memory, every rank delivers its own rows with its own sink
+    ring_mode = sharded and args.gather == "shm" and args.handover == "codes"
     if args.host_threads <= 0:
-        args.host_threads = 6 if world == 1 else min(12, 4 + 2 * world)
+        args.host_threads = 6 if world == 1 else 4 if ring_mode else min(12, 4 + 2 * world)
     n = args.batch
     if sharded and n % 4:
         print("bench.py: --batch must be a multiple of 4 when sharded (4 outcome codes per byte)", file=sys.stderr)
@@ -205,18 +216,22 @@ def main() -> int:
     # One GPU: the hand-over pipeline is deeper than the GPU's (twice as many host arrays / sink slots as streams), so
     # the launching thread waits for the delivery of step i - 2 * depth, not i - depth, before it enqueues step i:
     # waiting on the previous step of the SAME stream would leave the GPU one batch short for the length of the delivery
-    host_slots = depth if sharded else 2 * depth
+    host_slots = depth if sharded and not ring_mode else 2 * depth
+    ring = SharedRewardRing(dist, n, host_slots) if ring_mode else None
     batches, packed, packed_buf, all_packed, host_rewards, events = [], [], [], [], [], []
     for s in streams:
         with torch.cuda.stream(s):
             b = ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=local_rank, use_torch=True)  # ordered onto stream s
             b.set_first_game(shard_range(n * world, rank, world)[0])
             batches.append(b)
-            packed_buf.append(torch.zeros((n + 63) // 64 * 16, dtype=torch.uint8, device=gpu) if sharded else None)
-            packed.append(packed_buf[-1][:code_bytes] if sharded else None)
-            all_packed.append(torch.empty(world * code_bytes, dtype=torch.uint8, device=gpu) if sharded and owner else None)
-    for _ in range(host_slots):
-        if handover == "pairs":
+            packed_buf.append(torch.zeros((n + 63) // 64 * 16, dtype=torch.uint8, device=gpu) if sharded and not ring_mode else None)
+            packed.append(packed_buf[-1][:code_bytes] if sharded and not ring_mode else None)
+            all_packed.append(torch.empty(world * code_bytes, dtype=torch.uint8, device=gpu) if sharded and owner and not ring_mode else None)
+    for slot in range(host_slots):
+        if ring_mode:
+            host_rewards.append(ring.mine(slot))  # this rank's rows of the shared array (touched by the ring already)
+            events.append(None)
+        elif handover == "pairs":
             host_rewards.append(PinnedArray((n, 2), np.int8))
             events.append(HostEvent(local_rank))
         elif handover == "codes" and owner:
@@ -226,8 +241,11 @@ def main() -> int:
         else:
             host_rewards.append(None)
             events.append(None)
-    sink = RewardSink(world * n, slots=host_slots, threads=max(1, args.host_threads), device=local_rank) \
-        if handover == "codes" and owner else None
+    if ring_mode:
+        sink = RewardSink(n, slots=host_slots, threads=max(1, args.host_threads), device=local_rank)
+    else:
+        sink = RewardSink(world * n, slots=host_slots, threads=max(1, args.host_threads), device=local_rank) \
+            if handover == "codes" and owner else None
     device = gpu if backend == "nccl" else torch.device("cpu")
 
     def barrier():
@@ -237,6 +255,7 @@ def main() -> int:
             torch.cuda.synchronize()
 
     tickets = [None] * host_slots  # the sink ticket of the step last delivered into each host array
+    ticket_step = [0] * host_slots  # (shared array: the step that ticket belongs to, published once it is delivered)
     pending = [None] * depth       # the in-flight reward gather of each stream slot (N > 1)
 
     def settle(k, final=False):
@@ -247,6 +266,8 @@ def main() -> int:
         if tickets[k] is not None:      # the step submitted to the sink one turn ago: its rewards are in the host array
             sink.wait(tickets[k])
             tickets[k] = None
+            if ring is not None:
+                ring.publish(ticket_step[k])  # this rank's rows of that step are in the shared array
         if k < depth and pending[k] is not None:      # the gather started one turn ago
             pending[k].wait()           # (only makes stream k wait for the collective)
             pending[k] = None
@@ -266,8 +287,9 @@ def main() -> int:
     def one_step(i, with_handover, ev=None):
         k = i % depth
         b = batches[k]
-        if dist is None:
-            # one GPU: library calls only (each batch is bound to its own stream), no torch stream switching
+        if dist is None or ring_mode:
+            # one GPU, or N GPUs delivering into the shared host array (every rank runs the one-GPU loop on its rows):
+            # library calls only (each batch is bound to its own stream), no torch stream switching
             h = i % host_slots
             if with_handover:
                 settle(h)
@@ -277,6 +299,7 @@ def main() -> int:
                 b.rollout(SEED + i, from_initial=True)
             elif handover == "codes":
                 tickets[h] = sink.rollout(b, host_rewards[h], SEED + i, from_initial=True)
+                ticket_step[h] = i
             else:
                 b.rollout_to_host(host_rewards[h], SEED + i, from_initial=True, codes=False, event=events[h])
                 events[h].armed = True
@@ -356,7 +379,8 @@ def main() -> int:
     final_host = None
     if owner and handover != "none":
         slot = last % host_slots
-        final_host = np.array(host_rewards[slot].array if handover == "pairs" else host_rewards[slot])
+        final_host = np.array(ring.array(slot) if ring is not None else
+                              host_rewards[slot].array if handover == "pairs" else host_rewards[slot])
 
     gather_ok = None
     if dist is not None and owner:
@@ -435,8 +459,11 @@ def main() -> int:
                              f"{args.host_threads} host threads expand into int8[{world * n}, 2]",
                              "pairs": f"int8[{n}, 2] reward buffer ({2 * n} B per step over PCIe) -> page-locked host array",
                              "none": "rewards stay on the device"}[handover],
-                "sharding": f"game ids split over {world} rank(s); per step {'RCCL' if backend == 'nccl' else backend} gather of "
-                f"2-bit outcome codes ({code_bytes} B per rank) to rank 0" if sharded else "single GPU",
+                "sharding": (f"game ids split over {world} rank(s); no data-path collective: the host array int8[{world * n}, 2] is "
+                             f"in shared memory and every rank's own sink delivers its rows ({code_bytes} B of codes per step "
+                             f"over the rank's own PCIe link, {args.host_threads} host threads per rank)" if ring_mode else
+                             f"game ids split over {world} rank(s); per step {'RCCL' if backend == 'nccl' else backend} gather of "
+                             f"2-bit outcome codes ({code_bytes} B per rank) to rank 0" if sharded else "single GPU"),
                 "gathered_rewards_verified": gather_ok,
                 "inflight_batches": depth,
                 "waves_per_simd_per_launch": int(os.environ["BGS_ROLLOUT_WPS"]),

@@ -3,13 +3,23 @@
 Boards never interact, so the path partitions without any data-path exchange: rank r of R owns the contiguous
 global game ids [r * per_rank, (r + 1) * per_rank).  RNG streams are keyed by GLOBAL game id
 (``Batch.set_first_game``), so the union of the shards is bit-identical to the unsharded run for any R.
-The single collective is the reward gather to the rank that owns the host array: ranks contribute their 2-bit outcome
-codes (`gather_outcomes_to`; `gather_rewards` ships int8 pairs to every rank instead); torch.distributed's "nccl"
-backend is RCCL on ROCm (xGMI between the GPUs of a node), "gloo" runs the same code on CPUs in tests.
+The single exchange is the hand-over of the rewards to the ONE host array, and there are two ways to do it:
+
+* `SharedRewardRing` (ranks on one node; bench.py's default for N > 1): the host array lives in shared memory mapped by
+  every rank, and each rank's own reward sink delivers its games into its rows -- every GPU uses its OWN PCIe link
+  (0.25 B per game of outcome codes) and its own host threads for the expansion, nothing funnels through rank 0's GPU;
+* `gather_outcomes_to` (any topology): ranks contribute their 2-bit outcome codes to rank 0's GPU over RCCL (xGMI inside
+  a node), whose sink copies them to the host and expands all of them -- at 8 GPUs that is 2 MiB per step over one PCIe
+  link and 16 MiB of host writes per step by one process (`gather_rewards` ships int8 pairs to every rank instead).
+torch.distributed's "nccl" backend is RCCL on ROCm, "gloo" runs the same code on CPUs in tests.
 """
 
 from __future__ import annotations
 
+import mmap
+import os
+import time
+import uuid
 from typing import Tuple
 
 
@@ -21,6 +31,84 @@ def shard_range(total_games: int, rank: int, world: int) -> Tuple[int, int]:
         raise ValueError(f"{total_games} games do not split evenly over {world} ranks")
     per_rank = total_games // world
     return rank * per_rank, per_rank
+
+
+class SharedRewardRing:
+    """`slots` host arrays int8[world * per_rank, 2] in ONE shared-memory segment mapped by every rank of a node, plus a
+    progress word per rank.
+
+    Rank r delivers step s into `mine(s % slots)` (rows [r * per_rank, (r + 1) * per_rank) of `array(s % slots)`, e.g.
+    as the destination of `RewardSink.rollout`) and calls `publish(s)`; the consumer -- any rank, normally rank 0 --
+    calls `wait_all(s)` and then reads `array(s % slots)`: every rank's rewards of step s, in global game order.
+    The segment is a file in /dev/shm that rank 0 creates and unlinks as soon as everybody has mapped it, so nothing
+    is left behind however the processes end.  `dist` (torch.distributed, initialised) only carries the name and one
+    barrier at construction; the data path has no collective."""
+
+    def __init__(self, dist, per_rank: int, slots: int, directory: str = "/dev/shm"):
+        import numpy as np
+
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.per_rank, self.slots = int(per_rank), int(slots)
+        if self.per_rank < 1 or self.slots < 1:
+            raise ValueError("per_rank and slots must be positive")
+        self._slot_bytes = self.world * self.per_rank * 2
+        data = -(-self.slots * self._slot_bytes // 4096) * 4096
+        total = data + 64 * self.world  # one cache line of progress per rank
+        name = [os.path.join(directory, f"bgs_rewards_{os.getpid()}_{uuid.uuid4().hex}") if self.rank == 0 else None]
+        fd = -1
+        if self.rank == 0:
+            fd = os.open(name[0], os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            os.ftruncate(fd, total)
+        dist.broadcast_object_list(name, src=0)
+        try:
+            if self.rank != 0:
+                fd = os.open(name[0], os.O_RDWR)
+            self._map = mmap.mmap(fd, total, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
+        finally:
+            if fd >= 0:
+                os.close(fd)
+            dist.barrier()  # everybody has mapped (or failed): the name can go
+            if self.rank == 0:
+                os.unlink(name[0])
+        buf = np.frombuffer(self._map, dtype=np.int8, count=self.slots * self._slot_bytes)
+        self._arrays = buf.reshape(self.slots, self.world * self.per_rank, 2)
+        self._progress = np.frombuffer(self._map, dtype=np.int64, count=8 * self.world, offset=data).reshape(self.world, 8)
+        # first touch by the rank that will write the rows: the pages land on that rank's NUMA node
+        for k in range(self.slots):
+            self.mine(k)[...] = 0x55
+        if self.rank == 0:
+            self._progress[...] = 0
+        dist.barrier()
+
+    def array(self, slot: int):
+        """int8[world * per_rank, 2]: the host array of `slot` (every rank's rows)."""
+        return self._arrays[slot]
+
+    def mine(self, slot: int):
+        """int8[per_rank, 2]: this rank's rows of `array(slot)` (C-contiguous: a valid sink destination)."""
+        return self._arrays[slot, self.rank * self.per_rank : (self.rank + 1) * self.per_rank]
+
+    def publish(self, step: int) -> None:
+        """This rank's rewards of every step <= `step` are in their host arrays."""
+        self._progress[self.rank, 0] = step + 1
+
+    def done(self, step: int) -> bool:
+        return bool((self._progress[:, 0] > step).all())
+
+    def wait_all(self, step: int, timeout: float = 60.0) -> None:
+        """Block until every rank has published `step`."""
+        deadline = time.monotonic() + timeout
+        while not self.done(step):
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"ranks {[int(r) for r in (self._progress[:, 0] <= step).nonzero()[0]]} have not delivered step {step}")
+            time.sleep(0)
+
+    def close(self) -> None:
+        self._arrays = self._progress = None
+        try:
+            self._map.close()
+        except BufferError:  # a caller still holds a view: the mapping goes with the process
+            pass
 
 
 def gather_rewards(dist, local_reward, out=None):

@@ -477,37 +477,45 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_bench_two_ranks_gloo_rehearsal():
-    """bench.py's own N > 1 loop (shards, per-step gather of codes to rank 0, sink, host array) as two child processes
-    sharing this box's GPU, with gloo standing in for RCCL: rank 0's host array must verify."""
+@pytest.mark.parametrize("gather,ranks", [("shm", 3), ("rccl", 2)])
+def test_bench_multi_rank_rehearsal(gather, ranks):
+    """bench.py's own N > 1 loops as child processes sharing this box's GPU (gloo carries the control messages; RCCL
+    cannot run several ranks on one GPU): `shm` -- the default: one host array in shared memory, every rank's sink
+    delivers its rows; `rccl` -- per-step gather of the codes to rank 0, whose sink expands them all.  Rank 0's host
+    array must verify against a replay of the LAST rank's games."""
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+    for rank in range(ranks):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(ranks), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch",
-               str(1 << 16), "--no-cpu-baseline"]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "9", "--warmup", "2", "--batch",
+               str(1 << 16), "--no-cpu-baseline", "--gather", gather, "--host-threads", "2"]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
     line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["gathered_rewards_verified"] is True
-    assert d["config"]["rewards_to_host"] is True and d["config"]["global_batch"] == 2 << 16
+    assert d["n_gpus"] == ranks and d["config"]["gathered_rewards_verified"] is True
+    assert d["config"]["rewards_to_host"] is True and d["config"]["global_batch"] == ranks << 16
+    assert ("shared memory" in d["config"]["sharding"]) == (gather == "shm")
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # only rank 0 prints the line
 
 
-def test_bench_rccl_path_with_one_rank():
-    """The N > 1 loop over the REAL collective backend (nccl = RCCL) with a world of one rank -- what a one-GPU box can
-    run of it: process group on the GPU, per-step dist.gather of the outcome codes, rank-0 sink, verified host array."""
+@pytest.mark.parametrize("gather", ["rccl", "shm"])
+def test_bench_sharded_path_with_one_rank_over_rccl(gather):
+    """The N > 1 loops over the REAL collective backend (nccl = RCCL) with a world of one rank -- what a one-GPU box can
+    run of them: process group on the GPU, then either the per-step dist.gather of the outcome codes + rank-0 sink, or
+    the shared host array (RCCL then only carries the barriers and the step count); verified host array."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                BGS_FORCE_DIST="1")
     env.pop("BGS_DIST_BACKEND", None)
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "3",
-                           "--batch", str(1 << 18), "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                           "--batch", str(1 << 18), "--no-cpu-baseline", "--gather", gather], env=env, capture_output=True,
+                          text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-3000:]
     d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["config"]["gathered_rewards_verified"] is True and "RCCL gather" in d["config"]["sharding"]
+    assert d["config"]["gathered_rewards_verified"] is True
+    assert ("RCCL gather" in d["config"]["sharding"]) == (gather == "rccl")
     assert d["config"]["rewards_to_host"] is True and d["value"] > 0
 
 

@@ -217,7 +217,17 @@ def main() -> int:
     # the launching thread waits for the delivery of step i - 2 * depth, not i - depth, before it enqueues step i:
     # waiting on the previous step of the SAME stream would leave the GPU one batch short for the length of the delivery
     host_slots = depth if sharded and not ring_mode else 2 * depth
-    ring = SharedRewardRing(dist, n, host_slots) if ring_mode else None
+    ring = None
+    if ring_mode:
+        try:
+            ring = SharedRewardRing(dist, n, host_slots)
+        except RuntimeError as exc:  # raised on every rank or on none: all ranks fall back together
+            if rank == 0:
+                print(f"bench.py: {exc}; falling back to --gather rccl", file=sys.stderr)
+            ring_mode = False
+            host_slots = depth
+            if args.host_threads == 4:
+                args.host_threads = min(12, 4 + 2 * world)
     batches, packed, packed_buf, all_packed, host_rewards, events = [], [], [], [], [], []
     for s in streams:
         with torch.cuda.stream(s):

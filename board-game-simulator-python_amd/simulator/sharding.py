@@ -54,22 +54,41 @@ class SharedRewardRing:
         self._slot_bytes = self.world * self.per_rank * 2
         data = -(-self.slots * self._slot_bytes // 4096) * 4096
         total = data + 64 * self.world  # one cache line of progress per rank
-        name = [os.path.join(directory, f"bgs_rewards_{os.getpid()}_{uuid.uuid4().hex}") if self.rank == 0 else None]
-        fd = -1
+        # Rank 0 creates the file -- if the directory has room for it: a tmpfs accepts the ftruncate and kills the process
+        # that touches the first page it cannot back -- and everybody learns the name, or that there is none.  Whether
+        # all ranks mapped it is agreed on before anybody goes on: the constructor raises on every rank or on none, so
+        # callers can fall back to the collective gather consistently.
+        name, fd, error = [None], -1, None
         if self.rank == 0:
-            fd = os.open(name[0], os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
-            os.ftruncate(fd, total)
+            try:
+                st = os.statvfs(directory)
+                if st.f_bavail * st.f_frsize < total + (64 << 20):
+                    raise OSError(f"{directory} has {st.f_bavail * st.f_frsize >> 20} MiB free, the reward ring needs {total >> 20}")
+                path = os.path.join(directory, f"bgs_rewards_{os.getpid()}_{uuid.uuid4().hex}")
+                fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                name[0] = path
+                os.ftruncate(fd, total)
+            except OSError as exc:
+                error = f"rank 0: {exc}"
         dist.broadcast_object_list(name, src=0)
-        try:
-            if self.rank != 0:
-                fd = os.open(name[0], os.O_RDWR)
-            self._map = mmap.mmap(fd, total, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
-        finally:
-            if fd >= 0:
-                os.close(fd)
-            dist.barrier()  # everybody has mapped (or failed): the name can go
-            if self.rank == 0:
-                os.unlink(name[0])
+        self._map = None
+        if name[0] is not None:
+            try:
+                if self.rank != 0:
+                    fd = os.open(name[0], os.O_RDWR)
+                self._map = mmap.mmap(fd, total, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
+            except (OSError, ValueError) as exc:
+                error = f"rank {self.rank}: {exc}"
+        if fd >= 0:
+            os.close(fd)
+        errors = [None] * self.world
+        dist.all_gather_object(errors, error)  # (also the barrier after which the name can go)
+        if self.rank == 0 and name[0] is not None:
+            os.unlink(name[0])
+        if any(errors):
+            if self._map is not None:
+                self._map.close()
+            raise RuntimeError("shared reward ring unavailable: " + "; ".join(e for e in errors if e))
         buf = np.frombuffer(self._map, dtype=np.int8, count=self.slots * self._slot_bytes)
         self._arrays = buf.reshape(self.slots, self.world * self.per_rank, 2)
         self._progress = np.frombuffer(self._map, dtype=np.int64, count=8 * self.world, offset=data).reshape(self.world, 8)

@@ -120,6 +120,17 @@ RING_WORKER = textwrap.dedent(
             whole.rollout(seed + step)
             assert np.array_equal(ring.array(step % slots), whole.reward), f"step {{step}}: the shared array is not the unsharded run"
         dist.barrier()  # rank 0 has compared this step before anybody reuses its slot
+    # a directory that cannot hold the ring: the constructor raises on EVERY rank (callers then fall back together)
+    try:
+        SharedRewardRing(dist, 1 << 40, slots)
+        raise SystemExit("a ring larger than /dev/shm was accepted")
+    except RuntimeError as exc:
+        assert "rank 0" in str(exc)
+    try:
+        SharedRewardRing(dist, per_rank, slots, directory="/nonexistent-directory")
+        raise SystemExit("a ring in a missing directory was accepted")
+    except RuntimeError:
+        pass
     if rank == 0:
         try:
             ring.wait_all(steps, timeout=0.2)

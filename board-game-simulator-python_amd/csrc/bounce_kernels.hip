@@ -855,7 +855,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         // a grid that fills the chip (flat_wps waves per SIMD, never more waves than 64-board chunks); every wave
         // draws its boards from the shared queue
         const uint32_t chunk = (uint32_t)b->bounce_flat_chunk;
-        int64_t flat_waves = (int64_t)b->num_cus * 4 * b->bounce_flat_wps;
+        int64_t flat_waves = b->bounce_flat_waves > 0 ? b->bounce_flat_waves : (int64_t)b->num_cus * 4 * b->bounce_flat_wps;
         const int64_t most = (b->n + 63) / 64;    // (never more waves than 64-board loads)
         if (flat_waves > most) flat_waves = most;
         hipLaunchKernelGGL((k_bounce_rollout_flat<INITIAL>), dim3((unsigned)((flat_waves + 3) / 4)), dim3(BGS_BLOCK), tile,

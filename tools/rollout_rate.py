@@ -10,7 +10,11 @@ if "--depth" in sys.argv:
     _depth = int(sys.argv[sys.argv.index("--depth") + 1])
 # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): more batches in
 # flight than queues do not overlap.  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(_depth, 16))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(2 * _depth, 32)) if _depth > 4 else 4))
+# Bounce with many batches in flight: fewer, longer-lived waves per launch (less drain per batch; the launches fill the chip
+# together).  Must be set before the library reads it at batch creation.
+if "--bounce-waves" in sys.argv:
+    os.environ["BGS_BOUNCE_FLAT_WAVES"] = sys.argv[sys.argv.index("--bounce-waves") + 1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
 import numpy as np
@@ -24,6 +28,7 @@ ap.add_argument("--depth", type=int, default=3)
 ap.add_argument("--reps", type=int, default=24)
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--max-plies", type=int, default=4096)
+ap.add_argument("--bounce-waves", type=int, default=0, help="BGS_BOUNCE_FLAT_WAVES for this run (0: library default)")
 args = ap.parse_args()
 
 def make():

@@ -273,6 +273,11 @@ int device_facts(bgs_batch* b) {
         const int v = atoi(env);
         if (v >= 1 && v <= 4096) b->bounce_flat_chunk = v;
     }
+    b->bounce_park = kBouncePark;
+    if (const char* env = getenv("BGS_BOUNCE_PARK")) {
+        const int v = atoi(env);
+        if (v >= 0 && v <= 32) b->bounce_park = v;
+    }
     b->bounce_flat_waves = 0;
     if (const char* env = getenv("BGS_BOUNCE_FLAT_WAVES")) {
         const int v = atoi(env);

@@ -43,6 +43,7 @@ struct BounceGeom {
 constexpr int kRolloutOpeningBlocks = 3;    // K2o: 4-ply blocks played in lock step before a board joins the refill loop
 constexpr int kGamesPerLaneOneWord = 8;     // one-word Connect boards: games per lane a launch aims for (512 per wave at 2^20)
 constexpr int kGamesPerLane = 4;            // every other rollout
+constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBoards (0 = every wave drains alone)
 
 struct bgs_batch {
     int game;
@@ -62,6 +63,7 @@ struct bgs_batch {
     int bounce_flat;         // 1: one-lane-per-board Bounce rollouts use the flattened search (BGS_BOUNCE_FLAT=0: nested loops)
     int bounce_flat_wps;     // waves per SIMD of a flat Bounce rollout launch (BGS_BOUNCE_FLAT_WPS)
     int bounce_flat_waves;   // > 0: that many waves per launch instead (BGS_BOUNCE_FLAT_WAVES)
+    int bounce_park;         // flat rollout: a draining wave parks its boards for its workgroup at this many or fewer (0..32; BGS_BOUNCE_PARK)
     int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (BGS_BOUNCE_CHUNK)
     int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board
     uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];

@@ -540,14 +540,55 @@ __device__ __forceinline__ void pick_flat(const FlatMoves& m, const uint32_t* co
     dst_cell = (int)select_bit64(chosen, idx);
 }
 
+// Boards a draining wave has parked for the other waves of its workgroup (see the drain paragraph in the kernel).
+struct ParkedBoards {
+    static constexpr uint32_t WAVES = BGS_BLOCK / BGS_WAVE, CAP = 32;
+    uint64_t v[4][WAVES][CAP];   // the board's value planes
+    uint32_t game[WAVES][CAP];
+    uint32_t plies[WAVES][CAP];
+    uint32_t count[WAVES];       // entries of the segment; published once, after the entries
+    uint32_t head[WAVES];        // entries claimed so far (may run past count)
+    uint32_t active;             // waves still in their loop
+};
+
 template <bool FROM_INITIAL>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                       uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
                       unsigned long long* __restrict__ steps, uint32_t chunk, const uint32_t* __restrict__ worklist,
-                      const uint32_t* __restrict__ work_count, uint32_t* __restrict__ queue) {
+                      const uint32_t* __restrict__ work_count, uint32_t* __restrict__ queue, uint32_t park_at) {
     extern __shared__ uint32_t target_tile[];             // [2 * kMaxTrackedColumns dwords][256 lanes]
+    __shared__ ParkedBoards parked;
     uint32_t* const column = target_tile + threadIdx.x;   // this lane's dword column
+    constexpr uint32_t WAVES = ParkedBoards::WAVES;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x < WAVES) {
+        parked.count[threadIdx.x] = 0u;
+        parked.head[threadIdx.x] = 0u;
+    }
+    if (threadIdx.x == 0) parked.active = WAVES;
+    __syncthreads();
+    // The drain.  Game lengths are geometric-tailed: once the queue is dry a wave's last boards keep it alive for ~120
+    // more plies with ever fewer lanes busy, and with a few boards per lane per launch that is most of what a launch
+    // issues.  So a wave that has nothing left to draw and at most park_at boards in flight PARKS them in LDS and
+    // leaves; waves of the workgroup that are still running adopt parked boards into their idle lanes (they search the
+    // board's action list again, one extra search in a game's remaining plies).  Nobody waits for anybody: `active`
+    // counts the waves still in their loop, a wave that parks (or runs out of boards) leaves only if others remain,
+    // and the wave that finds itself the last one takes back what it parked and sweeps up what the others left.
+    // Fences are LDS-only ("local"): they never wait for the global stores of finished boards.
+    bool last = false;
+    auto bump = [&](uint32_t* word, uint32_t by) {  // wave-level atomic add (lane 0 issues it), old value to all lanes
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(word, by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (uint32_t)__builtin_amdgcn_readfirstlane(old);
+    };
+    auto leave = [&]() {  // this wave stops adopting; returns the number of waves that were still in their loop
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        const uint32_t before = bump(&parked.active, ~0u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        return before;
+    };
     const uint32_t total = worklist ? *work_count : (uint32_t)n;
     // Work is handed out dynamically: a wave draws chunks of `chunk` boards from a device-wide counter (zeroed before
     // the launch) whenever its lanes run out.  Game lengths are heavy-tailed, so with static chunks a wave lives as
@@ -605,6 +646,39 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             const uint32_t wanted = (uint32_t)__popcll(need);
             taken = avail - taken < wanted ? avail : taken + wanted;
         }
+        const bool draining = dry && taken >= avail;  // (wave-uniform) nothing left to draw
+        if (draining && need) {
+            // ---- idle lanes adopt parked boards.  count[] and head[] are adjacent: lanes 0..7 fetch them in one access
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            uint32_t word = 0;
+            if (lane < 2u * WAVES) word = __hip_atomic_load(&parked.count[0] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            uint32_t assigned = 0;
+#pragma unroll
+            for (uint32_t sgm = 0; sgm < WAVES; ++sgm) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(word, sgm);
+                const uint32_t h = (uint32_t)__builtin_amdgcn_readlane(word, WAVES + sgm);
+                if (assigned < wanted && h < c) {
+                    const uint32_t old = bump(&parked.head[sgm], wanted - assigned);
+                    const uint32_t got = old < c ? (c - old < wanted - assigned ? c - old : wanted - assigned) : 0u;
+                    if (!has && rank >= assigned && rank < assigned + got) {
+                        const uint32_t e = old + (rank - assigned);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b.v[j] = parked.v[j][sgm][e];
+                        game = parked.game[sgm][e];
+                        plies = parked.plies[sgm][e];
+                        first_ply = plies;  // (the wave that parked it has counted the plies up to here)
+                        st = BGS_ST_RUNNING;
+                        has = true;
+                        dirty = true;
+                        have_block = false;
+                        search = true;
+                    }
+                    assigned += got;
+                }
+            }
+        }
 
         // ---- the action lists of the boards that need one (new boards, boards that have just moved); a board whose
         // side to move has no action is settled here, also at the ply cap (the transition that blocked it counts)
@@ -639,7 +713,40 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             has = false;
             dirty = false;
         }
-        if (!__builtin_amdgcn_ballot_w64(has) && taken >= avail && dry) break;
+        if (!__builtin_amdgcn_ballot_w64(has)) {
+            if (!draining) continue;    // (a chunk of boards that were not running: draw the next one)
+            if (last) break;
+            if (leave() > 1u) break;    // others are still running: whatever gets parked later is theirs
+            last = true;                // everybody else has left: sweep up what they parked
+            continue;
+        }
+        if (draining && !last) {
+            const uint64_t still = __builtin_amdgcn_ballot_w64(has);  // (every board still held is running here)
+            const uint32_t left = (uint32_t)__popcll(still);
+            if (left <= park_at) {
+                const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(still >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)still, 0u));
+                if (has) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) parked.v[j][w][e] = b.v[j];
+                    parked.game[w][e] = game;
+                    parked.plies[w][e] = plies;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_store(&parked.count[w], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (leave() > 1u) {  // parked; somebody is still there to adopt them
+                    if (has) stepped += plies - first_ply;
+                    break;
+                }
+                // nobody is: take back what has not been adopted (an adopter that has left has finished its boards)
+                const uint32_t adopted = bump(&parked.head[w], left);
+                if (has && e < adopted) {
+                    stepped += plies - first_ply;
+                    has = false;
+                    dirty = false;
+                }
+                last = true;
+            }
+        }
 
         // ---- one ply on every running board
         if (run) {
@@ -860,7 +967,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         if (flat_waves > most) flat_waves = most;
         hipLaunchKernelGGL((k_bounce_rollout_flat<INITIAL>), dim3((unsigned)((flat_waves + 3) / 4)), dim3(BGS_BLOCK), tile,
                            b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
-                           seed, b->first_game, cap, b->d_steps, chunk, worklist, work_count, queue);
+                           seed, b->first_game, cap, b->d_steps, chunk, worklist, work_count, queue, (uint32_t)b->bounce_park);
     };
     auto with_group = [&](auto initial_tag) {
         if (group == 1 && b->bounce_flat) launch_flat(initial_tag);   // one lane per board, flattened search

@@ -324,6 +324,47 @@ def test_bounce_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("park,waves,chunk", [("0", "0", "32"), ("32", "0", "32"), ("32", "4", "7"), ("1", "8", "64"),
+                                              ("32", "64", "1"), ("16", "3", "32")])
+def test_bounce_flat_rollout_shared_drain_protocol(batch_mod, park, waves, chunk):
+    """The flat Bounce kernel's drain: waves that run out of boards park their last ones in LDS for the waves of their
+    workgroup that still run, and the last wave standing sweeps up.  Batch sizes around the wave / workgroup / chunk
+    boundaries, few waves with many boards each, many waves with nothing to do, parking thresholds 0 (off), 1, 16, 32:
+    every board must be finished exactly once and match the oracle, the step count included."""
+    import os
+
+    env = {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PARK": park, "BGS_BOUNCE_CHUNK": chunk}
+    if waves != "0":
+        env["BGS_BOUNCE_FLAT_WAVES"] = waves
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for n in (1, 63, 64, 65, 255, 256, 257, 1000, 4099, 20011):
+            dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+            orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+            dev.set_first_game(n)
+            dev.rollout(SEED ^ n, max_plies=3000, from_initial=True)
+            total = orc.rollout(SEED ^ n, first_game=n, max_plies=3000)
+            assert_same(dev, orc, f"park {park} waves {waves} chunk {chunk} n={n}")
+            assert dev.steps == total, (n, dev.steps, total)
+            # resumed from memory with a cap, then to the end: the not-from-initial variant of the same kernel
+            dev.reset()
+            orc.reset()
+            dev.reset_steps()
+            dev.rollout(SEED ^ n, max_plies=5)
+            dev.rollout(SEED ^ n, max_plies=3000)
+            orc.rollout(SEED ^ n, first_game=n, max_plies=3000)
+            assert_same(dev, orc, f"park {park} waves {waves} chunk {chunk} n={n}, capped then finished")
+            assert dev.steps == total
+            dev.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
 def test_unsupported_geometry_is_an_error(batch_mod):
     """Beyond the bit-packed limits the generic kernels take over (tests/test_gpu_generic.py); beyond THEIR limits the
     library refuses, loudly and before touching the GPU."""

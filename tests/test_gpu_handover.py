@@ -529,3 +529,30 @@ def test_bench_single_gpu_line():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] <= 1
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
     assert d["device_resident"]["value"] > 0 and d["steps"] == 12 and d["warmup"] == 3
+
+
+def test_rollout_pipeline_matches_the_oracle_step_by_step():
+    """simulator.pipeline.RolloutPipeline (the bench's loop as a library object): every step's host rewards equal the
+    oracle's for that step's seed, for Connect and for Bounce, whatever the depth; arrays are reused after 2 x depth."""
+    from simulator.batch import BounceBatch, ConnectBatch
+    from simulator.pipeline import RolloutPipeline
+
+    n = 5000
+    for depth in (1, 3):
+        with RolloutPipeline(ConnectBatch, (6, 7, 4), n, depth=depth, host_threads=3, first_game=77) as pipe:
+            seen = 0
+            for step, rewards in pipe.run(seeds=[SEED + 11 * s for s in range(9)]):
+                orc = oracle.ConnectOracle(6, 7, 4, n)
+                orc.rollout(SEED + 11 * step, first_game=77)
+                np.testing.assert_array_equal(rewards, orc.reward, err_msg=f"depth {depth} step {step}")
+                seen += 1
+            assert seen == 9 and pipe.env_steps > 9 * n * 7
+            with pytest.raises(KeyError):
+                pipe.result(0)  # 9 steps on 2 * depth <= 6 arrays: step 0's array has been reused
+    grid = np.zeros((9, 6), dtype=np.int8)
+    grid[1] = grid[7] = [1, 2, 3, 3, 2, 1]
+    with RolloutPipeline(BounceBatch, (grid,), 700, depth=2, host_threads=2, max_plies=2000) as pipe:
+        for step, rewards in pipe.run(seeds=range(5)):
+            orc = oracle.BounceOracle(grid, 700)
+            orc.rollout(step, max_plies=2000)
+            np.testing.assert_array_equal(rewards, orc.reward, err_msg=f"bounce step {step}")

@@ -181,7 +181,10 @@ int bgs_rollout_to_host(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t
 
 /* A reward sink delivers the rewards of successive batch steps into caller-owned host arrays int8[n][2] while the GPU
  * goes on playing: per submission the outcome codes cross PCIe into one of `slots` pinned buffers and `threads` host
- * worker threads expand them as soon as the copy has landed.  Submissions complete in order. */
+ * worker threads expand them as soon as the copy has landed (with more than one thread the first one only waits for
+ * the arrival events and releases the others, so the event latency of a submission overlaps the expansion of the one
+ * before it).  Submissions complete in order.  Environment: BGS_SINK_SPIN_US (microseconds a waiter spins before it
+ * sleeps, default 0), BGS_SINK_POLL (poll the arrival event), BGS_NO_STREAM_STORES. */
 typedef struct bgs_reward_sink bgs_reward_sink;
 int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_reward_sink** out);
 int bgs_sink_destroy(bgs_reward_sink* s);

@@ -890,9 +890,9 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
 //     dry, and parks them in a wave-private ring in LDS (128 slots of planes + column nibbles); idle lanes refill from
 //     the ring and join the main loop at block OPEN_BLOCKS (blocks 2.. of the opening are full blocks in lock step).
 //     A game that ends inside the opening is stored by the opening stage and parked as a dead slot (column word 0).
-// Status and reward are not stored per game either: the 2-bit outcome codes of the wave's chunk accumulate in LDS (they
-// are needed for the hand-over anyway) and are expanded into the status / reward arrays, four games per lane and
-// coalesced, when the chunk is done.  Results are those of K2a bit for bit: the draws are keyed by (game, block).
+// Status and reward are not stored per game either: a finished game leaves ONE outcome byte in the wave's LDS slice (a
+// plain ds_write_b8), and when the chunk is done a lane reads four games as one dword -- their four status bytes as they
+// go to memory -- and derives their reward pairs and their byte of 2-bit codes for the hand-over from it, coalesced.  Results are those of K2a bit for bit: the draws are keyed by (game, block).
 //
 // (Tried and measured, not kept: sharing the drain inside a workgroup -- a wave whose chunk is exhausted parks its last
 // <= 32 boards in LDS for the waves still running and leaves.  It cut another 6 % of the instructions and made the
@@ -909,7 +909,7 @@ __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                          int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps,
                          uint32_t games_per_wave, uint32_t* __restrict__ codes_out) {
-    extern __shared__ uint32_t code_lds[];  // games_per_wave / 16 dwords per wave (also when the codes stay on the device)
+    extern __shared__ uint32_t code_lds[];  // one outcome BYTE per game of the wave's chunk: games_per_wave / 4 dwords per wave
     __shared__ OpenedPool pools[BGS_BLOCK / BGS_WAVE];
     constexpr uint32_t ONES = 0x11111111u;
     const uint32_t top = (uint32_t)g.h() + 7u;
@@ -933,8 +933,11 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
     uint32_t hts = 0, blk = 0, live = 0, st = 0, game = 0, stepped = 0;
 
     if (avail == 0u) return;
-    WaveCodes codes;
-    codes.init(code_lds, games_per_wave, avail);
+    // The outcome of game i of the chunk is byte i of the wave's LDS slice (a plain byte store where the game ends, no
+    // read-modify-write): at the end a lane reads four games as one dword -- which IS their four status bytes.
+    uint8_t* const outcome = reinterpret_cast<uint8_t*>(code_lds + (threadIdx.x >> 6) * (games_per_wave >> 2));
+    for (uint32_t i = lane; i < ((avail + 3u) >> 2); i += BGS_WAVE) reinterpret_cast<uint32_t*>(outcome)[i] = 0u;
+    __builtin_amdgcn_wave_barrier();
 
     // one full ply of sub-step J on (q, h4, op, alive, won_by); the body of K2a's block
     auto full_ply = [&](auto j_tag, uint32_t draw, uint64_t (&q)[2], uint32_t& h4, uint32_t& op, uint32_t& alive,
@@ -1000,7 +1003,7 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
         if (was_live != 0 && live == 0) {
             *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane0) + (game * 8u)) = p[0];
             *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane1) + (game * 8u)) = p[1];
-            codes.add(game, st ? st : BGS_ST_DRAW);  // no cap: a board that stopped without a winner is full
+            outcome[game] = (uint8_t)(st ? st : BGS_ST_DRAW);  // no cap: a board that stopped without a winner is full
         }
     };
 
@@ -1042,7 +1045,7 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
                     if (OPEN_BLOCKS >= 2 && alive == 0) {  // ended inside the opening: a win, or a small board is full
                         plane0[og] = q[0];
                         plane1[og] = q[1];
-                        codes.add(og, won_by ? won_by : BGS_ST_DRAW);
+                        outcome[og] = (uint8_t)(won_by ? won_by : BGS_ST_DRAW);
                     }
                 } else {
                     stepped = before;  // a lane past the end of the chunk played for nobody
@@ -1073,27 +1076,25 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
     // ---- the drain: no games left to hand out, the boards in flight play to their end
     while (__builtin_amdgcn_ballot_w64(live != 0)) play_block();
 
-    // ---- the chunk is done: its codes go out, and status / reward are expanded from them, 4 games per lane
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the ds_or of every lane before the reads below
+    // ---- the chunk is done: four games per lane -- their status dword as it lies in LDS, their reward pairs, and their
+    // byte of 2-bit codes for the hand-over (64 lanes: 64 contiguous bytes per store, into host memory when mapped)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the byte stores of every lane before the reads below
     __builtin_amdgcn_wave_barrier();
-    if (CODES) {
-        uint32_t* dst = codes_out + (begin >> 4);
-        for (uint32_t i = lane; i < codes.words; i += BGS_WAVE) dst[i] = codes.slice[i];
-    }
     uint8_t* __restrict__ const status_out = status + begin;
     uint16_t* __restrict__ const reward_out = reward + begin;
+    uint8_t* __restrict__ const packed_out = reinterpret_cast<uint8_t*>(codes_out) + (begin >> 2);
     for (uint32_t g4 = lane * 4u; g4 < avail; g4 += BGS_WAVE * 4u) {
-        const uint32_t c = (codes.slice[g4 >> 4] >> (2u * (g4 & 15u))) & 255u;
+        const uint32_t four = reinterpret_cast<const uint32_t*>(outcome)[g4 >> 2];  // (bytes past avail are 0)
+        if (CODES) packed_out[g4 >> 2] = (uint8_t)((four & 3u) | ((four >> 6) & 0xCu) | ((four >> 12) & 0x30u) | ((four >> 18) & 0xC0u));
         if (g4 + 4u <= avail) {
-            const uint32_t c0 = c & 3u, c1 = (c >> 2) & 3u, c2 = (c >> 4) & 3u, c3 = c >> 6;
-            *reinterpret_cast<uint32_t*>(status_out + g4) = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+            *reinterpret_cast<uint32_t*>(status_out + g4) = four;
             uint2 r;
-            r.x = (uint32_t)reward_pair(c0) | ((uint32_t)reward_pair(c1) << 16);
-            r.y = (uint32_t)reward_pair(c2) | ((uint32_t)reward_pair(c3) << 16);
+            r.x = (uint32_t)reward_pair(four & 255u) | ((uint32_t)reward_pair((four >> 8) & 255u) << 16);
+            r.y = (uint32_t)reward_pair((four >> 16) & 255u) | ((uint32_t)reward_pair(four >> 24) << 16);
             *reinterpret_cast<uint2*>(reward_out + g4) = r;
         } else {
             for (uint32_t k = 0; g4 + k < avail; ++k) {
-                const uint32_t ck = (c >> (2u * k)) & 3u;
+                const uint32_t ck = (four >> (8u * k)) & 255u;
                 status_out[g4 + k] = (uint8_t)ck;
                 reward_out[g4 + k] = reward_pair(ck);
             }
@@ -1624,14 +1625,15 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
                                            b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr);
                     }
                 };
+                const size_t outcome_lds = (size_t)4 * per_wave;  // K2o: one outcome byte per game
                 if ((flags & 1u) && !capped && b->rollout_opening && b->cg.h >= 4 && b->cg.w >= 2 && b->cg.k >= 3 &&
-                    code_lds <= (32u << 10)) {
+                    outcome_lds <= (32u << 10)) {
                     // from the initial state, no cap: the kernel with the lock-step opening stage (K2o)
                     auto launch_opened = [&](auto blocks_tag, auto codes_tag) {
                         constexpr int OPEN_BLOCKS = decltype(blocks_tag)::value;
                         constexpr bool CODES = decltype(codes_tag)::value;
                         hipLaunchKernelGGL((k_connect_rollout_opened<G, OPEN_BLOCKS, CODES>), dim3(blocks), dim3(BGS_BLOCK),
-                                           code_lds, b->stream, g, b->d_planes, b->d_status,
+                                           outcome_lds, b->stream, g, b->d_planes, b->d_status,
                                            reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, b->d_steps,
                                            (uint32_t)per_wave, CODES ? codes_out : nullptr);
                         fused = CODES;

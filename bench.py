@@ -213,10 +213,13 @@ def main() -> int:
     owner = rank == 0  # rank 0 owns "the one host array"
     # per in-flight slot: the batch; (N > 1) its packed outcome codes and, on rank 0, the gathered codes of all ranks;
     # the HOST array the step's rewards end in: int8[world * n, 2] on rank 0 (N = 1: int8[n, 2])
-    # One GPU: the hand-over pipeline is deeper than the GPU's (twice as many host arrays / sink slots as streams), so
-    # the launching thread waits for the delivery of step i - 2 * depth, not i - depth, before it enqueues step i:
-    # waiting on the previous step of the SAME stream would leave the GPU one batch short for the length of the delivery
-    host_slots = depth if sharded and not ring_mode else 2 * depth
+    # One GPU: the hand-over pipeline is deeper than the GPU's (three times as many host arrays / sink slots as streams),
+    # so the launching thread waits for the delivery of step i - 3 * depth, not i - depth, before it enqueues step i:
+    # waiting on the previous step of the SAME stream would leave the GPU one batch short for the length of the delivery.
+    # (Measured, tools/slots_sweep.sh: 3 per stream is 3 % faster than 2 on a 20-step run -- every stream always has a
+    # launch queued behind the running one, whatever the host does for ~100 us -- and 4 is slower: more arrays than the
+    # caches hold.)
+    host_slots = depth if sharded and not ring_mode else int(os.environ.get("BGS_BENCH_SLOT_FACTOR", "3")) * depth
     ring = None
     if ring_mode:
         try:

@@ -2,11 +2,11 @@
 
 A single `ConnectBatch.rollout()` followed by `.reward` leaves the GPU idle while the rewards cross PCIe and the host
 idle while the GPU plays.  `RolloutPipeline` keeps `depth` batches in flight on their own HIP streams and hands every
-step's rewards to a `RewardSink` (2-bit outcome codes into page-locked slots, host threads expand them), with twice as
-many host arrays as streams so that the launching thread never waits for the step it has just enqueued:
+step's rewards to a `RewardSink` (2-bit outcome codes into page-locked slots, host threads expand them), with three times
+as many host arrays as streams so that the launching thread never waits for the step it has just enqueued:
 
     with RolloutPipeline(ConnectBatch, (6, 7, 4), n=1 << 20) as pipe:
-        for step, rewards in pipe.run(seeds=range(1000)):   # rewards: int8[n, 2], valid until 2 * depth steps later
+        for step, rewards in pipe.run(seeds=range(1000)):   # rewards: int8[n, 2], valid until 3 * depth steps later
             consume(rewards)
 
 Every step plays all `n` boards from the initial state to the end with uniformly sampled moves; step s uses RNG seed
@@ -24,9 +24,9 @@ from .batch import RewardSink
 
 class RolloutPipeline:
     def __init__(self, batch_cls, config_args: tuple, n: int, depth: int = 3, host_threads: int = 6, device: int = 0,
-                 first_game: int = 0, max_plies: int = 2**31 - 1, host_arrays=None):
+                 first_game: int = 0, max_plies: int = 2**31 - 1, host_arrays=None, arrays_per_stream: int = 3):
         """`batch_cls(*config_args, n, device=..., use_torch=True)` is built `depth` times, each bound to its own stream.
-        `host_arrays`: optional list of 2 * depth C-contiguous int8[n, 2] destinations (e.g. rows of a shared array,
+        `host_arrays`: optional list of arrays_per_stream * depth C-contiguous int8[n, 2] destinations (e.g. rows of a shared array,
         `SharedRewardRing.mine(slot)`); by default the pipeline allocates (and pre-faults) its own."""
         import torch
 
@@ -41,11 +41,11 @@ class RolloutPipeline:
                 b = batch_cls(*config_args, self.n, device=device, use_torch=True)
                 b.set_first_game(first_game)
                 self.batches.append(b)
-        self.slots = 2 * self.depth
+        self.slots = max(1, int(arrays_per_stream)) * self.depth
         if host_arrays is None:
             host_arrays = [np.full((self.n, 2), 0, dtype=np.int8) for _ in range(self.slots)]  # (np.full: pages mapped now)
         if len(host_arrays) != self.slots:
-            raise ValueError(f"need {self.slots} host arrays (2 x depth)")
+            raise ValueError(f"need {self.slots} host arrays (arrays_per_stream x depth)")
         self.host = list(host_arrays)
         self.sink = RewardSink(self.n, slots=self.slots, threads=max(1, host_threads), device=device)
         self._tickets = [None] * self.slots
@@ -55,7 +55,7 @@ class RolloutPipeline:
     # ---- one step at a time -----------------------------------------------------------------------
     def submit(self, seed: int) -> int:
         """Enqueue one step (all n boards, initial state to terminal) and return its step index.  Blocks only if the host
-        array this step reuses (the one of step index - 2 * depth) has not been collected with `result()` yet AND is
+        array this step reuses (the one of step index - arrays_per_stream * depth) has not been collected with `result()` yet AND is
         still being delivered."""
         i = self._next
         h = i % self.slots
@@ -67,7 +67,7 @@ class RolloutPipeline:
         return i
 
     def result(self, step: int) -> np.ndarray:
-        """The rewards int8[n, 2] of `step` (waits for their delivery).  The array is reused by step + 2 * depth."""
+        """The rewards int8[n, 2] of `step` (waits for their delivery).  The array is reused by step + arrays_per_stream * depth."""
         h = step % self.slots
         if self._steps[h] != step:
             raise KeyError(f"step {step} is not in flight any more (its host array was reused)")

@@ -533,7 +533,7 @@ def test_bench_single_gpu_line():
 
 def test_rollout_pipeline_matches_the_oracle_step_by_step():
     """simulator.pipeline.RolloutPipeline (the bench's loop as a library object): every step's host rewards equal the
-    oracle's for that step's seed, for Connect and for Bounce, whatever the depth; arrays are reused after 2 x depth."""
+    oracle's for that step's seed, for Connect and for Bounce, whatever the depth; arrays are reused after 3 x depth."""
     from simulator.batch import BounceBatch, ConnectBatch
     from simulator.pipeline import RolloutPipeline
 
@@ -541,14 +541,14 @@ def test_rollout_pipeline_matches_the_oracle_step_by_step():
     for depth in (1, 3):
         with RolloutPipeline(ConnectBatch, (6, 7, 4), n, depth=depth, host_threads=3, first_game=77) as pipe:
             seen = 0
-            for step, rewards in pipe.run(seeds=[SEED + 11 * s for s in range(9)]):
+            for step, rewards in pipe.run(seeds=[SEED + 11 * s for s in range(12)]):
                 orc = oracle.ConnectOracle(6, 7, 4, n)
                 orc.rollout(SEED + 11 * step, first_game=77)
                 np.testing.assert_array_equal(rewards, orc.reward, err_msg=f"depth {depth} step {step}")
                 seen += 1
-            assert seen == 9 and pipe.env_steps > 9 * n * 7
+            assert seen == 12 and pipe.env_steps > 12 * n * 7
             with pytest.raises(KeyError):
-                pipe.result(0)  # 9 steps on 2 * depth <= 6 arrays: step 0's array has been reused
+                pipe.result(0)  # 12 steps on 3 * depth <= 9 arrays: step 0's array has been reused
     grid = np.zeros((9, 6), dtype=np.int8)
     grid[1] = grid[7] = [1, 2, 3, 3, 2, 1]
     with RolloutPipeline(BounceBatch, (grid,), 700, depth=2, host_threads=2, max_plies=2000) as pipe:

@@ -29,6 +29,9 @@ data path (simulator/sharding.py: SharedRewardRing); `--gather rccl` gathers the
 GPU over RCCL (256 KiB per rank over xGMI), whose sink copies them to the host and expands them all.  Plus one
 all-reduce of the step counters after the timed region.  Weak scaling.
 
+Environment (experiments): BGS_BENCH_SLOT_FACTOR (host arrays / sink slots per stream, default 3), BGS_BENCH_TRACE=1
+(where the timed region's time goes), BGS_FORCE_DIST=1 / BGS_DIST_BACKEND=gloo (the N > 1 loops on a one-GPU box).
+
 Steps run on `--inflight` batches / HIP streams in rotation: a rollout is bound by VALU instruction issue, its drain
 (the last game of every lane) leaves SIMDs idle that the next launch fills, and the copy engine and the host workers
 deliver step i while steps i+1.. play.

@@ -9,47 +9,51 @@ rewards int8[batch, 2] are handed over to a host array ("... to re
 the reference returns `reward` as a host ndarray, connect.cpp:41).  env-steps are the transitions applied to running
 boards (masked no-ops are not counted); they are counted on the device.
 
-    python bench.py --gpus 1 --steps 200 --warmup 10
+    python bench.py                      # 1 GPU, 200 steps
+    python bench.py --gpus N ...         # N GPUs of this node: starts its own N ranks as child processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W      # ... or runs as one of a launcher's ranks
 
-Hand-over (`--handover`):
-  codes  (default) the device packs 2-bit outcome codes (0.25 B per game), one asynchronous copy moves them into a
-         page-locked slot and host worker threads expand them into the int8 pairs of the step's host array
-         (bgs_sink_*); 256 KiB instead of 2 MiB cross PCIe per step;
-  pairs  one asynchronous copy of the int8[batch, 2] reward buffer into a page-locked host array
-         (bgs_rollout_to_host);
-  none   rewards stay on the device (the round-1 measurement; reported as `device_resident` beside `value` otherwise).
+The loop itself is native (csrc/bgs_pipeline.hip, `simulator.pipeline.RolloutExecutor`): one library call enqueues the
+timed region's K steps on `--inflight` batches / HIP streams in rotation; the hand-over (`--handover codes`, default) is
+the reward sink's -- 2-bit outcome codes stored by the rollout kernel straight into page-locked slots, host threads
+expand them into the step's host array -- with three times as many host arrays as streams.
 
 N > 1: one process per GPU, rank r owns global game ids [r * 2^20, (r+1) * 2^20) (RNG streams are keyed by global
 game id, so the shards reproduce the unsharded run).  The only exchange is the hand-over into THE one host array
-int8[N * 2^20, 2] (`--gather`): by default that array lives in shared memory mapped by every rank of the node and each
-rank's own sink delivers its rows -- the one-GPU loop on every rank, every GPU on its own PCIe link, no collective in the
-data path (simulator/sharding.py: SharedRewardRing); `--gather rccl` gathers the ranks' 2-bit outcome codes to rank 0's
-GPU over RCCL (256 KiB per rank over xGMI), whose sink copies them to the host and expands them all.  Plus one
-all-reduce of the step counters after the timed region.  Weak scaling.
+int8[N * 2^20, 2] (`--gather`):
+  shm   (default) the array lives in shared memory mapped by every rank of the node and each rank's own sink delivers
+        its rows -- the one-GPU loop on every rank, every GPU on its own PCIe link, no collective in the data path;
+        rank 0 is the consumer: it waits (futex) for every rank's delivery of a step and releases the slot, and the
+        timed region ends when it has seen the last step of every rank (simulator/sharding.py: SharedRewardRing);
+  rccl  the north-star's collective: every rank's codes to rank 0's GPU over RCCL / xGMI, inside the library
+        (bgs_gather_*: persistent communicator, communication stream and thread; the launching thread never enters
+        RCCL), rank 0's sink copies them to the host and expands them all.
+Plus one all-reduce of the step counters after the timed region.  Weak scaling.
 
-Environment (experiments): BGS_BENCH_SLOT_FACTOR (host arrays / sink slots per stream, default 3), BGS_BENCH_TRACE=1
-(where the timed region's time goes), BGS_FORCE_DIST=1 / BGS_DIST_BACKEND=gloo (the N > 1 loops on a one-GPU box).
-
-Steps run on `--inflight` batches / HIP streams in rotation: a rollout is bound by VALU instruction issue, its drain
-(the last game of every lane) leaves SIMDs idle that the next launch fills, and the copy engine and the host workers
-deliver step i while steps i+1.. play.
+Environment (experiments): BGS_BENCH_SLOT_FACTOR (host arrays per stream, default 3), BGS_BENCH_TRACE=1 (where the
+timed region's time goes), BGS_FORCE_DIST=1 / BGS_DIST_BACKEND=gloo (the N > 1 loops on a one-GPU box).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     : bound "hbm" = the bytes the rollout kernel really moves per launch over its mean duration (HIP events
-                 on the launch stream) against 8 TB/s -- small by design: boards live in registers -- next to the
-                 SURVEY 8d algorithmic figure it avoids, the VALU-issue rate that actually binds (against the guide's
-                 SIMD-32 peak and the measured ceiling of this instruction mix) and the PCIe share of the hand-over;
-  cpu_baseline : the CPU oracle (plain C restatement, OpenMP) timed on this host on a bounded sample of the same
-                 workload -- a reported baseline, not the target.
+  roofline      : the binding resource of the rollout kernel -- VALU instruction issue: wave-instructions per launch
+                  (rocprofv3 SQ_INSTS_VALU, from the committed counters of THIS build) over the time a launch takes in
+                  the pipelined loop, against the SIMD-32 issue peak; beside it the HBM bytes the kernel really moves
+                  (`traffic`, counters; `hbm` block) and SURVEY 8d's algorithmic byte model (`algorithmic` block);
+  other_configs : BASELINE.json's configs 3 (Connect 12x13x5, 2^18 boards) and 4 (Bounce default, 2^18 boards, 4096
+                  plies), each measured by a child process of this script (`--only`), with a parity check of the host
+                  rewards against the oracle on the first 2^16 games;
+  cpu_baseline  : the CPU oracle (plain C restatement, OpenMP) timed on this host on a bounded sample of the same
+                  workload, and the latency of ONE game on it (config 1) -- a reported baseline, not the target.
 """
 
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -66,22 +70,84 @@ STORED_BYTES_PER_GAME = 19   # what the fused rollout really writes per finished
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PCIE_PEAK_GBS = 63.0         # PCIe Gen5 x16 spec (MI355X_MICROARCH.md)
 VALU_PEAK_SIMD32 = 256 * 4 * 2.4e9 / 2 / 1e9  # G wave64-instr/s: 256 CUs x 4 SIMD-32, 2 cycles per wave64 instruction
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_rollout_counters.json")
+# settings that change what a launch executes: counters taken under the defaults are not quoted when one is set
+LAUNCH_OVERRIDES = ("BGS_ROLLOUT_OPENING", "BGS_ROLLOUT_CHUNK", "BGS_ROLLOUT_GENERIC", "BGS_ROLLOUT_NO_LDS", "BGS_FORCE_GENERIC")
+BOUNCE_GRID = [[0] * 6, [1, 2, 3, 3, 2, 1]] + [[0] * 6] * 5 + [[1, 2, 3, 3, 2, 1], [0] * 6]  # textual/bounce.py:66-78
+OTHER_CONFIGS = {
+    # name: (BASELINE.json config, boards, batches in flight, max plies, SURVEY 8d bytes per env-step, counters file, kernel)
+    "connect_12x13x5": ("Connect4(12,13,5) large-board batch=262,144 on 1 MI355X", 1 << 18, 3, 2**31 - 1, 96, "k2c", "k_connect_rollout_lds"),
+    "bounce_default": ("Bounce default config batch=262,144 on 1 MI355X", 1 << 18, 16, 4096, 64, "bounce", "k_bounce_rollout"),
+}
 
 
-def cpu_baseline(last_seed, host_reward_head):
-    """Time the oracle on this host's cores on a bounded sample of the same workload, and use the same run to
-    cross-check the rewards the last timed step delivered (first games of the host array)."""
-    import numpy as np
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    from oracle import oracle
 
+def launch_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this process never touches
+    the GPU or imports torch), relay rank 0's JSON line and the children's exit codes."""
+    env = dict(os.environ, WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for rank in range(n_ranks):
+        renv = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        out = subprocess.PIPE if rank == 0 else subprocess.DEVNULL  # only rank 0 prints the line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv, stdout=out, text=True))
+    # a rank that dies leaves the others in a collective: give them a moment, then stop exactly the processes started here
+    codes = [None] * n_ranks
+    first_failure = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if first_failure is None and any(c not in (None, 0) for c in codes):
+            first_failure = time.monotonic()
+        if first_failure is not None and time.monotonic() - first_failure > 20.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.05)
+    line = procs[0].communicate(timeout=60)[0] if procs[0].stdout else ""
+    for r, p in enumerate(procs):
+        try:
+            codes[r] = p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes[r] = p.wait()
+    if line:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: rank(s) failed (rank, exit code): {bad}", file=sys.stderr)
+        return next(c for _, c in bad if c) if any(c for _, c in bad) else 1
+    return 0
+
+
+def cpu_threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cap = int(os.environ.get("BGS_CPU_THREADS", "16"))  # a 1-GPU box's CPU share is 16 cores
-    cores = min(avail, cap)
+    return avail, cap, min(avail, cap)
+
+
+def cpu_baseline(last_seed, host_reward_head):
+    """Time the oracle on this host's cores on a bounded sample of the same workload, and use the same run to
+    cross-check the rewards the last timed step delivered (first games of the host array)."""
+    import ctypes
+
+    import numpy as np
+
+    from oracle import oracle
+
+    avail, cap, cores = cpu_threads()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     n = 1 << 20
     reps = 4
@@ -97,17 +163,25 @@ def cpu_baseline(last_seed, host_reward_head):
         elapsed += time.perf_counter() - t0
         if r == 0 and host_reward_head is not None:
             parity = bool(np.array_equal(orc.reward[: host_reward_head.shape[0]], host_reward_head))
-    # the same oracle on ONE thread (the reference's own loop is single-threaded under the GIL)
-    single = None
+    # the same oracle on ONE thread (the reference's own loop is single-threaded under the GIL), and
+    # BASELINE.json's config 1: the latency of ONE game from the initial state to the end (N = 1)
+    single = latency = plies = None
     try:
-        import ctypes
-
         gomp = ctypes.CDLL("libgomp.so.1")
         gomp.omp_set_num_threads(1)
         small = oracle.ConnectOracle(HEIGHT, WIDTH, COUNT, 1 << 18)
         t0 = time.perf_counter()
         steps1 = small.rollout(SEED + 77)
         single = steps1 / (time.perf_counter() - t0)
+        one = oracle.ConnectOracle(HEIGHT, WIDTH, COUNT, 1)
+        games, moved = 2000, 0
+        one.rollout(SEED)
+        t0 = time.perf_counter()
+        for g in range(games):
+            one.reset()
+            moved += one.rollout(SEED, first_game=g)
+        latency = (time.perf_counter() - t0) / games * 1e6
+        plies = moved / games
         gomp.omp_set_num_threads(cores)
     except OSError:
         pass
@@ -117,22 +191,194 @@ def cpu_baseline(last_seed, host_reward_head):
         "unit": "env-steps/s",
         "cores": cores,
         "single_thread_value": single,
+        "single_game_latency_us": latency,
+        "single_game_mean_plies": plies,
         "kind": "port",
-        "sample": f"{reps} x 2^20 Connect4(6,7,4) games from the initial state ({total} env-steps), CPU oracle "
-        f"(oracle/bgs_oracle.c, OpenMP, {cores} threads{capped}); the reference's own core is not buildable offline",
+        "sample": f"CPU restatement (oracle/bgs_oracle.c, OpenMP, {cores} threads{capped}) -- the reference's own core is not "
+        f"buildable offline: {reps} x 2^20 Connect4(6,7,4) games from the initial state ({total} env-steps); "
+        "single_game_latency_us = one game (BASELINE config 1, N = 1) per call of the oracle through ctypes, mean of 2000 games",
         "parity_with_host_rewards": parity,
     }
 
 
-def committed_counters(build_id):
-    """Per-launch PMC figures of the rollout kernel, valid only for the build they were measured on."""
-    if not os.path.exists(COUNTERS_FILE):
-        return None, "no counters file"
-    with open(COUNTERS_FILE) as fh:
-        c = json.load(fh)
-    if c.get("build_id") != build_id:
-        return None, f"counters were taken on build {c.get('build_id')}, this is {build_id}: not quoted"
-    return c, None
+def committed_counters(build_id, stem, kernel_substring=None):
+    """Per-launch PMC figures (profiles/r*_<stem>.json, newest round first), valid only for the build they were
+    measured on and for default launch settings."""
+    overrides = [k for k in LAUNCH_OVERRIDES if os.environ.get(k)]
+    if overrides:
+        return None, f"launch overrides set ({', '.join(overrides)}): the committed counters describe the default launch"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{stem}.json")), reverse=True)
+    seen = []
+    for path in files:
+        with open(path) as fh:
+            c = json.load(fh)
+        if c.get("build_id") != build_id:
+            seen.append(f"{os.path.basename(path)}: build {c.get('build_id')}")
+            continue
+        if "kernels" in c:  # per-kernel summaries: pick the kernel
+            for name, k in c["kernels"].items():
+                if kernel_substring is None or kernel_substring in name:
+                    k = dict(k, kernel=name, file=os.path.basename(path))
+                    k.setdefault("valu_wave_instructions_per_launch", k.get("SQ_INSTS_VALU"))
+                    return k, None
+            continue
+        return dict(c, file=os.path.basename(path)), None
+    return None, f"no counters for build {build_id} ({'; '.join(seen) or 'no file'}): not quoted"
+
+
+def valu_issue_block(counters, why_not, seconds_per_launch, build):
+    if not counters or not counters.get("valu_wave_instructions_per_launch") or not seconds_per_launch:
+        return {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_SIMD32, "unit": "Ginstr/s", "frac": None,
+                "traffic": None, "note": why_not or "no measurement"}
+    instr = counters["valu_wave_instructions_per_launch"]
+    rate = instr / seconds_per_launch / 1e9
+    out = {
+        "bound": "valu_issue",
+        "achieved": rate,
+        "peak": VALU_PEAK_SIMD32,
+        "unit": "Ginstr/s",
+        "frac": rate / VALU_PEAK_SIMD32,
+        "traffic": counters.get("hbm_bytes_per_launch"),
+        "wave_instr_per_launch": instr,
+        "active_lanes_per_valu_instruction": counters.get("active_lanes_per_valu_instruction"),
+        "counters_file": counters.get("file"),
+    }
+    if counters.get("mix_cycles_per_instruction"):
+        mix_peak = VALU_PEAK_SIMD32 * 2.0 / counters["mix_cycles_per_instruction"]
+        out["mix_ceiling"] = {"Ginstr_per_s": mix_peak, "frac": rate / mix_peak,
+                              "cycles_per_instruction": counters["mix_cycles_per_instruction"],
+                              "basis": "the SIMD-32 peak with this kernel's measured cycles per instruction (tools/valu_mix.py: "
+                              "instruction mix x tools/ubench.hip issue costs) -- a builder model, not a guide figure"}
+    out["basis"] = ("achieved = wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU on build " + build + ") / the time a "
+                    "launch takes in the pipelined loop (ms_per_step: launches overlap); peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 "
+                    "cycles per wave64 instruction (MI355X_MICROARCH.md)")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs 3 and 4: `bench.py --only NAME` (a child process of the main run) prints one JSON object
+# ------------------------------------------------------------------------------------------------------------------
+def run_other_config(name: str, steps: int) -> int:
+    label, n, depth, max_plies, bytes_per_step, stem, kernel = OTHER_CONFIGS[name]
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 2 * depth)))  # HIP maps a process's streams onto 4 hardware queues by default
+    import numpy as np
+    import torch
+
+    from oracle import oracle
+    from simulator.batch import BounceBatch, ConnectBatch, RewardSink
+    from simulator.game import _abi
+    from simulator.pipeline import RolloutExecutor
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the rollout engine has no CPU fallback", file=sys.stderr)
+        return 2
+    grid = np.array(BOUNCE_GRID, dtype=np.int8)
+
+    def make(count):
+        streams = [torch.cuda.Stream(device=0) for _ in range(count)]
+        batches = []
+        for s in streams:
+            with torch.cuda.stream(s):
+                batches.append(ConnectBatch(12, 13, 5, n, device=0, use_torch=True) if name == "connect_12x13x5"
+                               else BounceBatch(grid, n, device=0, use_torch=True))
+        return streams, batches
+
+    def rate(exe, batches, count, handover, stride=0):
+        for b in batches:
+            b.reset_steps()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        exe.enqueue(count, handover, stride)
+        exe.drain()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return sum(b.steps for b in batches) / dt, dt / count * 1e3
+
+    slots = 2 * depth
+    streams, batches = make(depth)
+    hosts = [np.zeros((n, 2), dtype=np.int8) for _ in range(slots)]
+    sink = RewardSink(n, slots=slots, threads=4, device=0)
+    exe = RolloutExecutor(batches, sink=sink, host_arrays=hosts, seed0=SEED, max_plies=max_plies)
+    exe.enqueue(depth, True)
+    exe.drain()
+    value, ms = rate(exe, batches, steps, True)
+    last_seed = SEED + exe.steps - 1
+    head = 1 << 16
+    got = np.array(exe.last_host_array()[:head])
+    env_steps = sum(b.steps for b in batches) / steps
+    device_rate, _ = rate(exe, batches, steps, False)
+    # one launch at a time
+    solo_exe = RolloutExecutor(batches[:1], seed0=SEED + 5000, max_plies=max_plies)
+    solo_steps = max(3, steps // 8)
+    solo_exe.enqueue(1, False)
+    solo_exe.drain()
+    solo_rate, solo_ms = rate(solo_exe, batches[:1], solo_steps, False, 1)
+    kernel_ms, pairs = solo_exe.kernel_ms()
+    orc = oracle.ConnectOracle(12, 13, 5, head) if name == "connect_12x13x5" else oracle.BounceOracle(grid, head)
+    orc.rollout(last_seed, max_plies=max_plies)
+    parity = bool(np.array_equal(orc.reward, got))
+    build = _abi.build_id()
+    counters, why_not = committed_counters(build, stem, kernel)
+    out = {
+        "config": label,
+        "value": value,
+        "unit": "env-steps/s",
+        "rewards_to_host": True,
+        "inflight": depth,
+        "ms_per_step": ms,
+        "steps": steps,
+        "env_steps_per_step": env_steps,
+        "device_resident": device_rate,
+        "solo": {"value": solo_rate, "ms_per_launch": solo_ms, "kernel_ms_per_launch": kernel_ms, "event_pairs": pairs},
+        "max_plies": None if max_plies >= 2**31 - 1 else max_plies,
+        "parity_with_oracle": parity,
+        "parity_sample": f"host rewards of the last timed step vs the CPU oracle, first {head} games, seed 0x{last_seed:016X}",
+        "valu_issue": valu_issue_block(counters, why_not, ms * 1e-3, build),
+        "algorithmic": {"bytes_per_env_step": bytes_per_step, "GBps": value * bytes_per_step / 1e9,
+                        "frac_of_hbm_peak": value * bytes_per_step / 1e9 / HBM_PEAK_GBS,
+                        "note": "SURVEY 8d's per-ply byte model: a register/LDS-resident rollout does not move these bytes"},
+        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+    }
+    print(json.dumps(out), flush=True)
+    solo_exe.close()
+    exe.close()
+    sink.close()
+    return 0
+
+
+def other_configs():
+    """Run configs 3 and 4 as child processes (their own HIP queue settings; the GPU is idle meanwhile)."""
+    results = {}
+    for name in OTHER_CONFIGS:
+        steps = 48 if name == "connect_12x13x5" else 32  # (Bounce: two launches per stream)
+        cmd = [sys.executable, os.path.abspath(__file__), "--only", name, "--steps", str(steps)]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BGS_FORCE_DIST", "BGS_ROLLOUT_WPS")}
+        try:
+            proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+            results[name] = json.loads(lines[-1]) if proc.returncode == 0 and lines else {
+                "error": f"exit code {proc.returncode}: {proc.stderr.strip()[-400:]}"}
+        except (subprocess.TimeoutExpired, ValueError) as exc:
+            results[name] = {"error": str(exc)}
+    return results
+
+
+def gpu_single_game_latency():
+    """BASELINE config 1 on the GPU: one game (N = 1) from the initial state to the end, launch + synchronise per game."""
+    from simulator.batch import ConnectBatch
+
+    one = ConnectBatch(HEIGHT, WIDTH, COUNT, 1, device=0, use_torch=False)
+    one.rollout(SEED, from_initial=True)
+    one.synchronize()
+    games = 300
+    t0 = time.perf_counter()
+    for g in range(games):
+        one.set_first_game(g)
+        one.rollout(SEED, from_initial=True)
+        one.synchronize()
+    us = (time.perf_counter() - t0) / games * 1e6
+    one.close()
+    return us
 
 
 def main() -> int:
@@ -143,23 +389,36 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="boards per GPU (default 2^20)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight per GPU: step i runs on batch i %% D / HIP stream i %% D, so the drain of one "
-                    "rollout, its copy to the host and (N > 1) its reward gather overlap the next rollouts (default 3)")
-    ap.add_argument("--handover", choices=("codes", "pairs", "none"), default="codes",
-                    help="how a step's rewards reach the host array (see the module docstring)")
+                    "rollout, its hand-over and (N > 1) its reward gather overlap the next rollouts (default 3)")
+    ap.add_argument("--handover", choices=("codes", "none"), default="codes",
+                    help="codes: every step's rewards reach a host array through the reward sink (2-bit outcome codes over "
+                    "PCIe, host threads expand them); none: rewards stay on the device (reported as `device_resident` "
+                    "beside `value` otherwise)")
     ap.add_argument("--host-threads", type=int, default=0,
-                    help="worker threads of the reward sink (--handover codes); 0 = 6 on one GPU, min(12, 4 + 2 N) on N "
-                    "(rank 0 expands N x 2 MiB of rewards per step: tools/sink_rate.py)")
+                    help="worker threads of the reward sink; 0 = 6 on one GPU, 4 per rank with --gather shm, "
+                    "min(24, 4 + 2 N) on rank 0 with --gather rccl (it expands N x 2 MiB of rewards per step)")
     ap.add_argument("--gather", default="shm",
                     help="N > 1: how the ranks' rewards reach the one host array. shm (default): the array is in shared "
                          "memory and every rank's own sink delivers its rows (no collective, every GPU uses its own PCIe "
-                         "link); rccl: outcome codes gathered to rank 0's GPU over RCCL, rank 0's sink expands them all")
+                         "link); rccl: outcome codes gathered to rank 0's GPU over RCCL inside the library, rank 0's sink "
+                         "expands them all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-resident", action="store_true",
                     help="skip the extra, separately timed pass without hand-over that fills `device_resident`")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 3 and 4 (`other_configs`)")
+    ap.add_argument("--no-repeats", action="store_true", help="skip the two extra timed regions behind `value_median_of_3`")
+    ap.add_argument("--only", choices=sorted(OTHER_CONFIGS), help="measure one of the other BASELINE configs and print its JSON object")
     args = ap.parse_args()
     if args.gather not in ("shm", "rccl"):
         print("bench.py: --gather must be shm or rccl", file=sys.stderr)
         return 2
+    if args.only:
+        return run_other_config(args.only, max(2, args.steps))
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        print("bench.py: need --gpus >= 1, --steps >= 1, --warmup >= 0", file=sys.stderr)
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return launch_ranks(args.gpus)  # (before anything here has touched the GPU)
 
     import numpy as np
     import torch
@@ -168,9 +427,8 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs the torch.distributed.run launcher (see docstring)", file=sys.stderr)
-            return 2
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        return 2
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the rollout engine has no CPU fallback", file=sys.stderr)
         return 2
@@ -182,47 +440,53 @@ def main() -> int:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
-    # BGS_FORCE_DIST=1 takes the N > 1 code path (process group; shared host array or per-step RCCL gather) with whatever world
-    # size the launcher gave, 1 included: the way to run that path over RCCL on a one-GPU box
+    # BGS_FORCE_DIST=1 takes the N > 1 code path with whatever world size the launcher gave, 1 included: the way to run
+    # that path over RCCL on a one-GPU box
     sharded = world > 1 or os.environ.get("BGS_FORCE_DIST") == "1"
+
+    from simulator.batch import ConnectBatch, RewardSink, expand_outcomes_host
+    from simulator.game import _abi
+    from simulator.pipeline import RolloutExecutor
+    from simulator.sharding import RewardGather, SharedRewardRing, gather_outcomes_to, shard_range, sum_steps
+
+    bound_cpus = 0
     if sharded:
+        import ctypes
+
         import torch.distributed as dist
 
+        # every rank next to its GPU: launching thread, sink workers (they inherit the mask) and first-touch pages
+        if os.environ.get("BGS_BIND_NUMA", "1") != "0":
+            got = ctypes.c_int(0)
+            _abi.check(_abi.lib().bgs_bind_host_thread(local_rank, ctypes.byref(got)))
+            bound_cpus = got.value
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
 
-    from simulator.batch import ConnectBatch, HostEvent, PinnedArray, RewardSink, expand_outcomes_host
-    from simulator.game import _abi
-    from simulator.sharding import SharedRewardRing, gather_outcomes_to, shard_range, sum_steps
-
-    # N > 1, default: one host array in shared memory, every rank delivers its own rows with its own sink
-    ring_mode = sharded and args.gather == "shm" and args.handover == "codes"
-    if args.host_threads <= 0:
-        args.host_threads = 6 if world == 1 else 4 if ring_mode else min(12, 4 + 2 * world)
     n = args.batch
     if sharded and n % 4:
         print("bench.py: --batch must be a multiple of 4 when sharded (4 outcome codes per byte)", file=sys.stderr)
         return 2
     handover = args.handover
-    if sharded and handover == "pairs":
-        handover = "codes"  # ranks exchange codes; int8 pairs would put 8x the bytes on xGMI and on rank 0's PCIe link
+    ring_mode = sharded and args.gather == "shm" and handover == "codes"
+    lib_gather = sharded and args.gather == "rccl" and handover == "codes" and backend == "nccl"
+    torch_gather = sharded and args.gather == "rccl" and handover == "codes" and backend != "nccl"  # gloo rehearsal
+    if args.host_threads <= 0:
+        args.host_threads = 6 if not sharded else 4 if ring_mode else min(24, 4 + 2 * world)
     depth = max(1, args.inflight)
     os.environ.setdefault("BGS_ROLLOUT_WPS", "2")  # waves per SIMD per launch; `depth` launches share the chip
     streams = [torch.cuda.Stream(device=local_rank) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
     gpu = torch.device("cuda", local_rank)
     code_bytes = (n + 3) // 4
     owner = rank == 0  # rank 0 owns "the one host array"
-    # per in-flight slot: the batch; (N > 1) its packed outcome codes and, on rank 0, the gathered codes of all ranks;
-    # the HOST array the step's rewards end in: int8[world * n, 2] on rank 0 (N = 1: int8[n, 2])
-    # One GPU: the hand-over pipeline is deeper than the GPU's (three times as many host arrays / sink slots as streams),
-    # so the launching thread waits for the delivery of step i - 3 * depth, not i - depth, before it enqueues step i:
-    # waiting on the previous step of the SAME stream would leave the GPU one batch short for the length of the delivery.
-    # (Measured, tools/slots_sweep.sh: 3 per stream is 3 % faster than 2 on a 20-step run -- every stream always has a
-    # launch queued behind the running one, whatever the host does for ~100 us -- and 4 is slower: more arrays than the
-    # caches hold.)
-    host_slots = depth if sharded and not ring_mode else int(os.environ.get("BGS_BENCH_SLOT_FACTOR", "3")) * depth
+    # The hand-over pipeline is deeper than the GPU's (three times as many host arrays / sink slots as streams), so the
+    # launching thread waits for the delivery of step i - 3 * depth, not i - depth, before it enqueues step i (measured,
+    # tools/slots_sweep.sh: 3 per stream is 3 % faster than 2 on a 20-step run, 4 is slower: more arrays than the caches
+    # hold).  Rank 0 of an RCCL gather holds world x 2 MiB per array: two per stream there.
+    factor = int(os.environ.get("BGS_BENCH_SLOT_FACTOR", "2" if (lib_gather or torch_gather) and world > 1 else "3"))
+    host_slots = max(2, factor * depth)
     ring = None
     if ring_mode:
         try:
@@ -231,38 +495,38 @@ def main() -> int:
             if rank == 0:
                 print(f"bench.py: {exc}; falling back to --gather rccl", file=sys.stderr)
             ring_mode = False
-            host_slots = depth
+            lib_gather, torch_gather = backend == "nccl", backend != "nccl"
             if args.host_threads == 4:
-                args.host_threads = min(12, 4 + 2 * world)
-    batches, packed, packed_buf, all_packed, host_rewards, events = [], [], [], [], [], []
+                args.host_threads = min(24, 4 + 2 * world)
+    batches = []
     for s in streams:
         with torch.cuda.stream(s):
             b = ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=local_rank, use_torch=True)  # ordered onto stream s
             b.set_first_game(shard_range(n * world, rank, world)[0])
             batches.append(b)
-            packed_buf.append(torch.zeros((n + 63) // 64 * 16, dtype=torch.uint8, device=gpu) if sharded and not ring_mode else None)
-            packed.append(packed_buf[-1][:code_bytes] if sharded and not ring_mode else None)
-            all_packed.append(torch.empty(world * code_bytes, dtype=torch.uint8, device=gpu) if sharded and owner and not ring_mode else None)
-    for slot in range(host_slots):
-        if ring_mode:
-            host_rewards.append(ring.mine(slot))  # this rank's rows of the shared array (touched by the ring already)
-            events.append(None)
-        elif handover == "pairs":
-            host_rewards.append(PinnedArray((n, 2), np.int8))
-            events.append(HostEvent(local_rank))
-        elif handover == "codes" and owner:
-            # written by the sink's worker threads; filled here so that every page is mapped before the clock starts
-            host_rewards.append(np.full((world * n, 2), 0x55, dtype=np.int8))
-            events.append(None)
-        else:
-            host_rewards.append(None)
-            events.append(None)
-    if ring_mode:
-        sink = RewardSink(n, slots=host_slots, threads=max(1, args.host_threads), device=local_rank)
-    else:
-        sink = RewardSink(world * n, slots=host_slots, threads=max(1, args.host_threads), device=local_rank) \
-            if handover == "codes" and owner else None
     device = gpu if backend == "nccl" else torch.device("cpu")
+    rows = world * n if (lib_gather or torch_gather) else n
+    sink = gather = None
+    host_rewards = []
+    if handover == "codes":
+        if ring_mode:
+            host_rewards = [ring.mine(k) for k in range(host_slots)]  # this rank's rows of the shared arrays
+            sink = RewardSink(n, slots=host_slots, threads=args.host_threads, device=local_rank)
+            ring.attach(sink)  # the sink's workers announce every delivery in this rank's progress word
+        elif lib_gather:
+            # written by rank 0's sink workers; filled here so that every page is mapped before the clock starts
+            host_rewards = [np.full((rows, 2), 0x55, dtype=np.int8) if owner else None for _ in range(host_slots)]
+            gather = RewardGather(dist, n, slots=host_slots, host_threads=args.host_threads, device=local_rank)
+        elif torch_gather:
+            host_rewards = [np.full((rows, 2), 0x55, dtype=np.int8) if owner else None for _ in range(host_slots)]
+        else:
+            host_rewards = [np.full((n, 2), 0x55, dtype=np.int8) for _ in range(host_slots)]
+            sink = RewardSink(n, slots=host_slots, threads=args.host_threads, device=local_rank)
+    exe = None
+    if not torch_gather:
+        exe = RolloutExecutor(batches, sink=sink, gather=gather, host_arrays=host_rewards if (sink or gather) else (), seed0=SEED)
+        if ring_mode:
+            exe.set_ring(ring, consumer=owner, lag=host_slots - depth)
 
     def barrier():
         torch.cuda.synchronize()
@@ -270,136 +534,83 @@ def main() -> int:
             dist.barrier()
             torch.cuda.synchronize()
 
-    tickets = [None] * host_slots  # the sink ticket of the step last delivered into each host array
-    ticket_step = [0] * host_slots  # (shared array: the step that ticket belongs to, published once it is delivered)
-    pending = [None] * depth       # the in-flight reward gather of each stream slot (N > 1)
+    # ---- the gloo rehearsal of --gather rccl: torch collectives on host copies, a Python loop (never the timed path
+    # of a real run: RCCL cannot put several ranks on one GPU, so a one-GPU box exercises the gather's ordering here)
+    state = {"step": 0}
 
-    def settle(k, final=False):
-        """Bring slot k's earlier steps one stage further before the slot is reused.  The stages of a step are
-        rollout -> (N > 1: gather of the codes to rank 0 -> hand the gathered codes to the sink) -> rewards in
-        host_rewards[k]; the wait for a stage happens one turn of the slot later, so the host never blocks on work it
-        has only just enqueued.  final=True completes everything (end of the timed region)."""
-        if tickets[k] is not None:      # the step submitted to the sink one turn ago: its rewards are in the host array
-            sink.wait(tickets[k])
-            tickets[k] = None
-            if ring is not None:
-                ring.publish(ticket_step[k])  # this rank's rows of that step are in the shared array
-        if k < depth and pending[k] is not None:      # the gather started one turn ago
-            pending[k].wait()           # (only makes stream k wait for the collective)
-            pending[k] = None
-            if owner:                   # the gathered codes are on rank 0's device: the sink takes them to the host
-                tickets[k] = sink.submit_packed(all_packed[k], world * n, host_rewards[k], stream=streams[k].cuda_stream)
-        if final and tickets[k] is not None:
-            sink.wait(tickets[k])
-            tickets[k] = None
-        if handover == "pairs" and events[k] is not None and events[k].armed:
-            events[k].synchronize()
-            events[k].armed = False
+    def torch_gather_steps(count, with_handover):
+        for _ in range(count):
+            i = state["step"]
+            b = batches[i % depth]
+            with torch.cuda.stream(streams[i % depth]):
+                if not with_handover:
+                    b.rollout(SEED + i, from_initial=True)
+                else:
+                    buf = torch.zeros((n + 63) // 64 * 16, dtype=torch.uint8, device=gpu)
+                    b.rollout_outcomes_tensor(buf, SEED + i, from_initial=True)
+                    got = gather_outcomes_to(dist, buf[:code_bytes].cpu(), torch.empty(world * code_bytes, dtype=torch.uint8) if owner else None, dst=0)
+                    if owner:
+                        expand_outcomes_host(got.numpy(), world * n, host_rewards[i % host_slots])
+                        state["last_host"] = host_rewards[i % host_slots]
+            state["step"] = i + 1
 
-    for e in events:
-        if e is not None:
-            e.armed = False
-
-    def one_step(i, with_handover, ev=None):
-        k = i % depth
-        b = batches[k]
-        if dist is None or ring_mode:
-            # one GPU, or N GPUs delivering into the shared host array (every rank runs the one-GPU loop on its rows):
-            # library calls only (each batch is bound to its own stream), no torch stream switching
-            h = i % host_slots
-            if with_handover:
-                settle(h)
-            if ev is not None:
-                ev[0].record(streams[k])
-            if not with_handover or handover == "none":
-                b.rollout(SEED + i, from_initial=True)
-            elif handover == "codes":
-                tickets[h] = sink.rollout(b, host_rewards[h], SEED + i, from_initial=True)
-                ticket_step[h] = i
-            else:
-                b.rollout_to_host(host_rewards[h], SEED + i, from_initial=True, codes=False, event=events[h])
-                events[h].armed = True
-            if ev is not None:
-                ev[1].record(streams[k])  # (with a hand-over the bracket includes the pack kernel or the copy: the
-                # rollout kernel's own duration is taken from the device-resident pass then)
-            return
-        with torch.cuda.stream(streams[k]):
-            if with_handover:
-                settle(k)
-            if ev is not None:
-                ev[0].record(streams[k])
-            if not with_handover or handover == "none":
-                b.rollout(SEED + i, from_initial=True)
-                if ev is not None:
-                    ev[1].record(streams[k])
-                return
-            # N > 1: the path's only exchange -- every rank's outcome codes to rank 0 (RCCL over xGMI), asynchronous, so
-            # the stream goes straight on to its next rollout; rank 0's sink takes the codes to the host one turn later.
-            # The rollout kernel writes the codes into the send buffer itself (bgs_rollout_pack)
-            b.rollout_outcomes_tensor(packed_buf[k], SEED + i, from_initial=True)
-            if ev is not None:
-                ev[1].record(streams[k])
-            if backend == "nccl":
-                pending[k] = gather_outcomes_to(dist, packed[k], all_packed[k] if owner else None, dst=0, async_op=True)
-            else:
-                got = gather_outcomes_to(dist, packed[k].cpu(), torch.empty(world * code_bytes, dtype=torch.uint8) if owner else None, dst=0)
-                if owner:
-                    expand_outcomes_host(got.numpy(), world * n, host_rewards[k])
+    def run_steps(count, with_handover, stride=0):
+        if exe is not None:
+            exe.enqueue(count, with_handover and handover != "none", stride)
+        else:
+            torch_gather_steps(count, with_handover)
 
     def drain():
-        for k in range(host_slots):
-            with torch.cuda.stream(streams[k % depth]):
-                settle(k, final=True)
+        if exe is not None:
+            exe.drain()
 
-    def timed_region(first_step, count, with_handover, stride):
-        evs = {}
+    def steps_done():
+        return exe.steps if exe is not None else state["step"]
+
+    def timed_region(count, with_handover, stride):
         for b in batches:
             b.reset_steps()
         barrier()
         t0 = time.perf_counter()
-        for i in range(count):
-            ev = None
-            if stride and i % stride == 0:
-                ev = evs[i] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            one_step(first_step + i, with_handover, ev)
+        run_steps(count, with_handover, stride)
         t_enqueued = time.perf_counter()
-        if with_handover:
-            drain()  # every step's rewards are in their host array before the clock stops
+        drain()  # every step's rewards are in their host array (all ranks' rows, for the consumer) before the clock stops
         t_drained = time.perf_counter()
         barrier()
         dt = time.perf_counter() - t0
         if os.environ.get("BGS_BENCH_TRACE"):
-            print(f"[trace] {count} steps, handover={with_handover}: enqueued at {(t_enqueued - t0) * 1e3:.3f} ms, "
+            print(f"[trace] rank {rank}: {count} steps, handover={with_handover}: enqueued at {(t_enqueued - t0) * 1e3:.3f} ms, "
                   f"rewards on the host at {(t_drained - t0) * 1e3:.3f} ms, device idle at {dt * 1e3:.3f} ms", file=sys.stderr)
         steps_local = sum(b.steps for b in batches)
-        kernel_ms = sum(s.elapsed_time(e) for s, e in evs.values()) / max(len(evs), 1) if evs else None
-        return dt, steps_local, kernel_ms
+        kernel_ms = exe.kernel_ms()[0] if exe is not None and stride else None
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            steps_total = sum_steps(dist, steps_local, device)
+        else:
+            steps_total = steps_local
+        return dt, steps_total, steps_local, kernel_ms
 
-    for i in range(args.warmup):
-        one_step(i, True)
+    run_steps(args.warmup, True)
     drain()
-    # HIP-event pairs bracket a sample of the launches (each record is a marker packet on the stream): about 32 pairs
-    stride = max(2, args.steps // 32)
-    elapsed, steps_local, kernel_ms = timed_region(args.warmup, args.steps, True, stride)
-    last = args.warmup + args.steps - 1
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        steps_total = sum_steps(dist, steps_local, device)
-    else:
-        steps_total = steps_local
+    # HIP-event pairs bracket a sample of the launches on the launch stream: about 32 pairs
+    stride = max(1, args.steps // 32)
+    elapsed, steps_total, steps_local, kernel_ms = timed_region(args.steps, True, stride)
+    last = steps_done() - 1  # index (= seed offset) of the last timed step
 
     # the host array of the LAST timed step (a copy: the extra passes below reuse the slots)
     final_host = None
     if owner and handover != "none":
-        slot = last % host_slots
-        final_host = np.array(ring.array(slot) if ring is not None else
-                              host_rewards[slot].array if handover == "pairs" else host_rewards[slot])
+        if ring is not None:
+            final_host = np.array(ring.array((exe.handovers - 1) % host_slots))
+        elif exe is not None:
+            final_host = np.array(exe.last_host_array())
+        else:
+            final_host = np.array(state["last_host"])
 
     gather_ok = None
-    if dist is not None and owner:
+    if dist is not None and owner and final_host is not None:
         # the host array must hold every rank's rewards in global game order: rank 0 re-plays the first games of the
         # LAST rank's shard on its own GPU (RNG streams are keyed by global game id) and compares
         probe = ConnectBatch(HEIGHT, WIDTH, COUNT, 4096, device=local_rank, use_torch=True)
@@ -408,48 +619,48 @@ def main() -> int:
         gather_ok = bool((probe.reward == final_host[(world - 1) * n : (world - 1) * n + 4096]).all())
         probe.close()
 
+    # two more timed regions of the same length, back to back in the same process: how much one region's value moves
+    repeats = [steps_total / elapsed]
+    if not args.no_repeats:
+        for _ in range(2):
+            dt, st, _, _ = timed_region(args.steps, True, 0)
+            repeats.append(st / dt)
+
     # the same launches without the hand-over (rewards stay on the device), timed separately: what the hand-over costs
     device_resident = None
     if not args.no_device_resident and handover != "none":
         reps = min(args.steps, 100)
-        dt, st_local, k_ms = timed_region(last + 1, reps, False, max(2, reps // 32))
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-            st_local = sum_steps(dist, st_local, device)
-        device_resident = {"value": st_local / dt, "unit": "env-steps/s", "ms_per_step": dt / reps * 1e3, "steps": reps,
+        dt, st, _, k_ms = timed_region(reps, False, max(1, reps // 32))
+        device_resident = {"value": st / dt, "unit": "env-steps/s", "ms_per_step": dt / reps * 1e3, "steps": reps,
                            "kernel_ms_per_launch": k_ms}
-        if dist is None:
-            kernel_ms = k_ms  # the hand-over brackets include the pack kernel / the copy
 
     if rank == 0:
         value = steps_total / elapsed
-        ms_per_step = elapsed / max(args.steps, 1) * 1e3
-        steps_per_launch = steps_local / max(args.steps, 1)
+        ms_per_step = elapsed / args.steps * 1e3
+        steps_per_launch = steps_local / args.steps
         build = _abi.build_id()
-        counters, why_not = committed_counters(build) if n == BATCH_PER_GPU else (None, "counters are for batch 2^20")
+        counters, why_not = committed_counters(build, "rollout_counters") if n == BATCH_PER_GPU else (None, "counters are for batch 2^20")
+        roof = valu_issue_block(counters, why_not, ms_per_step * 1e-3, build)
+        roof["kernel"] = counters["kernel"].split("(")[0].split("::")[-1] if counters and counters.get("kernel") else "k_connect_rollout_opened"
+        roof["kernel_ms_per_launch"] = kernel_ms
+        roof["event_pairs"] = len(range(0, args.steps, stride))
+        roof["launches_in_flight"] = depth
         stored = STORED_BYTES_PER_GAME * n  # by construction: every game is written exactly once, when it ends
-        achieved = stored / (kernel_ms * 1e-3) / 1e9
-        valu = {"note": why_not}
-        if counters:
-            instr = counters["valu_wave_instructions_per_launch"]
-            rate = instr / (ms_per_step * 1e-3) / 1e9
-            mix_peak = VALU_PEAK_SIMD32 * 2.0 / counters["mix_cycles_per_instruction"]
-            valu = {
-                "wave_instr_per_launch": instr,
-                "achieved_Ginstr_per_s": rate,
-                "peak_simd32_Ginstr_per_s": VALU_PEAK_SIMD32,
-                "frac_of_simd32_peak": rate / VALU_PEAK_SIMD32,
-                "mix_ceiling_Ginstr_per_s": mix_peak,
-                "frac_of_mix_ceiling": rate / mix_peak,
-                "mix_cycles_per_instruction": counters["mix_cycles_per_instruction"],
-                "basis": "SIMD-32 peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction "
-                "(MI355X_MICROARCH.md); mix ceiling = the same with this kernel's measured cycles per instruction "
-                "(tools/valu_mix.py: loop-body instruction mix x tools/ubench.hip issue costs); instruction count from "
-                f"rocprofv3 SQ_INSTS_VALU on build {build}; launches overlap, so the rate uses ms_per_step",
-            }
-        to_host = {"none": 0, "pairs": 2 * n, "codes": code_bytes * world}[handover]
+        moved = counters["hbm_bytes_per_launch"] if counters and counters.get("hbm_bytes_per_launch") else stored
+        if kernel_ms:
+            roof["hbm"] = {"bytes_per_launch": moved, "by_construction": stored, "achieved_GBps": moved / (kernel_ms * 1e-3) / 1e9,
+                           "peak_GBps": HBM_PEAK_GBS, "frac": moved / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "bytes the kernel really moves (counters; 19 B per finished game by construction) over its "
+                           "own mean duration: boards live in registers from the first to the last ply, so HBM does not bind"}
+            roof["algorithmic"] = {"bytes_per_env_step": BYTES_PER_STEP, "bytes_per_launch": steps_per_launch * BYTES_PER_STEP,
+                                   "GBps_over_kernel_duration": steps_per_launch * BYTES_PER_STEP / (kernel_ms * 1e-3) / 1e9,
+                                   "GBps_over_ms_per_step": steps_per_launch * BYTES_PER_STEP / (ms_per_step * 1e-3) / 1e9,
+                                   "note": "SURVEY 8d's per-ply byte model (32 B per env-step): what a ply-per-launch design would "
+                                   "move. A fused rollout avoids it, so the figure may exceed the HBM peak; it is not a roofline"}
+        to_host = 0 if handover == "none" else code_bytes * (world if (lib_gather or torch_gather) else 1)
+        roof["pcie"] = {"bytes_per_step": to_host, "achieved_GBps": to_host / (ms_per_step * 1e-3) / 1e9,
+                        "peak_GBps": PCIE_PEAK_GBS, "frac": to_host / (ms_per_step * 1e-3) / 1e9 / PCIE_PEAK_GBS}
+        gather_name = "none" if not sharded else "shm" if ring_mode else "rccl" if lib_gather else f"{backend} (rehearsal)"
         out = {
             "metric": "env-steps/sec, Connect4(6,7,4) random rollout, batch="
             + ("2^20" if n == BATCH_PER_GPU else str(n)) + " per GPU",
@@ -464,62 +675,59 @@ def main() -> int:
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
+            "value_median_of_3": sorted(repeats)[len(repeats) // 2] if len(repeats) == 3 else None,
+            "values_of_3": repeats if len(repeats) == 3 else None,
             "config": {
                 "workload": f"Connect4({HEIGHT},{WIDTH},{COUNT}) uniform-random rollout from the initial state to terminal, "
                 f"batch={n} boards per GPU, seed 0x{SEED:016X}+step, philox4x32-10 keyed by global game id",
                 "batch_per_gpu": n,
                 "global_batch": n * world,
-                "env_steps_per_step": steps_total / max(args.steps, 1),
+                "env_steps_per_step": steps_total / args.steps,
                 "rewards_to_host": handover != "none",
-                "handover": {"codes": f"2-bit outcome codes ({code_bytes * world} B per step over PCIe) -> page-locked slot -> "
-                             f"{args.host_threads} host threads expand into int8[{world * n}, 2]",
-                             "pairs": f"int8[{n}, 2] reward buffer ({2 * n} B per step over PCIe) -> page-locked host array",
+                "handover": {"codes": f"2-bit outcome codes ({code_bytes} B per rank and step) -> page-locked slot -> "
+                             f"{args.host_threads} host threads expand into int8[{rows}, 2]",
                              "none": "rewards stay on the device"}[handover],
+                "gather": gather_name,
                 "sharding": (f"game ids split over {world} rank(s); no data-path collective: the host array int8[{world * n}, 2] is "
                              f"in shared memory and every rank's own sink delivers its rows ({code_bytes} B of codes per step "
-                             f"over the rank's own PCIe link, {args.host_threads} host threads per rank)" if ring_mode else
-                             f"game ids split over {world} rank(s); per step {'RCCL' if backend == 'nccl' else backend} gather of "
-                             f"2-bit outcome codes ({code_bytes} B per rank) to rank 0" if sharded else "single GPU"),
+                             f"over the rank's own PCIe link, {args.host_threads} host threads per rank); rank 0 consumes: it waits "
+                             f"for every rank's delivery of each step (futex) and releases the slot" if ring_mode else
+                             f"game ids split over {world} rank(s); per step RCCL gather (in-library: persistent communicator, "
+                             f"communication thread and stream) of 2-bit outcome codes ({code_bytes} B per rank) to rank 0, whose "
+                             f"sink expands them" if lib_gather else
+                             f"game ids split over {world} rank(s); per step {backend} gather of 2-bit outcome codes "
+                             f"({code_bytes} B per rank) to rank 0 (rehearsal of the RCCL gather on host copies)" if torch_gather else
+                             "single GPU"),
                 "gathered_rewards_verified": gather_ok,
+                "numa_bound_cpus": bound_cpus if sharded else None,
                 "inflight_batches": depth,
+                "host_arrays": host_slots,
+                "loop": "native (bgs_pipeline_enqueue: one library call per timed region)" if exe is not None else "python (rehearsal)",
                 "waves_per_simd_per_launch": int(os.environ["BGS_ROLLOUT_WPS"]),
                 "build_id": build,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_connect_rollout_opened",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": counters["hbm_bytes_per_launch"] if counters else None,
-                "bytes_per_launch": stored,
-                "kernel_ms_per_launch": kernel_ms,
-                "event_pairs": len(range(0, args.steps, stride)),
-                "launches_in_flight": depth,
-                "algorithmic_bytes_per_launch": steps_per_launch * BYTES_PER_STEP,
-                "algorithmic_GBps_avoided": steps_per_launch * BYTES_PER_STEP / (kernel_ms * 1e-3) / 1e9,
-                "valu_issue": valu,
-                "pcie": {"bytes_per_step": to_host, "achieved_GBps": to_host / (ms_per_step * 1e-3) / 1e9,
-                         "peak_GBps": PCIE_PEAK_GBS, "frac": to_host / (ms_per_step * 1e-3) / 1e9 / PCIE_PEAK_GBS},
-                "note": "achieved = bytes the kernel really moves (19 B per finished game: planes, status, reward; boards "
-                "live in registers from first to last ply) / its mean duration: the kernel is NOT HBM-bound, the fraction "
-                "is small by design. algorithmic_* is SURVEY 8d's 32 B per env-step model, i.e. the per-ply traffic the "
-                "fusion avoids (it may exceed the HBM peak and is not a roofline). The binding resource is VALU issue "
-                "(valu_issue). With launches_in_flight > 1 a launch shares the chip with its neighbours, so its own "
-                "duration is longer than ms_per_step.",
-            },
+            "roofline": roof,
         }
         if device_resident is not None:
             device_resident["host_over_device"] = value / device_resident["value"]
             out["device_resident"] = device_resident
-        if world == 1 and not args.no_cpu_baseline:
-            head = final_host[:65536] if final_host is not None else batches[last % depth].reward[:65536]
-            out["cpu_baseline"] = cpu_baseline(SEED + last, head)
+        if world == 1 and not sharded:
+            if not args.no_cpu_baseline:
+                head = final_host[:65536] if final_host is not None else batches[last % depth].reward[:65536]
+                out["cpu_baseline"] = cpu_baseline(SEED + last, head)
+                out["cpu_baseline"]["gpu_single_game_latency_us"] = gpu_single_game_latency()
+            if not args.no_other_configs:
+                out["other_configs"] = other_configs()
         print(json.dumps(out), flush=True)
 
+    if exe is not None:
+        exe.close()
+    if gather is not None:
+        gather.close()
     if sink is not None:
         sink.close()
+    if ring is not None:
+        ring.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -10,6 +10,13 @@
 // all of it enqueued behind the rollout on the batch's stream and overlapped with the next batches' kernels.
 // No game rule lives here: a reward pair is a fixed function of the outcome code (bgs_common.h reward_pair).
 #include <immintrin.h>
+#include <limits.h>
+#include <linux/futex.h>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -108,6 +115,59 @@ int enter_device(int device) {
     return BGS_OK;
 }
 
+// ---- progress words: monotonic int64 counters in (possibly shared) host memory that sleepers wait on ---------------
+// The futex is the low 32 bits of the word (little endian); a waiter re-reads the whole word after every wake-up.
+long futex(volatile void* addr, int op, uint32_t val, const struct timespec* timeout) {
+    return syscall(SYS_futex, addr, op, val, timeout, nullptr, 0);
+}
+
+void progress_store_max(volatile int64_t* word, int64_t value) {
+    auto* a = reinterpret_cast<std::atomic<int64_t>*>(const_cast<int64_t*>(word));
+    int64_t seen = a->load(std::memory_order_relaxed);
+    while (seen < value && !a->compare_exchange_weak(seen, value, std::memory_order_release, std::memory_order_relaxed)) {
+    }
+    if (seen < value) futex(word, FUTEX_WAKE, INT_MAX, nullptr);  // (not FUTEX_PRIVATE: waiters may be other processes)
+}
+
+// CPUs of the NUMA node the device hangs off, intersected with what this process may use; empty = unknown / one node
+bool device_node_cpus(int device, cpu_set_t* out) {
+    CPU_ZERO(out);
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return false;
+    for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
+    char path[256];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0) return false;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return false;
+    char list[4096] = {0};
+    const bool have = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!have) return false;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    int any = 0;
+    char* save = nullptr;
+    for (char* tok = strtok_r(list, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {
+        int lo = 0, hi = 0;
+        const int k = sscanf(tok, "%d-%d", &lo, &hi);
+        if (k < 1) continue;
+        if (k == 1) hi = lo;
+        for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &allowed)) {
+                CPU_SET(c, out);
+                ++any;
+            }
+    }
+    return any > 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -131,7 +191,9 @@ struct bgs_reward_sink {
     std::condition_variable cv_submit;   // a job was published / shutdown
     std::condition_variable cv_landed;   // a job's codes have arrived in its slot / shutdown
     std::condition_variable cv_done;     // a job completed
-    int64_t submitted = 0;               // tickets handed out: jobs [0, submitted) are published
+    int64_t claimed = 0;                 // tickets handed out (claim): their slots are reserved
+    int64_t submitted = 0;               // jobs [0, submitted) are published, in ticket order
+    volatile int64_t* progress = nullptr;  // optional progress word (bgs_sink_set_progress): receives `completed`
     int64_t landed_upto = 0;             // the codes of jobs [0, landed_upto) are in their slots
     int64_t completed = 0;               // jobs [0, completed) are in their host arrays
     std::vector<int> parts_done;         // [slots] workers that finished their share of the slot's job
@@ -179,7 +241,9 @@ struct bgs_reward_sink {
                     if (submitted <= ticket) return;  // stop, nothing left
                     job = jobs[slot];
                 }
-                if (poll) {
+                if (job.n_games == 0) {
+                    ok = false;  // the enqueue failed: no event was recorded for this ticket
+                } else if (poll) {
                     // busy-poll: the wake-up out of hipEventSynchronize costs tens of microseconds, which matters at
                     // the end of a short run (the last delivery is not overlapped with anything)
                     hipError_t e;
@@ -225,6 +289,7 @@ struct bgs_reward_sink {
                     ++completed;  // jobs complete in ticket order: every worker walks the tickets in order
                     a_completed.store(completed, std::memory_order_release);
                     cv_done.notify_all();
+                    if (progress) progress_store_max(progress, completed);  // sleepers in this or another process
                 }
             }
         }
@@ -233,26 +298,44 @@ struct bgs_reward_sink {
 
 namespace {
 
-// claim the next ticket's slot, waiting while the ring is full; returns the slot
+// Reserve the next ticket and its slot, waiting while the ring is full.  The ticket is taken HERE, under the lock, so
+// two threads submitting to one sink (say one per stream) never share a slot; what they enqueue for their tickets may
+// interleave freely, publish() puts the jobs back in ticket order.
 int64_t claim(bgs_reward_sink* s) {
     s->spin_for(s->a_completed, s->a_submitted.load(std::memory_order_relaxed) - s->slots);
     std::unique_lock<std::mutex> lock(s->mu);
-    s->cv_done.wait(lock, [&] { return s->submitted - s->completed < s->slots; });
-    return s->submitted;
+    s->cv_done.wait(lock, [&] { return s->claimed - s->completed < s->slots; });
+    return s->claimed++;
 }
 
-void publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward) {
+// `ok` false: the enqueue for this ticket failed; the job is published all the same (the ring must not stall) with
+// nothing to expand, and the sink remembers the failure
+void publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok = true) {
     {
-        std::lock_guard<std::mutex> lock(s->mu);
-        s->jobs[ticket % s->slots].n_games = n_games;
+        std::unique_lock<std::mutex> lock(s->mu);
+        s->cv_done.wait(lock, [&] { return s->submitted == ticket; });  // (tickets of other threads publish first)
+        s->jobs[ticket % s->slots].n_games = ok ? n_games : 0;
         s->jobs[ticket % s->slots].host_reward = host_reward;
+        if (!ok) s->failed = true;
         s->submitted = ticket + 1;
         s->a_submitted.store(ticket + 1, std::memory_order_release);
     }
     s->cv_submit.notify_one();  // only worker 0 waits here
+    s->cv_done.notify_all();    // (publishers waiting for their turn)
 }
 
 }  // namespace
+
+// ---- the sink as the in-library gather uses it (bgs_multi.hip) ------------------------------------------------------
+namespace bgs {
+int64_t sink_claim(bgs_reward_sink* s) { return claim(s); }
+uint8_t* sink_slot_device(bgs_reward_sink* s, int64_t ticket) { return s->mapped[ticket % s->slots]; }
+uint8_t* sink_slot_host(bgs_reward_sink* s, int64_t ticket) { return s->pinned[ticket % s->slots]; }
+hipEvent_t sink_slot_event(bgs_reward_sink* s, int64_t ticket) { return s->landed[ticket % s->slots]; }
+void sink_publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok) {
+    publish(s, ticket, n_games, host_reward, ok);
+}
+}  // namespace bgs
 
 extern "C" {
 
@@ -388,7 +471,75 @@ int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_r
         return fail(BGS_ERR_RUNTIME, "reward sink allocation failed: %s", hipGetErrorString(err));
     }
     for (int t = 0; t < threads; ++t) s->workers.emplace_back([s, t] { s->work(t); });
+    // the workers write the caller's array and read the slots the GPU fills: keep them on the NUMA node the device hangs
+    // off (a no-op on one-node hosts and when the process is already confined; BGS_SINK_AFFINITY=0 leaves them alone)
+    const char* aff = getenv("BGS_SINK_AFFINITY");
+    cpu_set_t cpus;
+    if (!(aff && atoi(aff) == 0) && device_node_cpus(device, &cpus))
+        for (auto& w : s->workers) (void)pthread_setaffinity_np(w.native_handle(), sizeof cpus, &cpus);
     *out = s;
+    return BGS_OK;
+}
+
+int bgs_sink_set_progress(bgs_reward_sink* s, int64_t* word) {
+    NEED(s != nullptr, "sink is NULL");
+    NEED(word == nullptr || (reinterpret_cast<uintptr_t>(word) & 7u) == 0, "progress word must be 8-byte aligned");
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->progress = word;
+    if (word) progress_store_max(word, s->completed);
+    return BGS_OK;
+}
+
+int bgs_sink_completed(bgs_reward_sink* s, int64_t* completed) {
+    NEED(s != nullptr && completed != nullptr, "NULL argument");
+    *completed = s->a_completed.load(std::memory_order_acquire);
+    return BGS_OK;
+}
+
+int bgs_progress_store(int64_t* word, int64_t value) {
+    NEED(word != nullptr && (reinterpret_cast<uintptr_t>(word) & 7u) == 0, "progress word must be 8-byte aligned");
+    progress_store_max(word, value);
+    return BGS_OK;
+}
+
+int bgs_progress_wait(const int64_t* words, int64_t count, int64_t stride_words, int64_t target, int64_t timeout_ms,
+                      int64_t* laggard) {
+    NEED(words != nullptr && count >= 1 && stride_words >= 1, "bad argument");
+    NEED((reinterpret_cast<uintptr_t>(words) & 7u) == 0, "progress words must be 8-byte aligned");
+    struct timespec start;
+    clock_gettime(CLOCK_MONOTONIC, &start);
+    for (int64_t i = 0; i < count; ++i) {
+        auto* a = reinterpret_cast<const std::atomic<int64_t>*>(words + i * stride_words);
+        for (;;) {
+            const int64_t seen = a->load(std::memory_order_acquire);
+            if (seen >= target) break;
+            struct timespec now;
+            clock_gettime(CLOCK_MONOTONIC, &now);
+            const int64_t waited_ms = (now.tv_sec - start.tv_sec) * 1000 + (now.tv_nsec - start.tv_nsec) / 1000000;
+            if (timeout_ms >= 0 && waited_ms >= timeout_ms) {
+                if (laggard) *laggard = i;
+                return bgs::fail(BGS_ERR_RUNTIME, "progress word %lld is at %lld, waiting for %lld: timed out after %lld ms",
+                                 (long long)i, (long long)seen, (long long)target, (long long)waited_ms);
+            }
+            // sleep until the low half changes (or 50 ms pass: a store by a process that died is never announced)
+            int64_t slice_ms = 50;
+            if (timeout_ms >= 0 && timeout_ms - waited_ms < slice_ms) slice_ms = timeout_ms - waited_ms;
+            if (slice_ms < 1) slice_ms = 1;
+            const struct timespec ts = {(time_t)(slice_ms / 1000), (long)(slice_ms % 1000) * 1000000L};
+            futex(const_cast<int64_t*>(words + i * stride_words), FUTEX_WAIT, (uint32_t)seen, &ts);
+        }
+    }
+    return BGS_OK;
+}
+
+int bgs_bind_host_thread(int device, int* cpus_out) {
+    cpu_set_t cpus;
+    int n = 0;
+    if (device_node_cpus(device, &cpus)) {
+        if (sched_setaffinity(0, sizeof cpus, &cpus) != 0) return fail(BGS_ERR_RUNTIME, "sched_setaffinity failed");
+        n = CPU_COUNT(&cpus);
+    }
+    if (cpus_out) *cpus_out = n;
     return BGS_OK;
 }
 
@@ -396,7 +547,7 @@ int bgs_sink_destroy(bgs_reward_sink* s) {
     if (!s) return BGS_OK;
     {
         std::unique_lock<std::mutex> lock(s->mu);
-        s->cv_done.wait(lock, [&] { return s->completed == s->submitted; });  // let published jobs finish
+        s->cv_done.wait(lock, [&] { return s->completed == s->claimed; });  // let claimed jobs finish
         s->stop = true;
         s->a_stop.store(true, std::memory_order_release);
     }
@@ -419,10 +570,11 @@ int bgs_sink_submit(bgs_reward_sink* s, bgs_batch* b, int8_t* host_reward, int64
     const int64_t t = claim(s);
     const int slot = (int)(t % s->slots);
     bgs::pack_outcomes(b, s->mapped[slot]);  // the codes go straight into the page-locked slot
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->landed[slot], b->stream));
-    publish(s, t, b->n, host_reward);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipEventRecord(s->landed[slot], b->stream);
+    publish(s, t, b->n, host_reward, err == hipSuccess);
     if (ticket) *ticket = t;
+    if (err != hipSuccess) return fail(BGS_ERR_RUNTIME, "reward hand-over could not be enqueued: %s", hipGetErrorString(err));
     return BGS_OK;
 }
 
@@ -436,10 +588,11 @@ int bgs_sink_rollout(bgs_reward_sink* s, bgs_batch* b, uint64_t seed, int32_t ma
     // the rollout kernel stores the outcome codes of the games it finishes straight into the page-locked slot (or the
     // pack kernel does, for kernels without that epilogue): when the event fires the codes are in host memory
     int rc = bgs::rollout_with_codes(b, seed, max_plies, flags, s->mapped[slot]);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(s->landed[slot], b->stream));
-    publish(s, t, b->n, host_reward);
+    hipError_t err = rc ? hipSuccess : hipEventRecord(s->landed[slot], b->stream);
+    publish(s, t, b->n, host_reward, rc == BGS_OK && err == hipSuccess);
     if (ticket) *ticket = t;
+    if (rc) return rc;
+    if (err != hipSuccess) return fail(BGS_ERR_RUNTIME, "reward hand-over could not be enqueued: %s", hipGetErrorString(err));
     return BGS_OK;
 }
 
@@ -453,10 +606,11 @@ int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* dev
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const int64_t t = claim(s);
     const int slot = (int)(t % s->slots);
-    HIP_TRY(hipMemcpyAsync(s->pinned[slot], device_packed, (size_t)(n_games + 3) / 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(s->landed[slot], stream));
-    publish(s, t, n_games, host_reward);
+    hipError_t err = hipMemcpyAsync(s->pinned[slot], device_packed, (size_t)(n_games + 3) / 4, hipMemcpyDeviceToHost, stream);
+    if (err == hipSuccess) err = hipEventRecord(s->landed[slot], stream);
+    publish(s, t, n_games, host_reward, err == hipSuccess);
     if (ticket) *ticket = t;
+    if (err != hipSuccess) return fail(BGS_ERR_RUNTIME, "reward hand-over could not be enqueued: %s", hipGetErrorString(err));
     return BGS_OK;
 }
 

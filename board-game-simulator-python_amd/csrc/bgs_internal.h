@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+struct bgs_reward_sink;  // bgs_host.hip
+
 enum { BGS_GAME_CONNECT = 1, BGS_GAME_BOUNCE = 2 };
 
 // limits of the packed representations
@@ -135,5 +137,16 @@ void pack_outcomes(const bgs_batch* b, uint8_t* d_packed);
 // bgs_rollout with the outcome codes delivered to `codes_out` (16-byte aligned, (n + 63) / 64 * 16 bytes; device or
 // device-mapped host memory): by the rollout kernel itself where it can, by k_pack_outcomes behind it otherwise
 int rollout_with_codes(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, uint8_t* codes_out);
+
+
+// ---- the reward sink as the in-library gather drives it (bgs_host.hip) ----
+// claim reserves the next ticket (blocking while every slot is in use); the caller then fills the ticket's slot --
+// sink_slot_device is the slot as the GPU sees it (device-mapped page-locked memory), sink_slot_host as the CPU does --
+// records sink_slot_event behind whatever fills it, and publishes the job (ok = false: the enqueue failed)
+int64_t sink_claim(bgs_reward_sink* s);
+uint8_t* sink_slot_device(bgs_reward_sink* s, int64_t ticket);
+uint8_t* sink_slot_host(bgs_reward_sink* s, int64_t ticket);
+hipEvent_t sink_slot_event(bgs_reward_sink* s, int64_t ticket);
+void sink_publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok);
 
 }  // namespace bgs

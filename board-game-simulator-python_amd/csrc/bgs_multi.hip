@@ -1,5 +1,10 @@
-// bgs_multi.hip -- several GPUs of one node from ONE host process, for hosts without torch.distributed
-// (include/bgs.h, bgs_multi_connect_rollout).  The path shards trivially: device r plays global game ids
+// bgs_multi.hip -- the path's only exchange between GPUs: every rank's outcome codes to rank 0 (RCCL over xGMI).
+//   * bgs_gather_*: one process per GPU (torch.distributed.run or any other launcher): a PERSISTENT communicator
+//     (ncclCommInitRank), a communication stream and a communication thread per rank, so the thread that launches the
+//     rollouts never calls into RCCL: it enqueues the rollout, records an event and goes on; the communication thread
+//     makes its stream wait for that event, enqueues the send (and, on rank 0, the receives and the hand-over of the
+//     gathered codes to the reward sink);
+//   * bgs_multi_connect_rollout: several GPUs of one node from ONE host process, for hosts without torch.distributed.  The path shards trivially: device r plays global game ids
 // [r * n, (r + 1) * n) (RNG streams are keyed by global game id, so the union equals the unsharded run); the only
 // exchange is the reward gather -- every device's 2-bit outcome codes to the first device with RCCL point-to-point
 // calls over xGMI (ncclSend / ncclRecv in one group = a gather), one copy of the gathered codes to the host and the
@@ -7,8 +12,13 @@
 // link-time dependency on it and shares the copy a framework in the same process may already have mapped.
 #include <dlfcn.h>
 
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "bgs_capi_util.h"
@@ -22,7 +32,14 @@ using bgs::fail;
 typedef void* ncclComm_t;
 constexpr int kNcclUint8 = 1;  // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1
 
+struct NcclUniqueId {
+    char internal[128];  // NCCL_UNIQUE_ID_BYTES
+};
+static_assert(sizeof(NcclUniqueId) == BGS_UNIQUE_ID_BYTES, "bgs.h promises 128 bytes");
+
 struct Rccl {
+    int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, NcclUniqueId, int) = nullptr;
     int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -31,6 +48,7 @@ struct Rccl {
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
+    std::string why;  // when !ok
 };
 
 const Rccl& rccl() {
@@ -41,7 +59,13 @@ const Rccl& rccl() {
             h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (h) break;
         }
-        if (!h) return r;
+        if (!h) {
+            const char* e = dlerror();  // (one call: a second one returns NULL)
+            r.why = e ? e : "librccl.so not found";
+            return r;
+        }
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
@@ -49,7 +73,9 @@ const Rccl& rccl() {
         r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(h, "ncclRecv"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-        r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.GetErrorString;
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send &&
+               r.Recv && r.GetErrorString;
+        if (!r.ok) r.why = "symbols missing";
         return r;
     }();
     return api;
@@ -80,7 +106,7 @@ extern "C" int bgs_multi_connect_rollout(const int* devices, int n_devices, int 
     NEED(devices != nullptr && host_reward != nullptr, "NULL argument");
     NEED(n_devices >= 1 && n_devices <= 64, "n_devices must be in 1..64");
     NEED(n_per_device >= 4 && (n_per_device & 3) == 0, "n_per_device must be a positive multiple of 4 (4 outcome codes per byte)");
-    NEED(rccl().ok, "RCCL (librccl.so) is not available: %s", dlerror() ? dlerror() : "symbols missing");
+    NEED(rccl().ok, "RCCL (librccl.so) is not available: %s", rccl().why.c_str());
     const size_t code_bytes = (size_t)n_per_device / 4;
     std::vector<bgs_batch*> batch(n_devices, nullptr);
     std::vector<hipStream_t> stream(n_devices, nullptr);
@@ -148,3 +174,220 @@ done:
     if (host_codes) (void)hipHostFree(host_codes);
     return rc;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// bgs_gather: one process per GPU, persistent communicator, communication thread
+// ------------------------------------------------------------------------------------------------
+struct bgs_gather {
+    int device = 0, rank = 0, world = 1, slots = 0;
+    int64_t n = 0;            // games per rank
+    size_t code_bytes = 0;    // n / 4: what a rank contributes per step
+    bool direct = false;      // rank 0 receives straight into the sink's device-mapped slot (BGS_GATHER_DIRECT=1)
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;        // everything RCCL does for this rank is enqueued here
+    std::vector<uint8_t*> codes;         // [slots] device: the rollout kernel writes a step's codes here
+    std::vector<uint8_t*> gathered;      // [slots] device, rank 0: the codes of all ranks, in global game order
+    std::vector<hipEvent_t> rolled;      // [slots] on the batch's stream, behind the rollout
+    std::vector<hipEvent_t> sent;        // [slots] on the communication stream, behind the step's group
+    std::vector<int8_t*> host;           // [slots] rank 0: destination of the step's rewards
+    bgs_reward_sink* sink = nullptr;     // rank 0
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t submitted = 0;               // steps handed to the communication thread
+    int64_t enqueued = 0;                // steps whose send / receives are on the communication stream
+    bool stop = false;
+    bool failed = false;
+    std::string error;
+    std::thread worker;
+
+    void fail_with(const char* what, const char* detail) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!failed) error = std::string(what) + ": " + detail;
+        failed = true;
+    }
+
+    void run() {
+        (void)hipSetDevice(device);
+        const Rccl& api = rccl();
+        for (int64_t t = 0;; ++t) {
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return stop || submitted > t; });
+                if (submitted <= t) return;
+            }
+            const int slot = (int)(t % slots);
+            bool ok = !failed;
+            hipError_t he = hipSuccess;
+            int ne = 0;
+            int64_t st = -1;
+            if (rank == 0) st = bgs::sink_claim(sink);  // (blocks while every sink slot is still being expanded)
+            uint8_t* dst = rank == 0 ? (direct ? bgs::sink_slot_device(sink, st) : gathered[slot]) : nullptr;
+            if (ok && (he = hipStreamWaitEvent(stream, rolled[slot], 0)) != hipSuccess) ok = false;
+            if (ok) {
+                // the gather: one group of point-to-point calls, every rank -> rank 0
+                if ((ne = api.GroupStart()) == 0) {
+                    ne = api.Send(codes[slot], code_bytes, kNcclUint8, 0, comm, stream);
+                    for (int r = 0; r < world && rank == 0 && ne == 0; ++r)
+                        ne = api.Recv(dst + (size_t)r * code_bytes, code_bytes, kNcclUint8, r, comm, stream);
+                    const int ge = api.GroupEnd();
+                    if (ne == 0) ne = ge;
+                }
+                if (ne != 0) ok = false;
+            }
+            if (ok && (he = hipEventRecord(sent[slot], stream)) != hipSuccess) ok = false;
+            if (rank == 0) {
+                if (ok && !direct)
+                    if ((he = hipMemcpyAsync(bgs::sink_slot_host(sink, st), gathered[slot], code_bytes * (size_t)world,
+                                             hipMemcpyDeviceToHost, stream)) != hipSuccess)
+                        ok = false;
+                if (ok && (he = hipEventRecord(bgs::sink_slot_event(sink, st), stream)) != hipSuccess) ok = false;
+                bgs::sink_publish(sink, st, n * world, host[slot], ok);
+            }
+            if (!ok && !failed) {
+                if (ne != 0) fail_with("RCCL", api.GetErrorString(ne));
+                else fail_with("HIP", hipGetErrorString(he));
+            }
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                enqueued = t + 1;
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+extern "C" {
+
+int bgs_gather_unique_id(uint8_t* id) {
+    NEED(id != nullptr, "id is NULL");
+    NEED(rccl().ok, "RCCL (librccl.so) is not available: %s", rccl().why.c_str());
+    NcclUniqueId u;
+    const int r = rccl().GetUniqueId(&u);
+    if (r != 0) return fail(BGS_ERR_RUNTIME, "ncclGetUniqueId failed: %s", rccl().GetErrorString(r));
+    memcpy(id, u.internal, sizeof u.internal);
+    return BGS_OK;
+}
+
+int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_t n_per_rank, int slots, int host_threads,
+                      bgs_gather** out) {
+    NEED(out != nullptr && id != nullptr, "NULL argument");
+    *out = nullptr;
+    NEED(world >= 1 && world <= 4096 && rank >= 0 && rank < world, "bad rank %d of %d", rank, world);
+    NEED(n_per_rank >= 4 && (n_per_rank & 3) == 0, "n_per_rank must be a positive multiple of 4 (4 outcome codes per byte)");
+    NEED(slots >= 1 && slots <= 64 && host_threads >= 1, "need 1 <= slots <= 64 and host_threads >= 1");
+    NEED(rccl().ok, "RCCL (librccl.so) is not available: %s", rccl().why.c_str());
+    HIP_TRY(hipSetDevice(device));
+    bgs_gather* g = new (std::nothrow) bgs_gather();
+    NEED(g != nullptr, "out of host memory");
+    g->device = device;
+    g->rank = rank;
+    g->world = world;
+    g->slots = slots;
+    g->n = n_per_rank;
+    g->code_bytes = (size_t)n_per_rank / 4;
+    if (const char* e = getenv("BGS_GATHER_DIRECT")) g->direct = atoi(e) != 0;
+    g->host.assign(slots, nullptr);
+    int rc = BGS_OK;
+    hipError_t he = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    const size_t padded = (size_t)(n_per_rank + 63) / 64 * 16;  // the rollout kernels store whole 16-byte units
+    for (int k = 0; k < slots && he == hipSuccess; ++k) {
+        void* p = nullptr;
+        hipEvent_t e = nullptr;
+        if ((he = hipMalloc(&p, padded)) == hipSuccess) g->codes.push_back(static_cast<uint8_t*>(p));
+        if (he == hipSuccess && rank == 0 && !g->direct && (he = hipMalloc(&p, g->code_bytes * (size_t)world)) == hipSuccess)
+            g->gathered.push_back(static_cast<uint8_t*>(p));
+        if (he == hipSuccess && (he = hipEventCreateWithFlags(&e, hipEventDisableTiming)) == hipSuccess) g->rolled.push_back(e);
+        if (he == hipSuccess && (he = hipEventCreateWithFlags(&e, hipEventDisableTiming)) == hipSuccess) g->sent.push_back(e);
+    }
+    if (he != hipSuccess) rc = fail(BGS_ERR_RUNTIME, "gather allocation failed: %s", hipGetErrorString(he));
+    if (rc == BGS_OK && rank == 0) rc = bgs_sink_create(device, n_per_rank * world, slots, host_threads, &g->sink);
+    if (rc == BGS_OK) {
+        // collective: every rank of the world is inside this call at the same time
+        NcclUniqueId u;
+        memcpy(u.internal, id, sizeof u.internal);
+        const int r = rccl().CommInitRank(&g->comm, world, u, rank);
+        if (r != 0) rc = fail(BGS_ERR_RUNTIME, "ncclCommInitRank failed: %s", rccl().GetErrorString(r));
+    }
+    if (rc != BGS_OK) {
+        (void)bgs_gather_destroy(g);
+        return rc;
+    }
+    g->worker = std::thread([g] { g->run(); });
+    *out = g;
+    return BGS_OK;
+}
+
+int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, int8_t* host_reward,
+                       int64_t* ticket) {
+    NEED(g != nullptr && b != nullptr, "NULL argument");
+    NEED(b->device == g->device, "batch lives on device %d, the gather on device %d", b->device, g->device);
+    NEED(b->n == g->n, "batch of %lld games, the gather was made for %lld per rank", (long long)b->n, (long long)g->n);
+    NEED(g->rank != 0 || host_reward != nullptr, "rank 0 needs the host array int8[world * n][2]");
+    HIP_TRY(hipSetDevice(g->device));
+    int64_t t;
+    {
+        // the codes buffer of this step was last used `slots` steps ago: its send must be on the communication stream
+        // before the batch's stream can be told to wait for it
+        std::unique_lock<std::mutex> lock(g->mu);
+        t = g->submitted;
+        g->cv.wait(lock, [&] { return g->enqueued > t - g->slots; });
+        if (g->failed) return fail(BGS_ERR_RUNTIME, "the reward gather failed earlier: %s", g->error.c_str());
+    }
+    const int slot = (int)(t % g->slots);
+    if (t >= g->slots) HIP_TRY(hipStreamWaitEvent(b->stream, g->sent[slot], 0));
+    int rc = bgs::rollout_with_codes(b, seed, max_plies, flags, g->codes[slot]);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g->rolled[slot], b->stream));
+    {
+        std::lock_guard<std::mutex> lock(g->mu);
+        g->host[slot] = host_reward;
+        g->submitted = t + 1;
+    }
+    g->cv.notify_all();
+    if (ticket) *ticket = t;
+    return BGS_OK;
+}
+
+int bgs_gather_wait(bgs_gather* g, int64_t ticket) {
+    NEED(g != nullptr, "gather is NULL");
+    int64_t enq;
+    {
+        std::unique_lock<std::mutex> lock(g->mu);
+        NEED(ticket >= 0 && ticket < g->submitted, "unknown ticket %lld", (long long)ticket);
+        g->cv.wait(lock, [&] { return g->enqueued > ticket; });
+        if (g->failed) return fail(BGS_ERR_RUNTIME, "the reward gather failed: %s", g->error.c_str());
+        enq = g->enqueued;
+    }
+    if (g->rank == 0) return bgs_sink_wait(g->sink, ticket);  // the sink belongs to the gather: same ticket numbers
+    // other ranks: "my codes have left".  A slot's event is reused `slots` steps later, and a step that old has been
+    // sent long ago (its successor could not have been enqueued otherwise)
+    if (ticket + g->slots >= enq) HIP_TRY(hipEventSynchronize(g->sent[ticket % g->slots]));
+    return BGS_OK;
+}
+
+int bgs_gather_destroy(bgs_gather* g) {
+    if (!g) return BGS_OK;
+    (void)hipSetDevice(g->device);
+    if (g->worker.joinable()) {
+        {
+            std::unique_lock<std::mutex> lock(g->mu);
+            g->cv.wait(lock, [&] { return g->enqueued == g->submitted; });
+            g->stop = true;
+        }
+        g->cv.notify_all();
+        g->worker.join();
+    }
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->sink) (void)bgs_sink_destroy(g->sink);
+    if (g->comm) (void)rccl().CommDestroy(g->comm);
+    for (auto p : g->codes) (void)hipFree(p);
+    for (auto p : g->gathered) (void)hipFree(p);
+    for (auto e : g->rolled) (void)hipEventDestroy(e);
+    for (auto e : g->sent) (void)hipEventDestroy(e);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+    return BGS_OK;
+}
+
+}  // extern "C"

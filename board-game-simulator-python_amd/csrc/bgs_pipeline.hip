@@ -1,0 +1,212 @@
+// bgs_pipeline.hip -- the rollout loop as a native executor (include/bgs.h, bgs_pipeline_*).
+//
+// The reference's loop is `while not state.has_ended: state = random.choice(state.actions).sample_next_state()`
+// (README.md:45-72), one board at a time under the GIL.  The batched form of "many such games, one after the other" is
+//   step s: batch (s mod depth) plays all its boards from the initial state to the end with seed seed0 + s, on its own
+//           stream, and the step's rewards go to host array (j mod n_host), j = number of hand-overs so far,
+// and at 2^20 Connect4 boards a step is ~34 us of GPU time: a Python loop that makes one ctypes call per step spends
+// 27 us per step on the launching thread and is launch-bound on short runs.  This executor makes the whole loop ONE
+// library call: it enqueues `count` steps back to back (~ a kernel launch and an event record each), blocks only when
+// the host array a step is about to reuse is still being delivered, and brackets a sample of the launches with timing
+// events for the roofline figures.  The hand-over is whatever the pipeline was given: a reward sink (one GPU, or N
+// ranks delivering into a shared host array) or a reward gather (RCCL to rank 0).
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+#include "bgs_capi_util.h"
+#include "bgs_common.h"
+#include "bgs_internal.h"
+
+using bgs::fail;
+
+struct bgs_pipeline {
+    int device = 0;
+    std::vector<bgs_batch*> batches;   // [depth]
+    bgs_reward_sink* sink = nullptr;
+    bgs_gather* gather = nullptr;
+    std::vector<int8_t*> host;         // [n_host] destinations (NULL entries: a gather rank other than 0)
+    std::vector<int64_t> ticket;       // [n_host] the hand-over last delivered into that array, -1 = none pending
+    uint64_t seed0 = 0;
+    int32_t max_plies = 0x7FFFFFFF;
+    uint32_t flags = BGS_ROLLOUT_FROM_INITIAL;
+    int64_t step = 0;                  // steps enqueued so far (seed of a step = seed0 + its index)
+    int64_t handed = 0;                // hand-overs enqueued so far (host array of a hand-over = its index mod n_host)
+    // shared-array hand-shake (bgs_pipeline_set_ring)
+    const int64_t* rank_words = nullptr;   // progress word of rank r at rank_words[r * word_stride]
+    int64_t word_stride = 8;
+    int world = 1;
+    int64_t* consumed = nullptr;
+    bool consumer = false;
+    int lag = 0;
+    int64_t timeout_ms = 60000;
+    // timing brackets
+    std::vector<hipEvent_t> ev0, ev1;
+    size_t brackets = 0;
+};
+
+extern "C" {
+
+int bgs_pipeline_create(bgs_batch* const* batches, int depth, bgs_reward_sink* sink, bgs_gather* gather,
+                        int8_t* const* host_rewards, int n_host, uint64_t seed0, int32_t max_plies, uint32_t flags,
+                        bgs_pipeline** out) {
+    NEED(out != nullptr && batches != nullptr, "NULL argument");
+    *out = nullptr;
+    NEED(depth >= 1 && depth <= 64, "depth must be in 1..64");
+    NEED(!(sink && gather), "a pipeline hands over through a sink OR a gather");
+    NEED(max_plies >= 0, "max_plies must be >= 0");
+    NEED((sink || gather) ? (host_rewards != nullptr && n_host >= 1 && n_host <= 64) : n_host == 0,
+         "a hand-over needs 1..64 host arrays, a pipeline without one takes none");
+    for (int k = 0; k < depth; ++k) {
+        NEED(batches[k] != nullptr, "batch %d is NULL", k);
+        NEED(batches[k]->device == batches[0]->device && batches[k]->n == batches[0]->n, "the batches must be alike");
+        for (int j = 0; j < k; ++j) NEED(batches[j] != batches[k], "batch %d is listed twice", k);
+    }
+    bgs_pipeline* p = new (std::nothrow) bgs_pipeline();
+    NEED(p != nullptr, "out of host memory");
+    p->device = batches[0]->device;
+    p->batches.assign(batches, batches + depth);
+    p->sink = sink;
+    p->gather = gather;
+    for (int h = 0; h < n_host; ++h) p->host.push_back(host_rewards[h]);
+    p->ticket.assign(n_host, -1);
+    p->seed0 = seed0;
+    p->max_plies = max_plies;
+    p->flags = flags;
+    *out = p;
+    return BGS_OK;
+}
+
+int bgs_pipeline_set_ring(bgs_pipeline* p, const int64_t* rank_words, int64_t word_stride, int world, int64_t* consumed,
+                          int is_consumer, int lag, int64_t timeout_ms) {
+    NEED(p != nullptr, "pipeline is NULL");
+    NEED(rank_words == nullptr || (world >= 1 && word_stride >= 1 && consumed != nullptr), "bad ring description");
+    NEED(!is_consumer || (lag >= 1 && lag < (int)p->host.size()),
+         "the consumer trails the launches by 1 .. (host arrays - 1) hand-overs");
+    p->rank_words = rank_words;
+    p->word_stride = word_stride;
+    p->world = world;
+    p->consumed = consumed;
+    p->consumer = is_consumer != 0;
+    p->lag = lag;
+    p->timeout_ms = timeout_ms;
+    return BGS_OK;
+}
+
+static int wait_ticket(bgs_pipeline* p, int64_t t) {
+    return p->sink ? bgs_sink_wait(p->sink, t) : bgs_gather_wait(p->gather, t);
+}
+
+// the consumer's side of the shared-array hand-shake: every rank has delivered hand-over j -> release its slot
+static int consume(bgs_pipeline* p, int64_t j) {
+    int rc = bgs_progress_wait(p->rank_words, p->world, p->word_stride, j + 1, p->timeout_ms, nullptr);
+    if (rc) return rc;
+    return bgs_progress_store(p->consumed, j + 1);
+}
+
+int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_stride) {
+    NEED(p != nullptr && count >= 0, "bad argument");
+    NEED(!handover || p->sink || p->gather, "this pipeline has no hand-over");
+    HIP_TRY(hipSetDevice(p->device));
+    const int depth = (int)p->batches.size();
+    const int n_host = (int)p->host.size();
+    for (int64_t i = 0; i < count; ++i) {
+        bgs_batch* b = p->batches[p->step % depth];
+        const uint64_t seed = p->seed0 + (uint64_t)p->step;
+        size_t bracket = (size_t)-1;
+        if (time_stride > 0 && i % time_stride == 0) {
+            if (p->brackets == p->ev0.size()) {
+                hipEvent_t a = nullptr, z = nullptr;
+                HIP_TRY(hipEventCreate(&a));
+                p->ev0.push_back(a);
+                HIP_TRY(hipEventCreate(&z));
+                p->ev1.push_back(z);
+            }
+            bracket = p->brackets;
+            HIP_TRY(hipEventRecord(p->ev0[bracket], b->stream));
+        }
+        int rc;
+        if (handover) {
+            const int64_t j = p->handed;
+            const int h = (int)(j % n_host);
+            if (p->ticket[h] >= 0) {   // the array is about to be overwritten: its previous delivery must be over
+                if ((rc = wait_ticket(p, p->ticket[h]))) return rc;
+                p->ticket[h] = -1;
+            }
+            if (p->rank_words) {
+                if (p->consumer && j - p->lag >= 0 && (rc = consume(p, j - p->lag))) return rc;
+                // ... and the consumer must have released what this hand-over overwrites
+                if (j >= n_host && (rc = bgs_progress_wait(p->consumed, 1, 1, j - n_host + 1, p->timeout_ms, nullptr))) return rc;
+            }
+            int64_t t = -1;
+            rc = p->sink ? bgs_sink_rollout(p->sink, b, seed, p->max_plies, p->flags, p->host[h], &t)
+                         : bgs_gather_rollout(p->gather, b, seed, p->max_plies, p->flags, p->host[h], &t);
+            if (rc) return rc;
+            // the ring's progress words count the sink's deliveries: hand-over j must be the sink's job j
+            NEED(!p->rank_words || t == j, "a pipeline on a shared array needs a sink of its own (ticket %lld for hand-over %lld)",
+                 (long long)t, (long long)j);
+            p->ticket[h] = t;
+            ++p->handed;
+        } else {
+            if ((rc = bgs_rollout(b, seed, p->max_plies, p->flags))) return rc;
+        }
+        if (bracket != (size_t)-1) {
+            // (the rollout kernels that deliver the outcome codes themselves leave nothing but an event record between
+            // the brackets; for the others the bracket includes the pack kernel)
+            HIP_TRY(hipEventRecord(p->ev1[bracket], b->stream));
+            ++p->brackets;
+        }
+        ++p->step;
+    }
+    return BGS_OK;
+}
+
+int bgs_pipeline_drain(bgs_pipeline* p) {
+    NEED(p != nullptr, "pipeline is NULL");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc;
+    for (size_t h = 0; h < p->ticket.size(); ++h)
+        if (p->ticket[h] >= 0) {
+            if ((rc = wait_ticket(p, p->ticket[h]))) return rc;
+            p->ticket[h] = -1;
+        }
+    // the consumer sees every hand-over of every rank before it calls the region done
+    if (p->rank_words && p->consumer && p->handed > 0 && (rc = consume(p, p->handed - 1))) return rc;
+    // steps without hand-over (and everything else the batches have enqueued): their streams run dry
+    for (bgs_batch* b : p->batches) HIP_TRY(hipStreamSynchronize(b->stream));
+    return BGS_OK;
+}
+
+int bgs_pipeline_progress(const bgs_pipeline* p, int64_t* steps, int64_t* handovers) {
+    NEED(p != nullptr, "pipeline is NULL");
+    if (steps) *steps = p->step;
+    if (handovers) *handovers = p->handed;
+    return BGS_OK;
+}
+
+int bgs_pipeline_kernel_ms(bgs_pipeline* p, double* mean_ms, int* pairs) {
+    NEED(p != nullptr && mean_ms != nullptr, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    double total = 0.0;
+    for (size_t k = 0; k < p->brackets; ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev0[k], p->ev1[k]));
+        total += ms;
+    }
+    *mean_ms = p->brackets ? total / (double)p->brackets : 0.0;
+    if (pairs) *pairs = (int)p->brackets;
+    p->brackets = 0;  // the events are reused by the next timed region
+    return BGS_OK;
+}
+
+int bgs_pipeline_destroy(bgs_pipeline* p) {
+    if (!p) return BGS_OK;
+    (void)hipSetDevice(p->device);
+    (void)bgs_pipeline_drain(p);
+    for (auto e : p->ev0) (void)hipEventDestroy(e);
+    for (auto e : p->ev1) (void)hipEventDestroy(e);
+    delete p;
+    return BGS_OK;
+}
+
+}  // extern "C"

@@ -117,17 +117,62 @@ def expand_outcomes_host(packed, n: int, out=None, first: int = 0, count: Option
     return out
 
 
+def _reward_destination(dst, n_games: int) -> int:
+    """Address of a host array the library's worker threads will fill with int8[n_games, 2] LATER: it must be large
+    enough, of 1-byte items and writeable -- the C side cannot check any of that from a bare pointer."""
+    if isinstance(dst, PinnedArray):
+        arr = dst.array
+    elif isinstance(dst, np.ndarray):
+        arr = dst
+    elif hasattr(dst, "data_ptr") and not getattr(dst, "is_cuda", False):
+        if dst.element_size() != 1 or dst.numel() < 2 * n_games or not dst.is_contiguous():
+            raise TypeError(f"host reward destination must be a contiguous 1-byte-item tensor of at least {2 * n_games} elements")
+        return dst.data_ptr()
+    else:
+        raise TypeError("host reward destination must be a PinnedArray, a numpy array or a CPU torch tensor")
+    if arr is None:
+        raise ValueError("host reward destination has been closed")
+    if arr.dtype.itemsize != 1:
+        raise TypeError(f"host reward destination must have 1-byte items (int8), got {arr.dtype}")
+    if not arr.flags.c_contiguous:
+        raise TypeError("host reward destination must be C-contiguous")
+    if not arr.flags.writeable:
+        raise ValueError("host reward destination is read-only")
+    if arr.nbytes < 2 * n_games:
+        raise ValueError(f"host reward destination holds {arr.nbytes} bytes, int8[{n_games}, 2] needs {2 * n_games}")
+    return arr.ctypes.data
+
+
 class RewardSink:
     """Delivers the rewards of successive batch steps into host arrays int8[n, 2] while the GPU goes on playing
-    (bgs_sink_*): outcome codes cross PCIe into pinned slots, worker threads expand them on arrival."""
+    (bgs_sink_*): outcome codes cross PCIe into pinned slots, worker threads expand them on arrival.
+
+    The destination of a submission is written by the library's worker threads after the call has returned: the sink
+    checks its size / item size / writeability up front and keeps a reference to it until the submission has been
+    waited for (or the sink is closed), so dropping the array early cannot turn into a write to freed memory."""
 
     def __init__(self, max_games: int, slots: int = 4, threads: int = 4, device: int = 0):
         self._handle = _abi.c_handle()
+        self._alive = {}  # ticket -> destination (and anything else that must outlive the delivery)
+        self.max_games = int(max_games)
         _abi.check(_abi.lib().bgs_sink_create(int(device), int(max_games), int(slots), int(threads), ctypes.byref(self._handle)))
+
+    def _keep(self, ticket: int, *objects) -> int:
+        if len(self._alive) >= 64:  # (callers that never wait: forget what has been delivered, now and then)
+            done = self.completed
+            for t in [t for t in self._alive if t < done]:
+                del self._alive[t]
+        self._alive[ticket] = objects
+        return ticket
 
     def submit(self, batch: "_Batch", host_reward) -> int:
         ticket = ctypes.c_int64(-1)
-        _abi.check(_abi.lib().bgs_sink_submit(self._handle, batch._handle, ctypes.c_void_p(_host_ptr(host_reward)), ctypes.byref(ticket)))
+        ptr = _reward_destination(host_reward, batch.n)
+        try:
+            _abi.check(_abi.lib().bgs_sink_submit(self._handle, batch._handle, ctypes.c_void_p(ptr), ctypes.byref(ticket)))
+        finally:
+            if ticket.value >= 0:  # the ticket exists even when the enqueue failed
+                self._keep(ticket.value, host_reward, batch)
         return ticket.value
 
     def rollout(self, batch: "_Batch", host_reward, seed: int = DEFAULT_SEED, max_plies: int = 2**31 - 1,
@@ -135,33 +180,63 @@ class RewardSink:
         """`batch.rollout(...)` + `submit(batch, host_reward)` in one library call (bgs_sink_rollout)."""
         flags = _abi.ROLLOUT_FROM_INITIAL if from_initial else 0
         ticket = ctypes.c_int64(-1)
-        _abi.check(
-            _abi.lib().bgs_sink_rollout(
-                self._handle, batch._handle, ctypes.c_uint64(seed), ctypes.c_int32(max_plies), ctypes.c_uint32(flags),
-                ctypes.c_void_p(_host_ptr(host_reward)), ctypes.byref(ticket),
+        ptr = _reward_destination(host_reward, batch.n)
+        try:
+            _abi.check(
+                _abi.lib().bgs_sink_rollout(
+                    self._handle, batch._handle, ctypes.c_uint64(seed), ctypes.c_int32(max_plies), ctypes.c_uint32(flags),
+                    ctypes.c_void_p(ptr), ctypes.byref(ticket),
+                )
             )
-        )
+        finally:
+            if ticket.value >= 0:
+                self._keep(ticket.value, host_reward, batch)
         return ticket.value
 
     def submit_packed(self, device_packed, n_games: int, host_reward, stream: int = 0) -> int:
         """`device_packed`: CUDA uint8 tensor (or device address) of the codes of n_games games, e.g. the RCCL-gathered
         codes of all ranks; copied on HIP stream `stream`."""
         ptr = device_packed.data_ptr() if hasattr(device_packed, "data_ptr") else int(device_packed)
+        if hasattr(device_packed, "numel") and device_packed.numel() * device_packed.element_size() < (int(n_games) + 3) // 4:
+            raise ValueError("device_packed is smaller than the codes of n_games games")
         ticket = ctypes.c_int64(-1)
-        _abi.check(
-            _abi.lib().bgs_sink_submit_packed(
-                self._handle, ctypes.c_void_p(stream), ctypes.c_void_p(ptr), int(n_games), ctypes.c_void_p(_host_ptr(host_reward)), ctypes.byref(ticket)
+        dst = _reward_destination(host_reward, int(n_games))
+        try:
+            _abi.check(
+                _abi.lib().bgs_sink_submit_packed(
+                    self._handle, ctypes.c_void_p(stream), ctypes.c_void_p(ptr), int(n_games), ctypes.c_void_p(dst), ctypes.byref(ticket)
+                )
             )
-        )
+        finally:
+            if ticket.value >= 0:
+                self._keep(ticket.value, host_reward, device_packed)
         return ticket.value
 
     def wait(self, ticket: int) -> None:
         _abi.check(_abi.lib().bgs_sink_wait(self._handle, int(ticket)))
+        self._alive.pop(int(ticket), None)
+
+    @property
+    def completed(self) -> int:
+        """Number of submissions whose rewards are in their host arrays (they complete in ticket order)."""
+        if not self._handle:
+            return 0
+        v = ctypes.c_int64(0)
+        _abi.check(_abi.lib().bgs_sink_completed(self._handle, ctypes.byref(v)))
+        return v.value
+
+    def set_progress(self, word_address: Optional[int], keepalive=None) -> None:
+        """Announce `completed` in the int64 at `word_address` (host memory, e.g. a SharedRewardRing progress word) after
+        every delivery; sleepers use `bgs_progress_wait`.  None stops it."""
+        _abi.check(_abi.lib().bgs_sink_set_progress(self._handle, ctypes.c_void_p(word_address) if word_address else None))
+        self._progress_keepalive = keepalive
 
     def close(self) -> None:
         if self._handle:
-            _abi.lib().bgs_sink_destroy(self._handle)
+            _abi.lib().bgs_sink_destroy(self._handle)  # waits for every claimed submission before the workers stop
             self._handle = _abi.c_handle()
+        self._alive.clear()
+        self._progress_keepalive = None
 
     def __del__(self):
         try:

@@ -109,6 +109,39 @@ SIGNATURES = {
         [c_handle, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
     ),
     "bgs_sink_wait": (ctypes.c_int, [c_handle, ctypes.c_int64]),
+    "bgs_sink_completed": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_int64)]),
+    "bgs_sink_set_progress": (ctypes.c_int, [c_handle, ctypes.c_void_p]),
+    "bgs_progress_store": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    "bgs_progress_wait": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)],
+    ),
+    "bgs_bind_host_thread": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "bgs_gather_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "bgs_gather_create": (
+        ctypes.c_int,
+        [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_handle)],
+    ),
+    "bgs_gather_rollout": (
+        ctypes.c_int,
+        [c_handle, c_handle, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
+    ),
+    "bgs_gather_wait": (ctypes.c_int, [c_handle, ctypes.c_int64]),
+    "bgs_gather_destroy": (ctypes.c_int, [c_handle]),
+    "bgs_pipeline_create": (
+        ctypes.c_int,
+        [ctypes.POINTER(c_handle), ctypes.c_int, c_handle, c_handle, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_uint64,
+         ctypes.c_int32, ctypes.c_uint32, ctypes.POINTER(c_handle)],
+    ),
+    "bgs_pipeline_enqueue": (ctypes.c_int, [c_handle, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "bgs_pipeline_drain": (ctypes.c_int, [c_handle]),
+    "bgs_pipeline_progress": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "bgs_pipeline_kernel_ms": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "bgs_pipeline_set_ring": (
+        ctypes.c_int,
+        [c_handle, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64],
+    ),
+    "bgs_pipeline_destroy": (ctypes.c_int, [c_handle]),
     "bgs_multi_connect_rollout": (
         ctypes.c_int,
         [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,

@@ -15,11 +15,100 @@ Every step plays all `n` boards from the initial state to the end with uniformly
 
 from __future__ import annotations
 
-from typing import Iterable, Iterator, Optional, Tuple
+import ctypes
+import os
+from typing import Iterable, Iterator, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .batch import RewardSink
+from .batch import RewardSink, _reward_destination
+from .game import _abi
+
+
+class RolloutExecutor:
+    """The rollout loop as ONE library call per burst of steps (`bgs_pipeline_*`, csrc/bgs_pipeline.hip): step s plays
+    every board of `batches[s % depth]` from the initial state to the end with seed `seed0 + s` on that batch's stream,
+    and -- with a hand-over -- the step's rewards go to `host_arrays[j % len(host_arrays)]`, j counting hand-overs,
+    through `sink` (a RewardSink) or `gather` (a sharding.RewardGather; ranks other than 0 pass None entries).
+
+    `enqueue(count)` returns when `count` more steps are enqueued (it blocks only while the host array a step is about to
+    reuse is still being delivered); `drain()` when every enqueued step's rewards are in their host arrays.  What a Python
+    loop of `sink.rollout(...)` calls costs the launching thread per step (~27 us) is most of a 2^20-board Connect4 step
+    (~34 us): this executor spends a kernel launch and an event record."""
+
+    def __init__(self, batches: Sequence, sink=None, gather=None, host_arrays: Sequence = (), seed0: int = 0,
+                 max_plies: int = 2**31 - 1, from_initial: bool = True):
+        if sink is not None and gather is not None:
+            raise ValueError("hand over through a sink OR a gather")
+        self.batches, self.sink, self.gather = list(batches), sink, gather
+        self.host = list(host_arrays)  # (kept alive: worker threads write them after enqueue() has returned)
+        n_games = self.batches[0].n * (gather.world if gather is not None else 1)
+        ptrs = (ctypes.c_void_p * max(len(self.host), 1))()
+        for k, a in enumerate(self.host):
+            ptrs[k] = None if a is None else _reward_destination(a, n_games)
+        handles = (_abi.c_handle * len(self.batches))(*[b._handle for b in self.batches])
+        self._handle = _abi.c_handle()
+        _abi.check(_abi.lib().bgs_pipeline_create(
+            handles, len(self.batches), sink._handle if sink is not None else None, gather._handle if gather is not None else None,
+            ptrs if self.host else None, len(self.host), ctypes.c_uint64(seed0), ctypes.c_int32(max_plies),
+            ctypes.c_uint32(_abi.ROLLOUT_FROM_INITIAL if from_initial else 0), ctypes.byref(self._handle)))
+        self.seed0 = int(seed0)
+        self._ring = None
+
+    def set_ring(self, ring, consumer: bool, lag: int, timeout: float = 60.0) -> None:
+        """N ranks, one shared host array (`sharding.SharedRewardRing`; `ring.attach(sink)` first): hand-overs wait for
+        the consumer's release of the array they overwrite, and on the consumer rank the loop itself consumes hand-over
+        j - lag (waits for every rank's delivery, releases it) before it enqueues hand-over j."""
+        _abi.check(_abi.lib().bgs_pipeline_set_ring(self._handle, ctypes.c_void_p(ring._words), 8, ring.world,
+                                                    ctypes.c_void_p(ring._words + 64 * ring.world), 1 if consumer else 0,
+                                                    int(lag), int(timeout * 1000)))
+        self._ring = ring
+
+    def enqueue(self, count: int, handover: bool = True, time_stride: int = 0) -> None:
+        _abi.check(_abi.lib().bgs_pipeline_enqueue(self._handle, int(count), 1 if handover else 0, int(time_stride)))
+
+    def drain(self) -> None:
+        _abi.check(_abi.lib().bgs_pipeline_drain(self._handle))
+
+    def kernel_ms(self) -> Tuple[Optional[float], int]:
+        """(mean duration in ms of the launches bracketed since the last call, how many) -- after `drain()`."""
+        ms, pairs = ctypes.c_double(0.0), ctypes.c_int(0)
+        _abi.check(_abi.lib().bgs_pipeline_kernel_ms(self._handle, ctypes.byref(ms), ctypes.byref(pairs)))
+        return (ms.value if pairs.value else None), pairs.value
+
+    @property
+    def steps(self) -> int:
+        """Steps enqueued so far; the next step's seed is seed0 + steps."""
+        v = ctypes.c_int64(0)
+        _abi.check(_abi.lib().bgs_pipeline_progress(self._handle, ctypes.byref(v), None))
+        return v.value
+
+    @property
+    def handovers(self) -> int:
+        v = ctypes.c_int64(0)
+        _abi.check(_abi.lib().bgs_pipeline_progress(self._handle, None, ctypes.byref(v)))
+        return v.value
+
+    def last_host_array(self):
+        """The host array the most recent hand-over went to (valid after `drain()`)."""
+        return self.host[(self.handovers - 1) % len(self.host)]
+
+    def close(self) -> None:
+        if self._handle:
+            _abi.lib().bgs_pipeline_destroy(self._handle)
+            self._handle = _abi.c_handle()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class RolloutPipeline:

@@ -8,7 +8,9 @@ The single exchange is the hand-over of the rewards to the ONE host array, and t
 * `SharedRewardRing` (ranks on one node; bench.py's default for N > 1): the host array lives in shared memory mapped by
   every rank, and each rank's own reward sink delivers its games into its rows -- every GPU uses its OWN PCIe link
   (0.25 B per game of outcome codes) and its own host threads for the expansion, nothing funnels through rank 0's GPU;
-* `gather_outcomes_to` (any topology): ranks contribute their 2-bit outcome codes to rank 0's GPU over RCCL (xGMI inside
+* `RewardGather` (any topology; `bench.py --gather rccl`): the same gather inside libbgs.so (`bgs_gather_*`) -- persistent
+  communicator, its own stream and thread, one library call per step on the launching thread;
+* `gather_outcomes_to` (torch collectives; the gloo rehearsals use it): ranks contribute their 2-bit outcome codes to rank 0's GPU over RCCL (xGMI inside
   a node), whose sink copies them to the host and expands all of them -- at 8 GPUs that is 2 MiB per step over one PCIe
   link and 16 MiB of host writes per step by one process (`gather_rewards` ships int8 pairs to every rank instead).
 torch.distributed's "nccl" backend is RCCL on ROCm, "gloo" runs the same code on CPUs in tests.
@@ -16,11 +18,13 @@ torch.distributed's "nccl" backend is RCCL on ROCm, "gloo" runs the same code on
 
 from __future__ import annotations
 
+import ctypes
 import mmap
 import os
-import time
 import uuid
 from typing import Tuple
+
+from .game import _abi
 
 
 def shard_range(total_games: int, rank: int, world: int) -> Tuple[int, int]:
@@ -35,11 +39,15 @@ def shard_range(total_games: int, rank: int, world: int) -> Tuple[int, int]:
 
 class SharedRewardRing:
     """`slots` host arrays int8[world * per_rank, 2] in ONE shared-memory segment mapped by every rank of a node, plus a
-    progress word per rank.
+    progress word per rank and one for the consumer.
 
     Rank r delivers step s into `mine(s % slots)` (rows [r * per_rank, (r + 1) * per_rank) of `array(s % slots)`, e.g.
-    as the destination of `RewardSink.rollout`) and calls `publish(s)`; the consumer -- any rank, normally rank 0 --
-    calls `wait_all(s)` and then reads `array(s % slots)`: every rank's rewards of step s, in global game order.
+    as the destination of `RewardSink.rollout`) and announces it -- `publish(s)`, or `attach(sink)` once and the sink's
+    worker threads do it themselves the moment a step is delivered.  The consumer -- any ONE rank, normally rank 0 --
+    calls `wait_all(s)`, reads `array(s % slots)` (every rank's rewards of step s, in global game order) and hands the
+    slot back with `release(s)`; a producer calls `acquire(s)` before it lets step s overwrite the slot of step
+    s - slots (immediate unless the consumer is more than `slots` steps behind).  All waits sleep on a futex
+    (`bgs_progress_wait`), nothing polls; progress only ever moves forward.
     The segment is a file in /dev/shm that rank 0 creates and unlinks as soon as everybody has mapped it, so nothing
     is left behind however the processes end.  `dist` (torch.distributed, initialised) only carries the name and one
     barrier at construction; the data path has no collective."""
@@ -53,7 +61,7 @@ class SharedRewardRing:
             raise ValueError("per_rank and slots must be positive")
         self._slot_bytes = self.world * self.per_rank * 2
         data = -(-self.slots * self._slot_bytes // 4096) * 4096
-        total = data + 64 * self.world  # one cache line of progress per rank
+        total = data + 64 * (self.world + 1)  # one cache line of progress per rank, one for the consumer
         # Rank 0 creates the file -- if the directory has room for it: a tmpfs accepts the ftruncate and kills the process
         # that touches the first page it cannot back -- and everybody learns the name, or that there is none.  Whether
         # all ranks mapped it is agreed on before anybody goes on: the constructor raises on every rank or on none, so
@@ -91,12 +99,13 @@ class SharedRewardRing:
             raise RuntimeError("shared reward ring unavailable: " + "; ".join(e for e in errors if e))
         buf = np.frombuffer(self._map, dtype=np.int8, count=self.slots * self._slot_bytes)
         self._arrays = buf.reshape(self.slots, self.world * self.per_rank, 2)
-        self._progress = np.frombuffer(self._map, dtype=np.int64, count=8 * self.world, offset=data).reshape(self.world, 8)
+        # (a fresh tmpfs file reads as zeros: every counter starts at 0 without anybody writing it)
+        self._progress = np.frombuffer(self._map, dtype=np.int64, count=8 * (self.world + 1), offset=data).reshape(self.world + 1, 8)
+        self._words = self._progress.ctypes.data  # rank r's word at + 64 r, the consumer's at + 64 world
+        self._sink = None
         # first touch by the rank that will write the rows: the pages land on that rank's NUMA node
         for k in range(self.slots):
             self.mine(k)[...] = 0x55
-        if self.rank == 0:
-            self._progress[...] = 0
         dist.barrier()
 
     def array(self, slot: int):
@@ -107,26 +116,108 @@ class SharedRewardRing:
         """int8[per_rank, 2]: this rank's rows of `array(slot)` (C-contiguous: a valid sink destination)."""
         return self._arrays[slot, self.rank * self.per_rank : (self.rank + 1) * self.per_rank]
 
+    # ---- producers ---------------------------------------------------------------------------------
     def publish(self, step: int) -> None:
-        """This rank's rewards of every step <= `step` are in their host arrays."""
-        self._progress[self.rank, 0] = step + 1
+        """This rank's rewards of every step <= `step` are in their host arrays (never moves backwards)."""
+        _abi.check(_abi.lib().bgs_progress_store(ctypes.c_void_p(self._words + 64 * self.rank), int(step) + 1))
 
+    def attach(self, sink) -> None:
+        """Let `sink` (a RewardSink whose submissions are exactly this rank's steps 0, 1, 2, ... in order) publish by
+        itself: its worker threads raise this rank's progress word the moment a step is in its host array."""
+        sink.set_progress(self._words + 64 * self.rank, keepalive=self)
+        self._sink = sink
+
+    def acquire(self, step: int, timeout: float = 60.0) -> None:
+        """Before step `step` may overwrite its slot: the consumer has released step `step - slots`."""
+        if step >= self.slots:
+            self._wait(self._words + 64 * self.world, 1, step - self.slots + 1, timeout, f"the consumer has not released step {step - self.slots}")
+
+    # ---- the consumer ------------------------------------------------------------------------------
     def done(self, step: int) -> bool:
-        return bool((self._progress[:, 0] > step).all())
+        return bool((self._progress[: self.world, 0] > step).all())
 
     def wait_all(self, step: int, timeout: float = 60.0) -> None:
-        """Block until every rank has published `step`."""
-        deadline = time.monotonic() + timeout
-        while not self.done(step):
-            if time.monotonic() > deadline:
-                raise TimeoutError(f"ranks {[int(r) for r in (self._progress[:, 0] <= step).nonzero()[0]]} have not delivered step {step}")
-            time.sleep(0)
+        """Sleep until every rank has delivered `step`."""
+        self._wait(self._words, self.world, step + 1, timeout, f"step {step} not delivered")
+
+    def release(self, step: int) -> None:
+        """The consumer is done with every step <= `step`: their slots may be overwritten."""
+        _abi.check(_abi.lib().bgs_progress_store(ctypes.c_void_p(self._words + 64 * self.world), int(step) + 1))
+
+    def _wait(self, address: int, count: int, target: int, timeout: float, what: str) -> None:
+        laggard = ctypes.c_int64(-1)
+        rc = _abi.lib().bgs_progress_wait(ctypes.c_void_p(address), count, 8, int(target), int(timeout * 1000), ctypes.byref(laggard))
+        if rc != 0:
+            behind = [int(r) for r in (self._progress[: self.world, 0] < target).nonzero()[0]] if count > 1 else []
+            raise TimeoutError(f"{what} after {timeout} s" + (f" by ranks {behind}" if behind else ""))
 
     def close(self) -> None:
+        if self._sink is not None:
+            try:
+                self._sink.set_progress(None)  # the word is about to be unmapped
+            except Exception:
+                pass
+            self._sink = None
         self._arrays = self._progress = None
         try:
             self._map.close()
         except BufferError:  # a caller still holds a view: the mapping goes with the process
+            pass
+
+
+class RewardGather:
+    """The north-star's collective as a library object: every rank's outcome codes to rank 0 over RCCL (xGMI inside a
+    node), rank 0's sink expands them into ONE host array int8[world * per_rank, 2] in global game order
+    (`bgs_gather_*`: persistent communicator, communication stream and thread inside libbgs.so; the launching thread
+    makes one call per step and never enters RCCL).  `dist` (torch.distributed, initialised, any backend) only carries
+    the communicator's 128-byte id from rank 0 to the others."""
+
+    def __init__(self, dist, per_rank: int, slots: int = 6, host_threads: int = 6, device: int = 0):
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.per_rank = int(per_rank)
+        ident = [None]
+        if self.rank == 0:
+            raw = (ctypes.c_uint8 * 128)()
+            _abi.check(_abi.lib().bgs_gather_unique_id(raw))
+            ident[0] = bytes(raw)
+        dist.broadcast_object_list(ident, src=0)
+        raw = (ctypes.c_uint8 * 128).from_buffer_copy(ident[0])
+        self._handle = _abi.c_handle()
+        self._alive = {}
+        _abi.check(_abi.lib().bgs_gather_create(int(device), self.rank, self.world, raw, self.per_rank, int(slots),
+                                                int(host_threads), ctypes.byref(self._handle)))
+
+    def rollout(self, batch, host_reward, seed: int, max_plies: int = 2**31 - 1, from_initial: bool = True) -> int:
+        """Enqueue one step: `batch.rollout(...)`, this rank's codes to rank 0 and -- on rank 0 -- everybody's rewards
+        into `host_reward` int8[world * per_rank, 2] (None on the other ranks).  Returns the step's ticket."""
+        from .batch import _reward_destination
+
+        ptr = None
+        if self.rank == 0:
+            ptr = ctypes.c_void_p(_reward_destination(host_reward, self.world * self.per_rank))
+        ticket = ctypes.c_int64(-1)
+        _abi.check(_abi.lib().bgs_gather_rollout(self._handle, batch._handle, ctypes.c_uint64(seed), ctypes.c_int32(max_plies),
+                                                 ctypes.c_uint32(_abi.ROLLOUT_FROM_INITIAL if from_initial else 0), ptr,
+                                                 ctypes.byref(ticket)))
+        self._alive[ticket.value] = (host_reward, batch)
+        return ticket.value
+
+    def wait(self, ticket: int) -> None:
+        """Rank 0: the step's rewards of ALL ranks are in its host array; other ranks: this rank's codes have left."""
+        _abi.check(_abi.lib().bgs_gather_wait(self._handle, int(ticket)))
+        for t in [t for t in self._alive if t <= ticket]:
+            del self._alive[t]
+
+    def close(self) -> None:
+        if self._handle:
+            _abi.lib().bgs_gather_destroy(self._handle)
+            self._handle = _abi.c_handle()
+        self._alive.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
             pass
 
 

@@ -200,6 +200,77 @@ int bgs_sink_rollout(bgs_reward_sink* s, bgs_batch* b, uint64_t seed, int32_t ma
 int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* device_packed, int64_t n_games,
                            int8_t* host_reward, int64_t* ticket);
 int bgs_sink_wait(bgs_reward_sink* s, int64_t ticket); /* until that submission's rewards are in its host array */
+/* Submissions to one sink may come from several threads (a ticket and its slot are reserved under the sink's lock);
+ * they are delivered in ticket order.  *completed = number of submissions whose rewards are in their host arrays. */
+int bgs_sink_completed(bgs_reward_sink* s, int64_t* completed);
+
+/* Progress words: monotonic int64 counters in host memory -- typically in a shared-memory segment several processes
+ * map -- that consumers sleep on (futex on the low half) instead of polling.  bgs_sink_set_progress makes a sink
+ * announce its completed count in *word after every delivery (word = NULL stops that; the word must outlive the sink or
+ * be unset first); bgs_progress_store raises *word to `value` (never lowers it) and wakes the sleepers;
+ * bgs_progress_wait blocks until each of the `count` words words[i * stride_words] is >= target, or fails with
+ * BGS_ERR_RUNTIME after timeout_ms (< 0: no timeout), *laggard = index of the word that was behind. */
+int bgs_sink_set_progress(bgs_reward_sink* s, int64_t* word);
+int bgs_progress_store(int64_t* word, int64_t value);
+int bgs_progress_wait(const int64_t* words, int64_t count, int64_t stride_words, int64_t target, int64_t timeout_ms,
+                      int64_t* laggard);
+/* Confine the calling thread (and the threads it creates later) to the CPUs of the NUMA node `device` hangs off,
+ * intersected with what the process may use: its first-touch pages, the sink's workers and the launching thread then
+ * sit next to the GPU's PCIe root.  *cpus = size of that set, 0 when the topology is unknown (nothing changed). */
+int bgs_bind_host_thread(int device, int* cpus);
+
+/* ---- the reward gather over RCCL / xGMI, one process per GPU -------------------------------------------------------
+ * The path shards without any exchange (rank r plays global game ids [r * n, (r + 1) * n), bgs_set_first_game); the one
+ * collective is the hand-over: every rank's 2-bit outcome codes to rank 0's GPU, from there to rank 0's host array
+ * int8[world * n][2] (State::get_reward of all games, connect.cpp:41, in global game order).  A bgs_gather owns a
+ * persistent communicator (ncclCommInitRank), a communication stream and a communication thread; rank 0's also owns the
+ * reward sink.  Per step the launching thread makes ONE call, bgs_gather_rollout, which enqueues the rollout on the
+ * batch's stream and returns; send, receives, copy to the host and expansion follow behind it on other threads and
+ * streams while the next rollouts play.  The launcher (torch.distributed, MPI, a file) only has to carry the 128-byte
+ * id from rank 0 to the others.  RCCL is loaded on first use (dlopen "librccl.so.1"). */
+#define BGS_UNIQUE_ID_BYTES 128
+typedef struct bgs_gather bgs_gather;
+int bgs_gather_unique_id(uint8_t* id /* [BGS_UNIQUE_ID_BYTES] */);   /* rank 0; ncclGetUniqueId */
+/* collective over the world (ncclCommInitRank).  n_per_rank: games per rank, a multiple of 4; slots: steps that may be
+ * in flight (code buffers per rank; on rank 0 also sink slots); host_threads: rank 0's sink workers. */
+int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_t n_per_rank, int slots, int host_threads,
+                      bgs_gather** out);
+/* bgs_rollout on `b`, then this rank's codes to rank 0 (and there: everybody's rewards into host_reward, which other
+ * ranks pass as NULL).  Every rank makes the same sequence of calls; one thread at a time per gather. */
+int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, int8_t* host_reward,
+                       int64_t* ticket);
+/* rank 0: that step's rewards of all ranks are in its host array; other ranks: this rank's codes have been sent */
+int bgs_gather_wait(bgs_gather* g, int64_t ticket);
+int bgs_gather_destroy(bgs_gather* g);
+
+/* ---- the rollout loop as ONE call (README.md:45-72 `while not state.has_ended`, for batch after batch) ------------------
+ * Step s (s = 0, 1, ... over the pipeline's life) plays every board of batches[s % depth] from the state `flags` says
+ * to the end with seed seed0 + s on that batch's stream; with a hand-over the step's rewards go to
+ * host_rewards[j % n_host], j = number of hand-overs so far, through `sink` (one GPU; or N ranks, each delivering its
+ * rows of a shared array) or `gather` (RCCL to rank 0; other ranks pass NULL entries) -- exactly one of the two, or
+ * neither (then n_host = 0 and every step stays on the device).  bgs_pipeline_enqueue returns when `count` more steps
+ * are enqueued; it blocks only while the host array a step is about to reuse is still being delivered (so n_host
+ * bounds how far the launching thread runs ahead).  time_stride > 0 brackets every time_stride-th launch of the call
+ * with timing events on the batch's stream; bgs_pipeline_kernel_ms (after bgs_pipeline_drain) returns their mean and
+ * resets them.  bgs_pipeline_drain: every enqueued step's rewards are in their host arrays and the streams are idle.
+ * The batches, sink, gather and host arrays belong to the caller and must outlive the pipeline. */
+typedef struct bgs_pipeline bgs_pipeline;
+int bgs_pipeline_create(bgs_batch* const* batches, int depth, bgs_reward_sink* sink, bgs_gather* gather,
+                        int8_t* const* host_rewards, int n_host, uint64_t seed0, int32_t max_plies, uint32_t flags,
+                        bgs_pipeline** out);
+int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_stride);
+int bgs_pipeline_drain(bgs_pipeline* p);
+int bgs_pipeline_progress(const bgs_pipeline* p, int64_t* steps, int64_t* handovers);
+int bgs_pipeline_kernel_ms(bgs_pipeline* p, double* mean_ms, int* pairs);
+/* N ranks delivering into one shared host array (progress words, see above): rank r's sink announces its deliveries in
+ * rank_words[r * word_stride] (bgs_sink_set_progress; the sink must serve this pipeline only), the consumer announces
+ * the hand-overs it has released in *consumed.  Every rank: hand-over j waits for the release of hand-over j - n_host
+ * before it overwrites that array.  The consumer rank (is_consumer; one per ring) also plays the consumer inside its
+ * launch loop: before hand-over j it waits until ALL ranks have delivered hand-over j - lag (1 <= lag < n_host) and
+ * releases it; bgs_pipeline_drain consumes the rest. */
+int bgs_pipeline_set_ring(bgs_pipeline* p, const int64_t* rank_words, int64_t word_stride, int world, int64_t* consumed,
+                          int is_consumer, int lag, int64_t timeout_ms);
+int bgs_pipeline_destroy(bgs_pipeline* p);
 
 /* ---- several GPUs of one node from one host process (no torch.distributed needed) ------------------------------
  * Device devices[r] plays Connect games with global ids [r * n_per_device, (r + 1) * n_per_device) from

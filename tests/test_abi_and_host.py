@@ -124,3 +124,46 @@ def test_product_package_never_touches_the_oracle():
                 with open(os.path.join(base, name)) as fh:
                     text = fh.read()
                 assert "liboracle" not in text and "import oracle" not in text and "from oracle" not in text, name
+
+
+def test_progress_words_wake_sleepers_and_never_move_backwards():
+    """bgs_progress_store / bgs_progress_wait (the futex-backed counters the shared reward array and the sinks use): a
+    sleeper wakes when every word has reached the target, a lower store does not lower a word, a wait times out with the
+    laggard's index."""
+    import ctypes
+    import threading
+    import time
+
+    import numpy as np
+
+    from simulator.game import _abi
+
+    lib = _abi.lib()
+    words = np.zeros((3, 8), dtype=np.int64)  # one word per cache line, as in SharedRewardRing
+    base = words.ctypes.data
+    woke = []
+
+    def sleeper():
+        rc = lib.bgs_progress_wait(ctypes.c_void_p(base), 3, 8, 5, 10000, None)
+        woke.append((rc, time.monotonic()))
+
+    t = threading.Thread(target=sleeper)
+    t.start()
+    time.sleep(0.1)
+    assert not woke
+    for r in (2, 0):
+        _abi.check(lib.bgs_progress_store(ctypes.c_void_p(base + 64 * r), 7))
+    time.sleep(0.1)
+    assert not woke  # word 1 is still behind
+    t_store = time.monotonic()
+    _abi.check(lib.bgs_progress_store(ctypes.c_void_p(base + 64), 5))
+    t.join(timeout=5)
+    assert woke and woke[0][0] == 0 and woke[0][1] - t_store < 0.5
+    _abi.check(lib.bgs_progress_store(ctypes.c_void_p(base), 3))
+    assert words[0, 0] == 7  # never lowered
+    laggard = ctypes.c_int64(-1)
+    t0 = time.monotonic()
+    rc = lib.bgs_progress_wait(ctypes.c_void_p(base), 3, 8, 6, 150, ctypes.byref(laggard))
+    assert rc == _abi.BGS_ERR_RUNTIME and laggard.value == 1 and 0.1 < time.monotonic() - t0 < 2.0
+    assert "timed out" in _abi.last_error()
+    assert lib.bgs_progress_wait(ctypes.c_void_p(base + 4), 1, 1, 0, 0, None) == _abi.BGS_ERR_ARG  # misaligned

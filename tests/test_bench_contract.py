@@ -46,6 +46,21 @@ def test_counters_file_names_its_build():
     assert 2.0 < c["mix_cycles_per_instruction"] < 6.0
 
 
+def test_bench_starts_ranks_itself_and_relays_their_failure():
+    """`python bench.py --gpus 2` with no launcher: two child ranks are started (before the parent touches any GPU API);
+    without a GPU each of them refuses, and the parent relays that as its own exit code and prints no line."""
+    sys.path[:0] = [os.path.join(ROOT, "board-game-simulator-python_amd")]
+    from simulator.game import _abi
+
+    if _abi.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                          capture_output=True, text=True, timeout=300, env=env)
+    assert proc.returncode == 2 and not proc.stdout.strip()
+    assert proc.stderr.count("no GPU visible") == 2 and "rank(s) failed" in proc.stderr
+
+
 def test_bench_refuses_to_run_without_a_gpu():
     sys.path[:0] = [os.path.join(ROOT, "board-game-simulator-python_amd")]
     from simulator.game import _abi

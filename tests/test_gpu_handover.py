@@ -481,14 +481,14 @@ def _free_port():
 def test_bench_multi_rank_rehearsal(gather, ranks):
     """bench.py's own N > 1 loops as child processes sharing this box's GPU (gloo carries the control messages; RCCL
     cannot run several ranks on one GPU): `shm` -- the default: one host array in shared memory, every rank's sink
-    delivers its rows; `rccl` -- per-step gather of the codes to rank 0, whose sink expands them all.  Rank 0's host
-    array must verify against a replay of the LAST rank's games."""
+    delivers its rows, rank 0 consumes (futex hand-shake inside the native loop); `rccl` -- the gather's rehearsal on
+    host copies.  Rank 0's host array must verify against a replay of the LAST rank's games."""
     port = _free_port()
     procs = []
     for rank in range(ranks):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(ranks), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "9", "--warmup", "2", "--batch",
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "25", "--warmup", "2", "--batch",
                str(1 << 16), "--no-cpu-baseline", "--gather", gather, "--host-threads", "2"]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
@@ -498,37 +498,66 @@ def test_bench_multi_rank_rehearsal(gather, ranks):
     assert d["n_gpus"] == ranks and d["config"]["gathered_rewards_verified"] is True
     assert d["config"]["rewards_to_host"] is True and d["config"]["global_batch"] == ranks << 16
     assert ("shared memory" in d["config"]["sharding"]) == (gather == "shm")
+    assert d["config"]["gather"] == ("shm" if gather == "shm" else "gloo (rehearsal)")
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # only rank 0 prints the line
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 3` with no launcher around it: the script starts its three ranks as child processes (before
+    it touches the GPU itself), relays rank 0's line and exits 0.  (gloo: the ranks share this box's one GPU.)"""
+    env = dict(os.environ, BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "20", "--warmup", "2",
+                           "--batch", str(1 << 16), "--host-threads", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["config"]["gathered_rewards_verified"] is True and d["config"]["gather"] == "shm"
+    assert d["config"]["global_batch"] == 3 << 16 and d["value"] > 0 and d["steps"] == 20
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
 
 
 @pytest.mark.parametrize("gather", ["rccl", "shm"])
 def test_bench_sharded_path_with_one_rank_over_rccl(gather):
     """The N > 1 loops over the REAL collective backend (nccl = RCCL) with a world of one rank -- what a one-GPU box can
-    run of them: process group on the GPU, then either the per-step dist.gather of the outcome codes + rank-0 sink, or
-    the shared host array (RCCL then only carries the barriers and the step count); verified host array."""
+    run of them: `rccl` = the in-library gather (bgs_gather_*: ncclCommInitRank, communication thread, send / receive
+    group per step, rank 0's sink), `shm` = the shared host array with the consumer hand-shake (RCCL then only carries
+    the barriers and the step count); verified host array."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                BGS_FORCE_DIST="1")
     env.pop("BGS_DIST_BACKEND", None)
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "3",
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "3",
                            "--batch", str(1 << 18), "--no-cpu-baseline", "--gather", gather], env=env, capture_output=True,
                           text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-3000:]
     d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["config"]["gathered_rewards_verified"] is True
-    assert ("RCCL gather" in d["config"]["sharding"]) == (gather == "rccl")
+    assert d["config"]["gathered_rewards_verified"] is True and d["config"]["gather"] == gather
+    assert ("RCCL gather (in-library" in d["config"]["sharding"]) == (gather == "rccl")
     assert d["config"]["rewards_to_host"] is True and d["value"] > 0
+    assert d["config"]["loop"].startswith("native")
 
 
 def test_bench_single_gpu_line():
-    """The default hand-over on one GPU at a small batch: contract fields, host rewards verified against the oracle."""
+    """The default hand-over on one GPU at a small batch: contract fields, host rewards verified against the oracle,
+    the other BASELINE configs measured and parity-checked by their child processes."""
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--batch",
                            str(1 << 16)], capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-2000:]
     d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["rewards_to_host"] is True and d["cpu_baseline"]["parity_with_host_rewards"] is True
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] <= 1
-    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    assert d["cpu_baseline"]["single_game_latency_us"] > 0 and d["cpu_baseline"]["gpu_single_game_latency_us"] > 0
+    roof = d["roofline"]
+    assert roof["bound"] == "valu_issue" and roof["unit"] == "Ginstr/s" and roof["peak"] == pytest.approx(1228.8)
+    assert roof["frac"] is None and roof["achieved"] is None  # the committed counters are for 2^20 boards per launch
+    assert roof["kernel_ms_per_launch"] > 0 and roof["hbm"]["frac"] > 0 and roof["pcie"]["frac"] <= 1
     assert d["device_resident"]["value"] > 0 and d["steps"] == 12 and d["warmup"] == 3
+    assert len(d["values_of_3"]) == 3 and min(d["values_of_3"]) <= d["value_median_of_3"] <= max(d["values_of_3"])
+    for name in ("connect_12x13x5", "bounce_default"):
+        o = d["other_configs"][name]
+        assert "error" not in o, o
+        assert o["parity_with_oracle"] is True and o["value"] > 0 and o["solo"]["value"] > 0 and o["rewards_to_host"] is True
 
 
 def test_rollout_pipeline_matches_the_oracle_step_by_step():

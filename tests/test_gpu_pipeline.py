@@ -1,0 +1,237 @@
+"""GPU tests of the native rollout loop (bgs_pipeline_*, simulator.pipeline.RolloutExecutor), the in-library RCCL reward
+gather (bgs_gather_*, simulator.sharding.RewardGather) with a world of one rank -- what a one-GPU box can run of it --
+and the reward sink's behaviour under several submitting threads and bad destinations.  Everything is compared with the
+CPU oracle, bit-exact, through the C ABI."""
+
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "board-game-simulator-python_amd")
+SEED = 0x0123456789ABCDEF
+
+DEFAULT_BOUNCE = np.zeros((9, 6), dtype=np.int8)
+DEFAULT_BOUNCE[1] = DEFAULT_BOUNCE[7] = [1, 2, 3, 3, 2, 1]
+
+
+def _batches(make, depth):
+    import torch
+
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    out = []
+    for s in streams:
+        with torch.cuda.stream(s):
+            out.append(make())
+    return streams, out
+
+
+@pytest.mark.parametrize("depth,slots", [(1, 2), (3, 9), (4, 5)])
+def test_executor_delivers_every_step_in_order(depth, slots):
+    """Step s = batch s % depth, seed seed0 + s, host array (hand-over index) % slots: the arrays of the last `slots`
+    hand-overs equal the oracle's rewards for their seeds, whatever depth and slot count; steps without hand-over in
+    between advance the seed but not the host array."""
+    from simulator.batch import ConnectBatch, RewardSink
+    from simulator.pipeline import RolloutExecutor
+
+    n, first = 6000, 123
+    streams, batches = _batches(lambda: ConnectBatch(6, 7, 4, n, use_torch=True), depth)
+    for b in batches:
+        b.set_first_game(first)
+    hosts = [np.full((n, 2), 9, dtype=np.int8) for _ in range(slots)]
+    sink = RewardSink(n, slots=slots, threads=3)
+    with RolloutExecutor(batches, sink=sink, host_arrays=hosts, seed0=SEED + 40) as exe:
+        exe.enqueue(7, True, time_stride=2)
+        exe.enqueue(3, False)             # steps 7, 8, 9 stay on the device
+        exe.enqueue(slots + 2, True)
+        exe.drain()
+        assert exe.steps == 12 + slots and exe.handovers == 9 + slots
+        ms, pairs = exe.kernel_ms()
+        assert pairs == 4 and ms > 0
+        assert exe.kernel_ms() == (None, 0)   # the brackets are consumed
+        # hand-over j came from step j (j < 7) or step j + 3 (j >= 7)
+        for j in range(exe.handovers - slots, exe.handovers):
+            step = j if j < 7 else j + 3
+            orc = oracle.ConnectOracle(6, 7, 4, n)
+            orc.rollout(SEED + 40 + step, first_game=first)
+            np.testing.assert_array_equal(hosts[j % slots], orc.reward, err_msg=f"hand-over {j} (step {step})")
+        assert exe.last_host_array() is hosts[(exe.handovers - 1) % slots]
+        assert sum(b.steps for b in batches) > (12 + slots) * n * 7
+    sink.close()
+    for b in batches:
+        b.close()
+
+
+def test_executor_bounce_with_a_ply_cap():
+    from simulator.batch import BounceBatch, RewardSink
+    from simulator.pipeline import RolloutExecutor
+
+    n = 900
+    streams, batches = _batches(lambda: BounceBatch(DEFAULT_BOUNCE, n, use_torch=True), 2)
+    hosts = [np.zeros((n, 2), dtype=np.int8) for _ in range(4)]
+    sink = RewardSink(n, slots=4, threads=2)
+    with RolloutExecutor(batches, sink=sink, host_arrays=hosts, seed0=5, max_plies=300) as exe:
+        exe.enqueue(6)
+        exe.drain()
+        for j in range(2, 6):
+            orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+            orc.rollout(5 + j, max_plies=300)
+            np.testing.assert_array_equal(hosts[j % 4], orc.reward, err_msg=f"step {j}")
+    sink.close()
+
+
+def test_executor_argument_checks():
+    from simulator.batch import ConnectBatch, RewardSink
+    from simulator.pipeline import RolloutExecutor
+
+    b = ConnectBatch(6, 7, 4, 64)
+    sink = RewardSink(64, slots=2, threads=1)
+    with pytest.raises(ValueError):
+        RolloutExecutor([b, b], sink=sink, host_arrays=[np.zeros((64, 2), np.int8)])  # the same batch twice
+    with pytest.raises(ValueError):
+        RolloutExecutor([b], sink=sink, host_arrays=[np.zeros((63, 2), np.int8)])     # destination too small
+    with pytest.raises(ValueError):
+        RolloutExecutor([b], sink=sink, host_arrays=[])                               # a hand-over without arrays
+    exe = RolloutExecutor([b])                                                        # no hand-over at all
+    with pytest.raises(ValueError):
+        exe.enqueue(1, True)
+    exe.enqueue(2, False)
+    exe.drain()
+    assert b.steps > 0
+    exe.close()
+    sink.close()
+
+
+def test_sink_serves_two_submitting_threads():
+    """Two threads, each with its own batch and stream, submit to ONE sink at the same time: tickets are reserved under
+    the sink's lock, so no two submissions share a slot and every host array ends up with its own step's rewards."""
+    from simulator.batch import ConnectBatch, RewardSink
+
+    n, rounds = 3000, 25
+    streams, batches = _batches(lambda: ConnectBatch(6, 7, 4, n, use_torch=True), 2)
+    sink = RewardSink(n, slots=3, threads=2)
+    hosts = [[np.zeros((n, 2), dtype=np.int8) for _ in range(rounds)] for _ in range(2)]
+    tickets = [[], []]
+    errors = []
+
+    def worker(k):
+        try:
+            for r in range(rounds):
+                tickets[k].append(sink.rollout(batches[k], hosts[k][r], SEED + 1000 * k + r, from_initial=True))
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert sorted(tickets[0] + tickets[1]) == list(range(2 * rounds))  # every ticket handed out exactly once
+    sink.wait(2 * rounds - 1)
+    assert sink.completed == 2 * rounds
+    for k in range(2):
+        for r in range(rounds):
+            orc = oracle.ConnectOracle(6, 7, 4, n)
+            orc.rollout(SEED + 1000 * k + r)
+            np.testing.assert_array_equal(hosts[k][r], orc.reward, err_msg=f"thread {k} round {r}")
+    sink.close()
+
+
+def test_sink_checks_and_keeps_its_destinations():
+    from simulator.batch import ConnectBatch, RewardSink
+
+    n = 4096
+    b = ConnectBatch(6, 7, 4, n)
+    sink = RewardSink(n, slots=2, threads=2)
+    with pytest.raises(ValueError):
+        sink.rollout(b, np.zeros((n - 1, 2), dtype=np.int8), SEED, from_initial=True)     # too small
+    with pytest.raises(TypeError):
+        sink.rollout(b, np.zeros((n, 2), dtype=np.int16), SEED, from_initial=True)        # wrong item size
+    ro = np.zeros((n, 2), dtype=np.int8)
+    ro.setflags(write=False)
+    with pytest.raises(ValueError):
+        sink.rollout(b, ro, SEED, from_initial=True)                                        # read-only
+    with pytest.raises(TypeError):
+        sink.rollout(b, np.zeros((n, 4), dtype=np.int8)[:, :2], SEED, from_initial=True)  # not contiguous
+    # the sink holds on to a destination the caller drops before the delivery
+    t = sink.rollout(b, np.zeros((n, 2), dtype=np.int8), SEED, from_initial=True)
+    kept = sink._alive[t][0]
+    sink.wait(t)
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    orc.rollout(SEED)
+    np.testing.assert_array_equal(kept, orc.reward)
+    assert t not in sink._alive
+    # close() waits for what is still in flight
+    last = np.zeros((n, 2), dtype=np.int8)
+    sink.rollout(b, last, SEED + 1, from_initial=True)
+    sink.close()
+    orc.reset()
+    orc.rollout(SEED + 1)
+    np.testing.assert_array_equal(last, orc.reward)
+
+
+GATHER_CHILD = """
+import os, sys
+sys.path[:0] = [{root!r}, {pkg!r}]
+import numpy as np, torch, torch.distributed as dist
+from oracle import oracle
+from simulator.batch import ConnectBatch
+from simulator.pipeline import RolloutExecutor
+from simulator.sharding import RewardGather
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1)
+n, depth, slots, seed0 = 40000, 3, 6, 0x0123456789ABCDEF + 9
+streams = [torch.cuda.Stream() for _ in range(depth)]
+batches = []
+for s in streams:
+    with torch.cuda.stream(s):
+        batches.append(ConnectBatch(6, 7, 4, n, use_torch=True))
+gather = RewardGather(dist, n, slots=slots, host_threads=3)
+hosts = [np.full((n, 2), 7, dtype=np.int8) for _ in range(slots)]
+exe = RolloutExecutor(batches, gather=gather, host_arrays=hosts, seed0=seed0)
+exe.enqueue(20, True, 4)
+exe.drain()
+for j in range(20 - slots, 20):
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    orc.rollout(seed0 + j)
+    assert np.array_equal(hosts[j % slots], orc.reward), f"step {{j}}"
+# single calls through the object, too
+t = gather.rollout(batches[0], hosts[0], 77)
+gather.wait(t)
+orc = oracle.ConnectOracle(6, 7, 4, n)
+orc.rollout(77)
+assert np.array_equal(hosts[0], orc.reward)
+try:
+    gather.rollout(batches[0], np.zeros((n - 4, 2), np.int8), 78)
+    raise SystemExit("a short destination was accepted")
+except ValueError:
+    pass
+exe.close(); gather.close()
+dist.destroy_process_group()
+print("GATHER_OK", os.environ.get("BGS_GATHER_DIRECT", "0"))
+"""
+
+
+@pytest.mark.parametrize("direct", ["0", "1"])
+def test_in_library_rccl_gather_with_one_rank(direct):
+    """bgs_gather_* over the real RCCL with a world of one rank: persistent communicator (ncclCommInitRank), the
+    communication thread's send / receive group per step, rank 0's sink -- through the native loop and by single calls.
+    direct=1: the receives land straight in the sink's device-mapped slot.  (Child process under `timeout`: a collective
+    that does not complete must not take the test session along.)"""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = GATHER_CHILD.format(root=ROOT, pkg=PKG, port=port)
+    env = dict(os.environ, BGS_GATHER_DIRECT=direct)
+    proc = subprocess.run(["timeout", "-k", "10", "300", sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert proc.returncode == 0 and "GATHER_OK" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-3000:]

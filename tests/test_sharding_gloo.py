@@ -87,7 +87,7 @@ def test_two_rank_sharding_and_reward_gather(tmp_path):
 
 RING_WORKER = textwrap.dedent(
     """
-    import os, sys
+    import os, sys, time
     sys.path[:0] = [{root!r}, os.path.join({root!r}, "board-game-simulator-python_amd")]
     import numpy as np, torch.distributed as dist
     from oracle import oracle
@@ -101,25 +101,39 @@ RING_WORKER = textwrap.dedent(
 
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    per_rank, slots, steps, seed = 1024, 2, 5, 0x0123456789ABCDEF
+    per_rank, slots, steps, seed = {per_rank}, {slots}, {steps}, 0x0123456789ABCDEF
     ring = SharedRewardRing(dist, per_rank, slots)
     assert ring.array(0).shape == (world * per_rank, 2) and ring.mine(1).shape == (per_rank, 2)
     assert ring.mine(0).flags["C_CONTIGUOUS"] and not ring.done(0)
     first, _ = shard_range(world * per_rank, rank, world)
+    # Producers run as far ahead as the consumer's releases allow; the consumer (rank 0, which also produces) trails and
+    # is slow on purpose: a producer that overwrote a slot before its release would be caught by the comparison below.
+    consumed = 0
+    def consume_upto(limit):
+        global consumed
+        while consumed <= limit:
+            ring.wait_all(consumed)
+            time.sleep(0.01)
+            whole = oracle.ConnectOracle(6, 7, 4, world * per_rank)
+            whole.rollout(seed + consumed)
+            assert np.array_equal(ring.array(consumed % slots), whole.reward), f"step {{consumed}}: the shared array is not the unsharded run"
+            ring.release(consumed)
+            consumed += 1
     for step in range(steps):
-        if step >= slots:
-            assert ring.done(step - slots)  # the step that used this slot before was delivered by everybody
+        if rank == 0:
+            consume_upto(step - slots)   # (what acquire() below is about to need from the consumer)
+        ring.acquire(step)               # the consumer has released the step that used this slot before
         shard = oracle.ConnectOracle(6, 7, 4, per_rank)
         shard.rollout(seed + step, first_game=first)
         # what a rank's reward sink does: expand its own outcome codes into ITS rows of the shared array
         expand_outcomes_host(pack_codes(shard.winner), per_rank, ring.mine(step % slots))
         ring.publish(step)
-        if rank == 0:
-            ring.wait_all(step)
-            whole = oracle.ConnectOracle(6, 7, 4, world * per_rank)
-            whole.rollout(seed + step)
-            assert np.array_equal(ring.array(step % slots), whole.reward), f"step {{step}}: the shared array is not the unsharded run"
-        dist.barrier()  # rank 0 has compared this step before anybody reuses its slot
+    if rank == 0:
+        consume_upto(steps - 1)
+    ring.publish(steps - 3)              # progress never moves backwards
+    assert ring._progress[rank, 0] == steps
+    dist.barrier()
+    assert ring.done(steps - 1)
     # a directory that cannot hold the ring: the constructor raises on EVERY rank (callers then fall back together)
     try:
         SharedRewardRing(dist, 1 << 40, slots)
@@ -132,9 +146,15 @@ RING_WORKER = textwrap.dedent(
     except RuntimeError:
         pass
     if rank == 0:
+        t0 = time.monotonic()
         try:
-            ring.wait_all(steps, timeout=0.2)
+            ring.wait_all(steps, timeout=0.3)
             raise SystemExit("wait_all returned for a step nobody published")
+        except TimeoutError as exc:
+            assert "ranks" in str(exc) and 0.25 < time.monotonic() - t0 < 5.0
+        try:
+            ring.acquire(steps + slots, timeout=0.2)
+            raise SystemExit("acquire returned for a slot the consumer has not released")
         except TimeoutError:
             pass
         left = [f for f in os.listdir("/dev/shm") if f.startswith("bgs_rewards_")]
@@ -147,20 +167,31 @@ RING_WORKER = textwrap.dedent(
 )
 
 
-def test_three_ranks_deliver_into_one_shared_host_array(tmp_path):
-    """The N > 1 hand-over bench.py uses on one node: no collective in the data path, every rank expands its own outcome
-    codes into its rows of one host array in shared memory; rank 0 sees the unsharded run."""
+def _run_ring(tmp_path, ranks, per_rank, slots, steps):
     script = tmp_path / "ring_worker.py"
-    script.write_text(RING_WORKER.format(root=ROOT))
+    script.write_text(RING_WORKER.format(root=ROOT, per_rank=per_rank, slots=slots, steps=steps))
     port = _free_port()
     procs = []
-    for rank in range(3):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    for rank in range(ranks):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(ranks), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=240)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    outs = [p.communicate(timeout=420)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     assert "SHARED_RING_OK" in outs[0]
+
+
+def test_three_ranks_deliver_into_one_shared_host_array(tmp_path):
+    """The N > 1 hand-over bench.py uses on one node: no collective in the data path, every rank expands its own outcome
+    codes into its rows of one host array in shared memory; rank 0 consumes (futex waits, release / acquire hand-shake)
+    and sees the unsharded run."""
+    _run_ring(tmp_path, ranks=3, per_rank=1024, slots=2, steps=6)
+
+
+def test_eight_ranks_rehearsal_of_the_shared_host_array(tmp_path):
+    """The 8-GPU layout as 8 CPU processes: eight producers, a slow consumer three slots behind, the too-small-/dev/shm
+    fall-back raised on all eight ranks."""
+    _run_ring(tmp_path, ranks=8, per_rank=512, slots=3, steps=9)
 
 
 def test_shard_range_validation():

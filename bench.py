@@ -193,10 +193,12 @@ def cpu_baseline(last_seed, host_reward_head):
         "single_thread_value": single,
         "single_game_latency_us": latency,
         "single_game_mean_plies": plies,
+        "single_game_us_inside_a_batch": (plies / single * 1e6) if single and plies else None,
         "kind": "port",
         "sample": f"CPU restatement (oracle/bgs_oracle.c, OpenMP, {cores} threads{capped}) -- the reference's own core is not "
         f"buildable offline: {reps} x 2^20 Connect4(6,7,4) games from the initial state ({total} env-steps); "
-        "single_game_latency_us = one game (BASELINE config 1, N = 1) per call of the oracle through ctypes, mean of 2000 games",
+        "single_game_latency_us = one game (BASELINE config 1, N = 1) per reset + rollout call of the oracle through ctypes, mean "
+        "of 2000 games (mostly call overhead: single_game_us_inside_a_batch is the same game's share of a one-thread batch)",
         "parity_with_host_rewards": parity,
     }
 
@@ -402,6 +404,10 @@ def main() -> int:
                          "memory and every rank's own sink delivers its rows (no collective, every GPU uses its own PCIe "
                          "link); rccl: outcome codes gathered to rank 0's GPU over RCCL inside the library, rank 0's sink "
                          "expands them all")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="untimed steps (hand-over included) before the W warm-up steps until this many milliseconds have "
+                    "passed: the GPU's power state climbs for tens of milliseconds under load, and RCCL connects on first "
+                    "use; without it a short timed region measures that ramp (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-resident", action="store_true",
                     help="skip the extra, separately timed pass without hand-over that fills `device_resident`")
@@ -484,8 +490,11 @@ def main() -> int:
     # The hand-over pipeline is deeper than the GPU's (three times as many host arrays / sink slots as streams), so the
     # launching thread waits for the delivery of step i - 3 * depth, not i - depth, before it enqueues step i (measured,
     # tools/slots_sweep.sh: 3 per stream is 3 % faster than 2 on a 20-step run, 4 is slower: more arrays than the caches
-    # hold).  Rank 0 of an RCCL gather holds world x 2 MiB per array: two per stream there.
-    factor = int(os.environ.get("BGS_BENCH_SLOT_FACTOR", "2" if (lib_gather or torch_gather) and world > 1 else "3"))
+    # hold).
+    # Shared array: the consumer rank's launch loop also waits for EVERY rank's delivery of hand-over j - lag before it
+    # enqueues hand-over j, so it runs `lag`, not `host_slots`, steps ahead of the deliveries: one more array per stream
+    # keeps lag at 3 per stream (a delivery -> futex wake-up -> enqueue chain takes ~100 us, 3 steps' worth).
+    factor = int(os.environ.get("BGS_BENCH_SLOT_FACTOR", "4" if ring_mode else "3"))
     host_slots = max(2, factor * depth)
     ring = None
     if ring_mode:
@@ -592,6 +601,21 @@ def main() -> int:
             steps_total = steps_local
         return dt, steps_total, steps_local, kernel_ms
 
+    # untimed: bring the device to its loaded power state (and RCCL to connected peers), then the W warm-up steps
+    prewarm_steps = 0
+    if args.prewarm_ms > 0:
+        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
+        while True:
+            run_steps(4 * depth, True)
+            drain()
+            prewarm_steps += 4 * depth
+            go_on = time.perf_counter() < t_end
+            if dist is not None:  # every rank makes the same number of (collective) steps
+                flag = torch.tensor([1 if go_on else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                go_on = bool(flag.item())
+            if not go_on:
+                break
     run_steps(args.warmup, True)
     drain()
     # HIP-event pairs bracket a sample of the launches on the launch stream: about 32 pairs
@@ -701,6 +725,7 @@ def main() -> int:
                 "gathered_rewards_verified": gather_ok,
                 "numa_bound_cpus": bound_cpus if sharded else None,
                 "inflight_batches": depth,
+                "prewarm": {"ms": args.prewarm_ms, "steps": prewarm_steps},
                 "host_arrays": host_slots,
                 "loop": "native (bgs_pipeline_enqueue: one library call per timed region)" if exe is not None else "python (rehearsal)",
                 "waves_per_simd_per_launch": int(os.environ["BGS_ROLLOUT_WPS"]),

@@ -485,14 +485,22 @@ int bgs_connect_arena_bytes(int height, int width, int count, int64_t n, size_t*
     return BGS_OK;
 }
 
+// one arena layout per board SIZE, for the size query and for the carve alike (up to 64 cells: the packed form's four
+// planes, which also hold a small generic board)
+static auto bounce_layout(int64_t n, int height, int width) {
+    return layout_for(height * width > BGS_BOUNCE_MAX_CELLS ? 0 : 4, n, height, width, bgs::generic_bounce_legal_bytes(height, width));
+}
+
 int bgs_bounce_arena_bytes(int height, int width, int64_t n, size_t* bytes) {
     BounceGeom bg;
     int generic = 0;
     int rc = bounce_geom(nullptr, height, width, &bg, &generic);
     if (rc) return rc;
     NEED(n >= 1 && bytes, "n must be >= 1 and bytes non-NULL");
-    // (whether the batch is packed or generic also depends on the piece values: the arena covers both forms)
-    *bytes = layout_for(generic ? 0 : 4, n, height, width, bgs::generic_bounce_legal_bytes(height, width)).total;
+    // Whether the batch is packed or generic also depends on the piece values (and on BGS_FORCE_GENERIC), which this
+    // query cannot see: the size follows the CELL COUNT alone, exactly as bgs_bounce_create carves it
+    (void)generic;
+    *bytes = bounce_layout(n, height, width).total;
     return BGS_OK;
 }
 
@@ -556,9 +564,7 @@ int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, 
     rc = device_facts(b);
     if (rc == BGS_OK) {
         // the arena is sized for whichever form the values select (bgs_bounce_arena_bytes cannot know them)
-        const int size_generic = height * width > BGS_BOUNCE_MAX_CELLS;
-        rc = carve(b, arena, arena_bytes,
-                   layout_for(size_generic ? 0 : 4, n, height, width, bgs::generic_bounce_legal_bytes(height, width)));
+        rc = carve(b, arena, arena_bytes, bounce_layout(n, height, width));
     }
     if (rc == BGS_OK) rc = make_order_event(b);
     if (rc == BGS_OK && generic) rc = generic_bounce_setup(b, cfg_grid);

@@ -208,7 +208,11 @@ struct bgs_reward_sink {
     // alone; the knob stays for callers with one batch in flight.  The counters themselves stay under mu.
     std::atomic<int64_t> a_submitted{0}, a_landed{0}, a_completed{0};
     std::atomic<bool> a_stop{false};
+    std::atomic<int> urgent{0};          // > 0: somebody is waiting for the LAST deliveries (bgs_sink_wait): worker 0 polls the
+                                         // arrival events instead of sleeping in the runtime (a wake-up out of
+                                         // hipEventSynchronize costs tens of microseconds, nothing overlaps it at the end)
     int spin_us = 0;
+    int wait_spin_us = 200;              // bgs_sink_wait spins this long before it sleeps (BGS_SINK_WAIT_SPIN_US)
 
     // true once counter > ticket (or stop); false when the spin budget ran out
     bool spin_for(const std::atomic<int64_t>& counter, int64_t ticket) const {
@@ -243,7 +247,7 @@ struct bgs_reward_sink {
                 }
                 if (job.n_games == 0) {
                     ok = false;  // the enqueue failed: no event was recorded for this ticket
-                } else if (poll) {
+                } else if (poll || urgent.load(std::memory_order_relaxed) > 0) {
                     // busy-poll: the wake-up out of hipEventSynchronize costs tens of microseconds, which matters at
                     // the end of a short run (the last delivery is not overlapped with anything)
                     hipError_t e;
@@ -334,6 +338,31 @@ uint8_t* sink_slot_host(bgs_reward_sink* s, int64_t ticket) { return s->pinned[t
 hipEvent_t sink_slot_event(bgs_reward_sink* s, int64_t ticket) { return s->landed[ticket % s->slots]; }
 void sink_publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok) {
     publish(s, ticket, n_games, host_reward, ok);
+}
+// urgent: the caller is at the END of a run (bgs_pipeline_drain): worker 0 polls the arrival events from here on and
+// the caller spins a little before it sleeps -- the last deliveries are a few tens of microseconds away and overlap
+// with nothing, while a wake-up out of hipEventSynchronize or a condition variable costs as much again.  In the steady
+// state (waits that only throttle the launching thread) nobody spins.
+int sink_wait(bgs_reward_sink* s, int64_t ticket, bool urgent) {
+    NEED(s != nullptr, "sink is NULL");
+    NEED(ticket >= 0 && ticket < s->a_submitted.load(std::memory_order_acquire), "unknown ticket %lld", (long long)ticket);
+    if (s->a_completed.load(std::memory_order_acquire) <= ticket) {
+        if (urgent) {
+            s->urgent.fetch_add(1, std::memory_order_relaxed);
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(s->wait_spin_us);
+            while (s->a_completed.load(std::memory_order_acquire) <= ticket && std::chrono::steady_clock::now() < until)
+                for (int i = 0; i < 32; ++i) _mm_pause();
+        } else {
+            s->spin_for(s->a_completed, ticket);
+        }
+        {
+            std::unique_lock<std::mutex> lock(s->mu);
+            s->cv_done.wait(lock, [&] { return s->completed > ticket; });
+        }
+        if (urgent) s->urgent.fetch_sub(1, std::memory_order_relaxed);
+    }
+    if (s->failed) return fail(BGS_ERR_RUNTIME, "a reward hand-over failed (enqueue or hipEventSynchronize)");
+    return BGS_OK;
 }
 }  // namespace bgs
 
@@ -446,6 +475,10 @@ int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_r
     s->threads = threads;
     s->jobs.resize(slots);
     if (const char* env = getenv("BGS_SINK_POLL")) s->poll = atoi(env) != 0;
+    if (const char* env = getenv("BGS_SINK_WAIT_SPIN_US")) {
+        const int v = atoi(env);
+        if (v >= 0 && v <= 1000000) s->wait_spin_us = v;
+    }
     if (const char* env = getenv("BGS_SINK_SPIN_US")) {
         const int v = atoi(env);
         if (v >= 0 && v <= 1000000) s->spin_us = v;
@@ -614,14 +647,6 @@ int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* dev
     return BGS_OK;
 }
 
-int bgs_sink_wait(bgs_reward_sink* s, int64_t ticket) {
-    NEED(s != nullptr, "sink is NULL");
-    NEED(ticket >= 0 && ticket < s->a_submitted.load(std::memory_order_acquire), "unknown ticket %lld", (long long)ticket);
-    s->spin_for(s->a_completed, ticket);
-    std::unique_lock<std::mutex> lock(s->mu);
-    s->cv_done.wait(lock, [&] { return s->completed > ticket; });
-    if (s->failed) return fail(BGS_ERR_RUNTIME, "a reward copy failed (hipEventSynchronize)");
-    return BGS_OK;
-}
+int bgs_sink_wait(bgs_reward_sink* s, int64_t ticket) { return bgs::sink_wait(s, ticket, false); }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 #include <stddef.h>
 
 struct bgs_reward_sink;  // bgs_host.hip
+struct bgs_gather;       // bgs_multi.hip
 
 enum { BGS_GAME_CONNECT = 1, BGS_GAME_BOUNCE = 2 };
 
@@ -148,5 +149,7 @@ uint8_t* sink_slot_device(bgs_reward_sink* s, int64_t ticket);
 uint8_t* sink_slot_host(bgs_reward_sink* s, int64_t ticket);
 hipEvent_t sink_slot_event(bgs_reward_sink* s, int64_t ticket);
 void sink_publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok);
+int sink_wait(bgs_reward_sink* s, int64_t ticket, bool urgent);  // urgent: poll / spin (the end of a run)
+int gather_wait(bgs_gather* g, int64_t ticket, bool urgent);     // bgs_multi.hip
 
 }  // namespace bgs

@@ -12,6 +12,7 @@
 // link-time dependency on it and shares the copy a framework in the same process may already have mapped.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -79,6 +80,13 @@ const Rccl& rccl() {
         return r;
     }();
     return api;
+}
+
+// gathered codes (device) -> the sink's page-locked slot as the GPU sees it: 16-byte stores over PCIe, no copy engine
+// and no copy call (a hipMemcpyAsync device -> host per step costs the communication stream ~10x this kernel)
+__global__ void __launch_bounds__(256) k_codes_to_slot(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t units) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < units) dst[i] = src[i];
 }
 
 #define NCCL_TRY(expr)                                                                                   \
@@ -178,12 +186,18 @@ done:
 
 // ------------------------------------------------------------------------------------------------
 // bgs_gather: one process per GPU, persistent communicator, communication thread
+// Measured with a one-rank world (the gather is then a self send / receive, which RCCL turns into ~25 small fill / copy
+// dispatches per group on the communication stream): 1 step per group 0.85 of the device-resident rate, 3 per group
+// 0.87, 6 per group 0.96; receiving into device memory + copy kernel instead of straight into the sink's slot: -7 %.
 // ------------------------------------------------------------------------------------------------
 struct bgs_gather {
     int device = 0, rank = 0, world = 1, slots = 0;
     int64_t n = 0;            // games per rank
     size_t code_bytes = 0;    // n / 4: what a rank contributes per step
-    bool direct = false;      // rank 0 receives straight into the sink's device-mapped slot (BGS_GATHER_DIRECT=1)
+    bool direct = true;       // rank 0 receives straight into the sink's device-mapped slot; BGS_GATHER_DIRECT=0: into
+                              // device memory, and a copy kernel takes the gathered codes to the slot
+    int batch = 3;            // steps per group of point-to-point calls (BGS_GATHER_BATCH; at most `slots`)
+    int64_t flush_upto = 0;   // somebody waits for a step below this: send partial groups
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;        // everything RCCL does for this rank is enqueued here
     std::vector<uint8_t*> codes;         // [slots] device: the rollout kernel writes a step's codes here
@@ -207,50 +221,67 @@ struct bgs_gather {
         failed = true;
     }
 
+    // The communication thread.  Steps are gathered `batch` at a time (BGS_GATHER_BATCH, default 1): ONE group of
+    // point-to-point calls -- one RCCL kernel -- carries the codes of `batch` consecutive steps, at the price of
+    // delivering a step only when the last rollout of its group has finished.  A partial group goes out as soon as
+    // somebody waits for one of its steps (flush_upto).
     void run() {
         (void)hipSetDevice(device);
         const Rccl& api = rccl();
-        for (int64_t t = 0;; ++t) {
+        std::vector<int64_t> st((size_t)batch, -1);
+        for (int64_t t = 0;;) {
+            int k;
             {
                 std::unique_lock<std::mutex> lock(mu);
-                cv.wait(lock, [&] { return stop || submitted > t; });
-                if (submitted <= t) return;
+                cv.wait(lock, [&] { return stop || submitted >= t + batch || (submitted > t && flush_upto > t); });
+                if (submitted <= t) return;  // stop, nothing left
+                k = (int)std::min<int64_t>(batch, submitted - t);
             }
-            const int slot = (int)(t % slots);
             bool ok = !failed;
             hipError_t he = hipSuccess;
             int ne = 0;
-            int64_t st = -1;
-            if (rank == 0) st = bgs::sink_claim(sink);  // (blocks while every sink slot is still being expanded)
-            uint8_t* dst = rank == 0 ? (direct ? bgs::sink_slot_device(sink, st) : gathered[slot]) : nullptr;
-            if (ok && (he = hipStreamWaitEvent(stream, rolled[slot], 0)) != hipSuccess) ok = false;
+            for (int i = 0; i < k; ++i) {
+                const int slot = (int)((t + i) % slots);
+                if (rank == 0) st[i] = bgs::sink_claim(sink);  // (blocks while every sink slot is still being expanded)
+                if (ok && (he = hipStreamWaitEvent(stream, rolled[slot], 0)) != hipSuccess) ok = false;
+            }
             if (ok) {
                 // the gather: one group of point-to-point calls, every rank -> rank 0
                 if ((ne = api.GroupStart()) == 0) {
-                    ne = api.Send(codes[slot], code_bytes, kNcclUint8, 0, comm, stream);
-                    for (int r = 0; r < world && rank == 0 && ne == 0; ++r)
-                        ne = api.Recv(dst + (size_t)r * code_bytes, code_bytes, kNcclUint8, r, comm, stream);
+                    for (int i = 0; i < k && ne == 0; ++i) {
+                        const int slot = (int)((t + i) % slots);
+                        ne = api.Send(codes[slot], code_bytes, kNcclUint8, 0, comm, stream);
+                        uint8_t* dst = rank != 0 ? nullptr : direct ? bgs::sink_slot_device(sink, st[i]) : gathered[slot];
+                        for (int r = 0; r < world && rank == 0 && ne == 0; ++r)
+                            ne = api.Recv(dst + (size_t)r * code_bytes, code_bytes, kNcclUint8, r, comm, stream);
+                    }
                     const int ge = api.GroupEnd();
                     if (ne == 0) ne = ge;
                 }
                 if (ne != 0) ok = false;
             }
-            if (ok && (he = hipEventRecord(sent[slot], stream)) != hipSuccess) ok = false;
-            if (rank == 0) {
-                if (ok && !direct)
-                    if ((he = hipMemcpyAsync(bgs::sink_slot_host(sink, st), gathered[slot], code_bytes * (size_t)world,
-                                             hipMemcpyDeviceToHost, stream)) != hipSuccess)
-                        ok = false;
-                if (ok && (he = hipEventRecord(bgs::sink_slot_event(sink, st), stream)) != hipSuccess) ok = false;
-                bgs::sink_publish(sink, st, n * world, host[slot], ok);
+            for (int i = 0; i < k; ++i) {
+                const int slot = (int)((t + i) % slots);
+                if (ok && (he = hipEventRecord(sent[slot], stream)) != hipSuccess) ok = false;
+                if (rank != 0) continue;
+                if (ok && !direct) {
+                    const size_t units = (code_bytes * (size_t)world + 15) / 16;  // (both buffers are whole 16-byte units)
+                    hipLaunchKernelGGL(k_codes_to_slot, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream,
+                                       reinterpret_cast<const uint4*>(gathered[slot]),
+                                       reinterpret_cast<uint4*>(bgs::sink_slot_device(sink, st[i])), units);
+                    if ((he = hipGetLastError()) != hipSuccess) ok = false;
+                }
+                if (ok && (he = hipEventRecord(bgs::sink_slot_event(sink, st[i]), stream)) != hipSuccess) ok = false;
+                bgs::sink_publish(sink, st[i], n * world, host[slot], ok);
             }
             if (!ok && !failed) {
                 if (ne != 0) fail_with("RCCL", api.GetErrorString(ne));
                 else fail_with("HIP", hipGetErrorString(he));
             }
+            t += k;
             {
                 std::lock_guard<std::mutex> lock(mu);
-                enqueued = t + 1;
+                enqueued = t;
             }
             cv.notify_all();
         }
@@ -287,6 +318,11 @@ int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_
     g->n = n_per_rank;
     g->code_bytes = (size_t)n_per_rank / 4;
     if (const char* e = getenv("BGS_GATHER_DIRECT")) g->direct = atoi(e) != 0;
+    if (const char* e = getenv("BGS_GATHER_BATCH")) {
+        const int v = atoi(e);
+        if (v >= 1) g->batch = v;
+    }
+    if (g->batch > slots) g->batch = slots;
     g->host.assign(slots, nullptr);
     int rc = BGS_OK;
     hipError_t he = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
@@ -295,7 +331,8 @@ int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_
         void* p = nullptr;
         hipEvent_t e = nullptr;
         if ((he = hipMalloc(&p, padded)) == hipSuccess) g->codes.push_back(static_cast<uint8_t*>(p));
-        if (he == hipSuccess && rank == 0 && !g->direct && (he = hipMalloc(&p, g->code_bytes * (size_t)world)) == hipSuccess)
+        if (he == hipSuccess && rank == 0 && !g->direct &&
+            (he = hipMalloc(&p, (g->code_bytes * (size_t)world + 15) / 16 * 16)) == hipSuccess)
             g->gathered.push_back(static_cast<uint8_t*>(p));
         if (he == hipSuccess && (he = hipEventCreateWithFlags(&e, hipEventDisableTiming)) == hipSuccess) g->rolled.push_back(e);
         if (he == hipSuccess && (he = hipEventCreateWithFlags(&e, hipEventDisableTiming)) == hipSuccess) g->sent.push_back(e);
@@ -331,6 +368,10 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
         // before the batch's stream can be told to wait for it
         std::unique_lock<std::mutex> lock(g->mu);
         t = g->submitted;
+        if (g->enqueued <= t - g->slots) {
+            g->flush_upto = std::max(g->flush_upto, t - g->slots + 1);
+            g->cv.notify_all();
+        }
         g->cv.wait(lock, [&] { return g->enqueued > t - g->slots; });
         if (g->failed) return fail(BGS_ERR_RUNTIME, "the reward gather failed earlier: %s", g->error.c_str());
     }
@@ -349,22 +390,32 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
     return BGS_OK;
 }
 
-int bgs_gather_wait(bgs_gather* g, int64_t ticket) {
+int bgs_gather_wait(bgs_gather* g, int64_t ticket) { return bgs::gather_wait(g, ticket, false); }
+
+}  // extern "C"
+
+int bgs::gather_wait(bgs_gather* g, int64_t ticket, bool urgent) {
     NEED(g != nullptr, "gather is NULL");
     int64_t enq;
     {
         std::unique_lock<std::mutex> lock(g->mu);
         NEED(ticket >= 0 && ticket < g->submitted, "unknown ticket %lld", (long long)ticket);
+        if (g->enqueued <= ticket) {
+            g->flush_upto = std::max(g->flush_upto, ticket + 1);
+            g->cv.notify_all();
+        }
         g->cv.wait(lock, [&] { return g->enqueued > ticket; });
         if (g->failed) return fail(BGS_ERR_RUNTIME, "the reward gather failed: %s", g->error.c_str());
         enq = g->enqueued;
     }
-    if (g->rank == 0) return bgs_sink_wait(g->sink, ticket);  // the sink belongs to the gather: same ticket numbers
+    if (g->rank == 0) return bgs::sink_wait(g->sink, ticket, urgent);  // the sink belongs to the gather: same ticket numbers
     // other ranks: "my codes have left".  A slot's event is reused `slots` steps later, and a step that old has been
     // sent long ago (its successor could not have been enqueued otherwise)
     if (ticket + g->slots >= enq) HIP_TRY(hipEventSynchronize(g->sent[ticket % g->slots]));
     return BGS_OK;
 }
+
+extern "C" {
 
 int bgs_gather_destroy(bgs_gather* g) {
     if (!g) return BGS_OK;
@@ -372,6 +423,8 @@ int bgs_gather_destroy(bgs_gather* g) {
     if (g->worker.joinable()) {
         {
             std::unique_lock<std::mutex> lock(g->mu);
+            g->flush_upto = g->submitted;
+            g->cv.notify_all();
             g->cv.wait(lock, [&] { return g->enqueued == g->submitted; });
             g->stop = true;
         }

@@ -93,8 +93,8 @@ int bgs_pipeline_set_ring(bgs_pipeline* p, const int64_t* rank_words, int64_t wo
     return BGS_OK;
 }
 
-static int wait_ticket(bgs_pipeline* p, int64_t t) {
-    return p->sink ? bgs_sink_wait(p->sink, t) : bgs_gather_wait(p->gather, t);
+static int wait_ticket(bgs_pipeline* p, int64_t t, bool urgent = false) {
+    return p->sink ? bgs::sink_wait(p->sink, t, urgent) : bgs::gather_wait(p->gather, t, urgent);
 }
 
 // the consumer's side of the shared-array hand-shake: every rank has delivered hand-over j -> release its slot
@@ -165,11 +165,11 @@ int bgs_pipeline_drain(bgs_pipeline* p) {
     NEED(p != nullptr, "pipeline is NULL");
     HIP_TRY(hipSetDevice(p->device));
     int rc;
-    for (size_t h = 0; h < p->ticket.size(); ++h)
-        if (p->ticket[h] >= 0) {
-            if ((rc = wait_ticket(p, p->ticket[h]))) return rc;
-            p->ticket[h] = -1;
-        }
+    // the newest hand-over first: every waiter it turns urgent stays so until the last delivery is in
+    int64_t newest = -1;
+    for (int64_t t : p->ticket) newest = t > newest ? t : newest;
+    if (newest >= 0 && (rc = wait_ticket(p, newest, true))) return rc;   // (deliveries complete in ticket order)
+    for (size_t h = 0; h < p->ticket.size(); ++h) p->ticket[h] = -1;
     // the consumer sees every hand-over of every rank before it calls the region done
     if (p->rank_words && p->consumer && p->handed > 0 && (rc = consume(p, p->handed - 1))) return rc;
     // steps without hand-over (and everything else the batches have enqueued): their streams run dry

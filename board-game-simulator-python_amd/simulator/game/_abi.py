@@ -179,10 +179,45 @@ def _one_hip_runtime_per_process() -> None:
         ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
 
 
+HW_QUEUES_WANTED = 32
+hw_queues_too_late = False  # True: HIP was initialised with the default 4 hardware queues before this module could ask for more
+
+
+def _more_hardware_queues() -> None:
+    """The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues -- 4 by default -- and reads
+    the variable once, when it initialises: beyond 4 batches in flight nothing overlaps until it is raised (the Bounce
+    rollouts want 16 batches in flight on 32 queues: 5x one launch at a time; Connect's 3 are unaffected either way,
+    measured).  Ask for more while that is still possible; remember when it is not, so that `RolloutPipeline` can refuse
+    a depth it cannot deliver instead of silently running 4 wide."""
+    global hw_queues_too_late
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return
+    torch = sys.modules.get("torch")
+    try:
+        initialised = torch is not None and torch.cuda.is_initialized()
+    except Exception:  # noqa: BLE001
+        initialised = False
+    if initialised:
+        hw_queues_too_late = True
+    else:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(HW_QUEUES_WANTED)
+
+
+def hardware_queues() -> int:
+    """Hardware queues this process's streams can spread over (what the HIP runtime was, or will be, initialised with)."""
+    if hw_queues_too_late:
+        return 4
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return 4
+
+
 def lib() -> ctypes.CDLL:
     """Load libbgs.so; fail loudly when it is absent (build it with `python __graft_entry__.py`)."""
     global _lib
     if _lib is None:
+        _more_hardware_queues()
         _one_hip_runtime_per_process()
         if not os.path.exists(LIB_PATH):
             raise ImportError(

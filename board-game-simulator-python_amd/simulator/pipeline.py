@@ -111,16 +111,39 @@ class RolloutExecutor:
             pass
 
 
+def default_depth(batch_cls) -> int:
+    """Batches in flight that saturate the chip: a Connect rollout is a ~50 us launch bound by VALU issue (3 in flight
+    fill the drain of one launch with the next); a Bounce rollout is a 5-15 ms launch whose tail is a handful of long
+    games (16 in flight on 32 hardware queues: 5x one launch at a time)."""
+    return 16 if getattr(batch_cls, "game", 0) == _abi.GAME_BOUNCE else 3
+
+
+def check_depth(depth: int) -> None:
+    """More than 4 batches in flight need more than the HIP runtime's default 4 hardware queues, and the runtime reads
+    GPU_MAX_HW_QUEUES only once, when it initialises: fail loudly when that moment has passed."""
+    if depth > 4 and _abi.hardware_queues() < depth:
+        raise RuntimeError(
+            f"{depth} batches in flight need GPU_MAX_HW_QUEUES >= {depth} (this process has {_abi.hardware_queues()}): the HIP "
+            "runtime was initialised before `simulator` could ask for more. Import `simulator` (or set GPU_MAX_HW_QUEUES=32) "
+            "before the first torch.cuda / HIP call, or pass depth <= 4.")
+
+
 class RolloutPipeline:
-    def __init__(self, batch_cls, config_args: tuple, n: int, depth: int = 3, host_threads: int = 6, device: int = 0,
+    def __init__(self, batch_cls, config_args: tuple, n: int, depth: Optional[int] = None, host_threads: int = 6, device: int = 0,
                  first_game: int = 0, max_plies: int = 2**31 - 1, host_arrays=None, arrays_per_stream: int = 3):
-        """`batch_cls(*config_args, n, device=..., use_torch=True)` is built `depth` times, each bound to its own stream.
+        """`batch_cls(*config_args, n, device=..., use_torch=True)` is built `depth` times, each bound to its own stream
+        (default: `default_depth(batch_cls)` -- 3 for Connect, 16 for Bounce).
         `host_arrays`: optional list of arrays_per_stream * depth C-contiguous int8[n, 2] destinations (e.g. rows of a shared array,
         `SharedRewardRing.mine(slot)`); by default the pipeline allocates (and pre-faults) its own."""
+        _abi.lib()  # (asks for more hardware queues while that is still possible: before torch touches the GPU)
         import torch
 
+        if depth is None:
+            depth = default_depth(batch_cls)
+            arrays_per_stream = min(arrays_per_stream, max(1, 48 // depth))
         if depth < 1:
             raise ValueError("depth must be >= 1")
+        check_depth(depth)
         self.n, self.depth, self.max_plies = int(n), int(depth), int(max_plies)
         self._torch = torch
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]

@@ -257,3 +257,17 @@ def test_object_api_on_generic_geometries(bm):
     st = bounce.Config(big).sample_initial_state()
     orc = oracle.BounceOracle(big, 1)
     assert [(tuple(map(int, a.source)), tuple(map(int, a.target))) for a in st.actions] == orc.actions(0)
+
+
+def test_forced_generic_small_bounce_board_in_a_caller_owned_arena(bm, forced_generic):
+    """A Bounce board of fewer than 32 cells on the generic kernels with the arena supplied by the caller (use_torch=True
+    queries bgs_bounce_arena_bytes first): the size query and the carve must agree on the layout (advisor, round 2)."""
+    grid = bounce_grid(5, 4, (1, 3), [1, 2, 2, 1])
+    n = 1500
+    dev = bm.BounceBatch(grid, n, use_torch=True)
+    assert dev.generic
+    orc = oracle.BounceOracle(grid, n)
+    dev.rollout(SEED, max_plies=500, from_initial=True)
+    orc.rollout(SEED, max_plies=500)
+    assert_same(dev, orc, "5x4 forced generic, torch arena")
+    dev.close()

@@ -147,6 +147,8 @@ def test_bounce_reference_games(golden_dir):
         assert bool(o.ended[0]) == test["final"]["has_ended"], test["name"]
         assert len(o.actions(0)) == test["final"]["n_actions"]
         assert o.reward[0].tolist() == test["final"]["reward"], test["name"]
+    # SURVEY 8c counts 16 reference positions: these 15 scripted ones (tests/test_bounce.py:92-362) plus the JSON
+    # round-trip position (tests/test_bounce.py:365-410), which test_bounce_reference_json_position checks below
     assert n_positions == 15
 
 

@@ -130,6 +130,22 @@ int bounce_geom(const int8_t* cfg, int h, int w, BounceGeom* bg, int* generic) {
             for (int p = 0; p < 4; ++p)
                 if ((v >> p) & 1) bg->init[p] |= bit;
         }
+    // the piece list: ascending (value, cell)
+    int pieces = 0;
+    for (int c = 0; c < h * w; ++c) pieces += cfg[c] > 0;
+    if (pieces >= 1 && pieces <= BGS_BOUNCE_MAX_PIECES) {
+        int k = 0;
+        for (int v = 1; v <= BGS_BOUNCE_MAX_VALUE; ++v)
+            for (int c = 0; c < h * w; ++c)
+                if (cfg[c] == v) {
+                    bg->piece_value[k] = (uint8_t)v;
+                    bg->piece_cell[k] = (uint8_t)c;
+                    for (int p = 0; p < 4; ++p)
+                        if ((k >> p) & 1) bg->piece_idx[p] |= 1ull << c;
+                    ++k;
+                }
+        bg->piece_count = (uint32_t)k;
+    }
     return BGS_OK;
 }
 
@@ -268,6 +284,10 @@ int device_facts(bgs_batch* b) {
     if (const char* env = getenv("BGS_BOUNCE_GROUP")) b->bounce_group = atoi(env) == 1 ? 1 : 8;
     b->bounce_flat = 1;
     if (const char* env = getenv("BGS_BOUNCE_FLAT")) b->bounce_flat = atoi(env) != 0;
+    b->bounce_pieces = 1;
+    if (const char* env = getenv("BGS_BOUNCE_PIECES")) b->bounce_pieces = atoi(env) != 0;
+    b->bounce_block = 256;
+    if (const char* env = getenv("BGS_BOUNCE_BLOCK")) b->bounce_block = atoi(env);
     b->bounce_flat_chunk = 32;
     if (const char* env = getenv("BGS_BOUNCE_CHUNK")) {
         const int v = atoi(env);
@@ -291,10 +311,14 @@ int device_facts(bgs_batch* b) {
     // multi-pass Bounce rollout (bounce_kernels.hip, bounce_rollout): "cap:lanes,..."; the last entry's cap is the
     // caller's max_plies whatever it says; "single" = one launch that plays every game to the end
     {
+        // default "auto": one launch, except for large from-initial batches on the piece-list kernel, whose handful of
+        // very long games (a random Bounce game can go on for ever: it stops at max_plies) is finished by a second pass
+        // with 8 lanes per board -- see bounce_rollout()
         const char* plan = getenv("BGS_BOUNCE_PLAN");
-        if (!plan) plan = "single";  // (measured on 2^18 default boards: the passes cost more than their tails save)
+        if (!plan) plan = "auto";
         b->bounce_passes = 0;
-        if (strcmp(plan, "single") != 0) {
+        b->bounce_plan_auto = strcmp(plan, "auto") == 0;
+        if (!b->bounce_plan_auto && strcmp(plan, "single") != 0) {
             const char* p = plan;
             while (*p && b->bounce_passes < BGS_BOUNCE_MAX_PASSES) {
                 char* endp = nullptr;

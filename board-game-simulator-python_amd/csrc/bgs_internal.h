@@ -18,6 +18,7 @@ enum {
     BGS_BOUNCE_MAX_CELLS = 64,   // height * width <= 64: one bit per cell in a uint64
     BGS_BOUNCE_MAX_VALUE = 15,   // 4 value bit-planes
     BGS_BOUNCE_MAX_PASSES = 8,   // passes of the multi-pass Bounce rollout
+    BGS_BOUNCE_MAX_PIECES = 16,  // piece-list rollout kernel (K3p): pieces on the configured start position
     // the generic (reference-layout) kernels take over beyond the packed limits
     BGS_GENERIC_CONNECT_MAX_DIM = 64,      // height, width <= 64 (the oracle's own limit: nothing larger can be checked)
     BGS_GENERIC_BOUNCE_MAX_CELLS = 1024,   // height * width <= 1024, piece values <= 127 (int8)
@@ -39,6 +40,13 @@ struct BounceGeom {
     uint64_t not_collast;    // cells with x < w-1
     uint64_t init[4];        // value bit-planes of the configured start position
     uint32_t init_status;    // 0, or the terminal code of a start position without legal moves
+    // The start position as a piece list (Bounce never captures and never changes a piece's value, so a board IS the
+    // cells of its pieces): piece k has value piece_value[k] and starts on cell piece_cell[k]; pieces are numbered by
+    // ascending (value, cell).  piece_count = 0: more than BGS_BOUNCE_MAX_PIECES pieces (the piece-list rollout is off).
+    uint32_t piece_count;
+    uint8_t piece_value[16];
+    uint8_t piece_cell[16];
+    uint64_t piece_idx[4];   // index planes of the start position: bit c of plane p = bit p of the index of the piece on cell c
 };
 
 // Launch tuning of the fused rollouts.  These live here (a header the build id hashes) and not in bgs_capi.hip because
@@ -47,6 +55,8 @@ constexpr int kRolloutOpeningBlocks = 3;    // K2o: 4-ply blocks played in lock 
 constexpr int kGamesPerLaneOneWord = 8;     // one-word Connect boards: games per lane a launch aims for (512 per wave at 2^20)
 constexpr int kGamesPerLane = 4;            // every other rollout
 constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBoards (0 = every wave drains alone)
+constexpr int kBounceTailCap = 384;         // K3p, automatic plan: games longer than this are finished by the tail pass
+constexpr int kBounceBoardsPerWave = 512;   // K3p: boards a wave plays in a launch (fewer, longer-lived waves drain less)
 
 struct bgs_batch {
     int game;
@@ -64,10 +74,13 @@ struct bgs_batch {
     int rollout_wps;         // waves per SIMD the fused rollout is sized for
     int bounce_group;        // lanes per board of a single-launch Bounce rollout: 8 (default) or 1 (BGS_BOUNCE_GROUP)
     int bounce_flat;         // 1: one-lane-per-board Bounce rollouts use the flattened search (BGS_BOUNCE_FLAT=0: nested loops)
+    int bounce_pieces;       // 1: from-initial flat rollouts run on the piece list (K3p; BGS_BOUNCE_PIECES=0: K3f)
+    int bounce_block;        // K3p: threads per workgroup, 256 / 512 / 1024 (BGS_BOUNCE_BLOCK): the waves of a workgroup share their drain
     int bounce_flat_wps;     // waves per SIMD of a flat Bounce rollout launch (BGS_BOUNCE_FLAT_WPS)
     int bounce_flat_waves;   // > 0: that many waves per launch instead (BGS_BOUNCE_FLAT_WAVES)
     int bounce_park;         // flat rollout: a draining wave parks its boards for its workgroup at this many or fewer (0..32; BGS_BOUNCE_PARK)
     int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (BGS_BOUNCE_CHUNK)
+    int bounce_plan_auto;    // 1: the library chooses between one launch and bulk + tail passes (BGS_BOUNCE_PLAN unset or "auto")
     int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board
     uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];
     int bounce_pass_group[BGS_BOUNCE_MAX_PASSES];

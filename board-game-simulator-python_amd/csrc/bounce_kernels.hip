@@ -350,6 +350,10 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
                  unsigned long long* __restrict__ steps, uint32_t games_per_wave, const uint32_t* __restrict__ worklist,
                  const uint32_t* __restrict__ work_count) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
+    // A work list is the tail of a multi-pass rollout: a handful of very long games, each a chain of thousands of
+    // dependent plies, and the launch ends when the longest is through.  Their waves go first in the SIMD's issue
+    // arbitration: next to 16 batches' bulk waves a ply of theirs otherwise takes 2-3x as long as on an idle chip.
+    if (worklist) __builtin_amdgcn_s_setprio(3);
     const int64_t total = worklist ? (int64_t)*work_count : n;
     const int64_t begin = (int64_t)wave * games_per_wave;
     const int64_t end = begin + games_per_wave < total ? begin + games_per_wave : total;
@@ -767,6 +771,452 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
     add_steps(steps, stepped);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3p: the fused rollout on the PIECE LIST (from the start position).  Bounce never captures and never changes a
+// piece's value, so a board is the cells of its P pieces, and every board of a batch has the same pieces: piece k's
+// value is wave-uniform.  The landing cells of a segment depend only on the cell it starts from and on the board -- not
+// on which source's walk got there -- so a ply's move search splits into
+//   A  every lane runs the segment of EVERY piece of its board, piece by piece: the trip count of the step loop is the
+//      piece's value, the same in all 64 lanes -- no divergence at all (K3f: a lane expands the cells of its own queue,
+//      ~8.75 a ply with ~5.9 distinct, a wave pays the maximum over its lanes, and a segment of 1-3 steps runs as 3);
+//      the P landing masks go to the lane's LDS column;
+//   B  the closure per source -- K3f's loop "take a pending cell, add its landing cells" -- with the segment replaced by
+//      a look-up: which piece stands on the cell (index planes), then its mask from LDS (~30 instructions a cell
+//      instead of ~110).
+// The per-source target masks are not kept: a source's count is enough to sample, and the sampled source's closure is
+// run once more to find the target.  Everything around the search (work queue, parked boards, refill) is K3f's.
+// ------------------------------------------------------------------------------------------------
+template <int PMAX>
+struct PieceBoard {
+    uint32_t pos[PMAX / 4];   // piece k stands on cell (pos[k >> 2] >> 8 (k & 3)) & 255
+    uint64_t idx[4];          // plane p: bit c = bit p of the index of the piece on cell c
+    uint64_t occ;
+};
+
+template <int PMAX>
+__device__ __forceinline__ void pieces_from_start(const BounceGeom& g, PieceBoard<PMAX>& b) {
+#pragma unroll
+    for (int j = 0; j < PMAX / 4; ++j)
+        b.pos[j] = (uint32_t)g.piece_cell[4 * j] | ((uint32_t)g.piece_cell[4 * j + 1] << 8) |
+                   ((uint32_t)g.piece_cell[4 * j + 2] << 16) | ((uint32_t)g.piece_cell[4 * j + 3] << 24);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) b.idx[p] = g.piece_idx[p];
+    b.occ = g.init[0] | g.init[1] | g.init[2] | g.init[3];
+}
+
+// index planes and occupancy from the positions (adopted boards)
+template <int PMAX>
+__device__ __forceinline__ void pieces_rebuild(const BounceGeom& g, PieceBoard<PMAX>& b) {
+    b.idx[0] = b.idx[1] = b.idx[2] = b.idx[3] = 0;
+    b.occ = 0;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        if (k < (int)g.piece_count) {
+            const uint64_t bit = 1ull << ((b.pos[k >> 2] >> (8 * (k & 3))) & 63u);
+            b.occ |= bit;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if ((k >> p) & 1) b.idx[p] |= bit;
+        }
+}
+
+// value planes (the batch's memory format) from the positions
+template <int PMAX>
+__device__ __forceinline__ Board pieces_to_planes(const BounceGeom& g, const PieceBoard<PMAX>& b) {
+    Board out;
+    out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        if (k < (int)g.piece_count) {
+            const uint64_t bit = 1ull << ((b.pos[k >> 2] >> (8 * (k & 3))) & 63u);
+            const uint32_t v = g.piece_value[k];  // (wave-uniform)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if ((v >> p) & 1u) out.v[p] |= bit;
+        }
+    return out;
+}
+
+template <int PMAX>
+__device__ __forceinline__ uint32_t piece_on(const PieceBoard<PMAX>& b, int c) {
+    return (uint32_t)((b.idx[0] >> c) & 1ull) | ((uint32_t)((b.idx[1] >> c) & 1ull) << 1) |
+           ((uint32_t)((b.idx[2] >> c) & 1ull) << 2) | ((uint32_t)((b.idx[3] >> c) & 1ull) << 3);
+}
+
+template <int PMAX>
+__device__ __forceinline__ void move_piece_on(PieceBoard<PMAX>& b, int src_cell, int dst_cell) {
+    const uint32_t k = piece_on(b, src_cell);
+    const uint64_t keep = ~(1ull << src_cell), put = 1ull << dst_cell;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) b.idx[p] = (b.idx[p] & keep) | (((k >> p) & 1u) ? put : 0ull);
+    b.occ = (b.occ & keep) | put;
+    const uint32_t sh = 8u * (k & 3u);
+#pragma unroll
+    for (int j = 0; j < PMAX / 4; ++j)
+        b.pos[j] = (k >> 2) == (uint32_t)j ? (b.pos[j] & ~(255u << sh)) | ((uint32_t)dst_cell << sh) : b.pos[j];
+}
+
+// phase A: the landing cells of every piece's segment for `player`, into the lane's LDS column (dwords 3k, 3k + 1 of a
+// [dword][STRIDE lanes] tile; dword 3k + 2: the pieces standing on them)
+template <int PMAX, int STRIDE>
+__device__ __forceinline__ void land_all(const BounceGeom& g, const PieceBoard<PMAX>& b, uint32_t player, uint32_t* lands) {
+    const uint64_t empty_interior = ~b.occ & g.interior;
+    const uint32_t up = player ? 0u : (uint32_t)g.w, down = player ? (uint32_t)g.w : 0u;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        if (k < (int)g.piece_count) {
+            const uint32_t c = (b.pos[k >> 2] >> (8 * (k & 3))) & 63u;
+            const uint32_t v = g.piece_value[k];  // wave-uniform: the step loop below does not diverge
+            uint64_t a0 = 1ull << c, al = 0, ar = 0, land = 0;
+            for (uint32_t s = 1; s <= v; ++s) {
+                const uint64_t via_left = a0 | al, via_right = a0 | ar;  // who may go on left / right (no reversal)
+                const uint64_t nf = ((via_left | ar) << up) >> down;
+                const uint64_t nl = (via_left & g.not_col0) >> 1;
+                const uint64_t nr = (via_right & g.not_collast) << 1;
+                if (s < v) {
+                    a0 = nf & empty_interior;
+                    al = nl & empty_interior;
+                    ar = nr & empty_interior;
+                } else {
+                    land = nf | nl | nr;
+                }
+            }
+            lands[(3 * k) * STRIDE] = (uint32_t)land;
+            lands[(3 * k + 1) * STRIDE] = (uint32_t)(land >> 32);
+            // ... and the pieces it lands ON (a walk that lands on a piece goes on with that piece's segment): bit j =
+            // piece j stands on a landing cell.  The closure of a source is then a search over 16-bit piece sets.
+            uint32_t hits = 0;
+#pragma unroll
+            for (int j = 0; j < PMAX; ++j)
+                if (j < (int)g.piece_count) hits |= (uint32_t)((land >> ((b.pos[j >> 2] >> (8 * (j & 3))) & 63u)) & 1ull) << j;
+            lands[(3 * k + 2) * STRIDE] = hits;
+        }
+}
+
+// what a lane knows about its board's action list: per column of the active row the number of targets (8 bits each) and
+// the PIECES whose landing cells make them up (the source's closure as a 16-bit set of piece indices, two columns a word)
+struct PieceMoves {
+    uint64_t counts;
+    uint32_t reach[kMaxTrackedColumns / 2];
+    uint32_t n;
+    uint32_t row_base;
+#ifdef BGS_BOUNCE_STATS
+    uint32_t loops;
+#endif
+};
+
+// phase B: counts and closures of `player` for the lanes with `want` set (phase A must have run for this board and
+// player); the other lanes idle through the loops.  The lanes walk their sources in lock step -- trip s of the outer
+// loop is every lane's s-th source -- so that booking a source and opening the next one (25 + 15 instructions) run once
+// per source, not once per closure cell as in one flat loop over (source, cell) pairs.
+template <int PMAX, int STRIDE>
+__device__ __forceinline__ void count_from_lands(const BounceGeom& g, const PieceBoard<PMAX>& b, uint32_t player, bool want,
+                                                 const uint32_t* lands, PieceMoves& m) {
+    const uint64_t occ = b.occ;
+    const uint64_t landing = (~occ & g.interior) | (player ? g.goal_bottom : g.goal_top);
+    uint64_t rem = want ? movable(g, occ, player) : 0ull;   // sources still to search
+    const int first = rem ? __ffsll((unsigned long long)rem) - 1 : 0;
+    m.row_base = (uint32_t)((int)(((uint32_t)first * g.inv_w) >> 16) * g.w);
+    m.counts = 0;
+    m.n = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxTrackedColumns / 2; ++j) m.reach[j] = 0;
+    while (__builtin_amdgcn_ballot_w64(rem != 0)) {
+        const bool open = rem != 0;
+        const int cell = open ? __ffsll((unsigned long long)rem) - 1 : 0;
+        rem &= rem - 1;
+        const uint32_t x = ((uint32_t)cell - m.row_base) & 7u;
+        uint32_t pending = open ? 1u << piece_on(b, cell) : 0u, members = 0;   // sets of piece indices
+        uint64_t targets = 0;
+        while (__builtin_amdgcn_ballot_w64(pending != 0)) {
+#ifdef BGS_BOUNCE_STATS
+            ++m.loops;
+#endif
+            if (pending) {  // one piece of the closure: its landing cells, and the pieces standing on them
+                const uint32_t k = (uint32_t)__ffs((int)pending) - 1u;
+                pending &= pending - 1u;
+                members |= 1u << k;
+                const uint32_t* entry = lands + (3u * k) * STRIDE;
+                const uint64_t land = ((uint64_t)entry[STRIDE] << 32) | entry[0];
+                targets |= land;
+                pending |= entry[2 * STRIDE] & ~members;
+            }
+        }
+        if (open) {  // book the source
+            const uint32_t cnt = (uint32_t)__popcll(targets & landing);
+            m.counts |= (uint64_t)cnt << (8u * x);
+            m.n += cnt;
+            const uint32_t field = members << (16u * (x & 1u));
+#pragma unroll
+            for (int j = 0; j < kMaxTrackedColumns / 2; ++j) m.reach[j] |= (x >> 1) == (uint32_t)j ? field : 0u;
+        }
+    }
+}
+
+// the idx-th action of the canonical list: the column from the packed counts, its targets from the closure's landing masks
+template <int PMAX, int STRIDE>
+__device__ __forceinline__ void pick_from_lands(const BounceGeom& g, const PieceBoard<PMAX>& b, uint32_t player,
+                                                const PieceMoves& m, const uint32_t* lands, uint32_t idx, int& src_cell,
+                                                int& dst_cell) {
+    uint32_t col = 0;
+    bool found = false;
+#pragma unroll
+    for (int x = 0; x < kMaxTrackedColumns; ++x) {
+        const uint32_t cnt = (uint32_t)(m.counts >> (8 * x)) & 255u;
+        const bool here = !found && idx < cnt;
+        col = here ? (uint32_t)x : col;
+        idx = (found || here) ? idx : idx - cnt;
+        found = found || here;
+    }
+    src_cell = (int)((m.row_base + col) & 63u);
+    uint32_t word = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxTrackedColumns / 2; ++j) word = (col >> 1) == (uint32_t)j ? m.reach[j] : word;
+    const uint32_t members = (word >> (16u * (col & 1u))) & 0xFFFFu;
+    uint64_t targets = 0;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        if (k < (int)g.piece_count) {
+            const uint64_t land = ((uint64_t)lands[(3 * k + 1) * STRIDE] << 32) | lands[(3 * k) * STRIDE];
+            targets |= ((members >> k) & 1u) ? land : 0ull;
+        }
+    const uint64_t landing = (~b.occ & g.interior) | (player ? g.goal_bottom : g.goal_top);
+    dst_cell = (int)select_bit64(targets & landing, idx);
+}
+
+template <int PMAX, int BLOCK>
+struct ParkedPieces {
+    static constexpr uint32_t WAVES = BLOCK / BGS_WAVE, CAP = 32;
+    uint32_t pos[PMAX / 4][WAVES][CAP];
+    uint32_t game[WAVES][CAP];
+    uint32_t plies[WAVES][CAP];
+    uint32_t count[WAVES];       // entries of the segment; published once, after the entries
+    uint32_t head[WAVES];        // entries claimed so far (may run past count)
+    uint32_t active;             // waves still in their loop
+};
+
+// BLOCK threads per workgroup (256, 512 or 1024): the waves of a workgroup share their drain through LDS, so a larger
+// workgroup ends with fewer half-empty waves (one per workgroup carries the workgroup's longest games to their end)
+template <int PMAX, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+                        uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
+                        unsigned long long* __restrict__ steps, uint32_t chunk, uint32_t* __restrict__ queue, uint32_t park_at) {
+    extern __shared__ uint32_t land_tile[];               // [3 * PMAX dwords][BLOCK lanes]
+    __shared__ ParkedPieces<PMAX, BLOCK> parked;
+    uint32_t* const lands = land_tile + threadIdx.x;      // this lane's dword column
+    constexpr uint32_t WAVES = ParkedPieces<PMAX, BLOCK>::WAVES;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x < WAVES) {
+        parked.count[threadIdx.x] = 0u;
+        parked.head[threadIdx.x] = 0u;
+    }
+    if (threadIdx.x == 0) parked.active = WAVES;
+    __syncthreads();
+    // (the drain -- parked boards, `active`, the last wave sweeping up -- is k_bounce_rollout_flat's, see there)
+    bool last = false;
+    auto bump = [&](uint32_t* word, uint32_t by) {
+        uint32_t old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(word, by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (uint32_t)__builtin_amdgcn_readfirstlane(old);
+    };
+    auto leave = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        const uint32_t before = bump(&parked.active, ~0u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        return before;
+    };
+    const uint32_t total = (uint32_t)n;
+    uint32_t begin = 0, avail = 0, taken = 0;   // the wave's current chunk: boards begin + [taken, avail)
+    bool dry = false;                             // the queue has nothing left
+
+    PieceBoard<PMAX> b;
+    pieces_from_start(g, b);   // (every lane always holds valid positions: phase A runs on all 64 lanes)
+    PieceMoves mv;
+    mv.counts = 0;
+    mv.n = 0;
+    mv.row_base = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxTrackedColumns / 2; ++j) mv.reach[j] = 0;
+    uint32_t st = 0, plies = 0, first_ply = 0, game = 0, stepped = 0;
+    bool has = false;      // this lane holds a board
+    bool search = false;   // ... whose side to move has no action list yet
+    Philox4 blk;
+    blk.v[0] = blk.v[1] = blk.v[2] = blk.v[3] = 0;
+    bool have_block = false;
+
+#ifdef BGS_BOUNCE_STATS
+    uint32_t stat_iters = 0, stat_search = 0, stat_drain_iters = 0;
+    mv.loops = 0;
+#endif
+    for (;;) {
+#ifdef BGS_BOUNCE_STATS
+        ++stat_iters;
+#endif
+        // ---- refill: free lanes take the next boards of the wave's chunk; an empty chunk is replaced from the queue
+        const uint64_t need = __builtin_amdgcn_ballot_w64(!has);
+        if (need && taken >= avail && !dry) {
+            uint32_t next = 0;
+            if (lane == 0u) next = atomicAdd(queue, chunk);
+            begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+            taken = 0;
+            avail = begin < total ? (total - begin < chunk ? total - begin : chunk) : 0u;
+            dry = avail == 0u;
+        }
+        if (need && taken < avail) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (!has && taken + rank < avail) {
+                game = begin + taken + rank;
+                pieces_from_start(g, b);
+                st = g.init_status;
+                plies = 0;
+                first_ply = 0;
+                has = true;
+                have_block = false;
+                search = st == BGS_ST_RUNNING;
+            }
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            taken = avail - taken < wanted ? avail : taken + wanted;
+        }
+        const bool draining = dry && taken >= avail;  // (wave-uniform) nothing left to draw
+#ifdef BGS_BOUNCE_STATS
+        if (draining) ++stat_drain_iters;
+#endif
+#ifdef BGS_DRAIN_PRIO
+        if (draining) __builtin_amdgcn_s_setprio(BGS_DRAIN_PRIO);
+#endif
+        if (draining && need) {
+            // ---- idle lanes adopt parked boards.  count[] and head[] are adjacent: lanes 0 .. 2 WAVES - 1 fetch them in one access
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            uint32_t word = 0;
+            if (lane < 2u * WAVES) word = __hip_atomic_load(&parked.count[0] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            uint32_t assigned = 0;
+            bool adopted_one = false;
+            for (uint32_t sgm = 0; sgm < WAVES; ++sgm) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(word, sgm);
+                const uint32_t h = (uint32_t)__builtin_amdgcn_readlane(word, WAVES + sgm);
+                if (assigned < wanted && h < c) {
+                    const uint32_t old = bump(&parked.head[sgm], wanted - assigned);
+                    const uint32_t got = old < c ? (c - old < wanted - assigned ? c - old : wanted - assigned) : 0u;
+                    if (!has && rank >= assigned && rank < assigned + got) {
+                        const uint32_t e = old + (rank - assigned);
+#pragma unroll
+                        for (int j = 0; j < PMAX / 4; ++j) b.pos[j] = parked.pos[j][sgm][e];
+                        game = parked.game[sgm][e];
+                        plies = parked.plies[sgm][e];
+                        first_ply = plies;  // (the wave that parked it has counted the plies up to here)
+                        st = BGS_ST_RUNNING;
+                        has = true;
+                        have_block = false;
+                        search = true;
+                        adopted_one = true;
+                    }
+                    assigned += got;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(adopted_one)) {
+                PieceBoard<PMAX> fresh = b;
+                pieces_rebuild(g, fresh);
+                if (adopted_one) b = fresh;
+            }
+        }
+
+        // ---- the action counts of the boards that need them (new boards, boards that have just moved); a board whose
+        // side to move has no action is settled here, also at the ply cap (the transition that blocked it counts)
+        if (__builtin_amdgcn_ballot_w64(search)) {
+#ifdef BGS_BOUNCE_STATS
+            ++stat_search;
+#endif
+            land_all<PMAX, BLOCK>(g, b, plies & 1u, lands);
+            count_from_lands<PMAX, BLOCK>(g, b, plies & 1u, search, lands, mv);
+            const bool blocked = search && mv.n == 0u;
+            if (__builtin_amdgcn_ballot_w64(blocked)) {
+                // the other side wins if IT could move, else a draw (Appendix B rule 7)
+                PieceMoves other;
+                land_all<PMAX, BLOCK>(g, b, 1u - (plies & 1u), lands);
+                count_from_lands<PMAX, BLOCK>(g, b, 1u - (plies & 1u), blocked, lands, other);
+                if (blocked) st = other.n ? (1u - (plies & 1u)) + 1u : BGS_ST_DRAW;
+                // (a blocked board stops here, and the others' landing masks are recomputed: phase A of the side to
+                // move must be in LDS when the move is picked)
+                land_all<PMAX, BLOCK>(g, b, plies & 1u, lands);
+            }
+            search = false;
+        }
+        const bool run = has && st == BGS_ST_RUNNING && plies < max_plies;
+
+        // ---- boards that stopped go to memory and free their lane (from the start position: every board is written)
+        if (has && !run) {
+            const int64_t i = game;
+            store_board(planes, n, i, pieces_to_planes(g, b));
+            status[i] = (uint8_t)st;
+            plies_buf[i] = (uint16_t)plies;
+            reward[i] = reward_pair(st);
+            stepped += plies - first_ply;
+            has = false;
+        }
+        if (!__builtin_amdgcn_ballot_w64(has)) {
+            if (!draining) continue;    // (a chunk of boards that were not running: draw the next one)
+            if (last) break;
+            if (leave() > 1u) break;    // others are still running: whatever gets parked later is theirs
+            last = true;                // everybody else has left: sweep up what they parked
+            continue;
+        }
+        if (draining && !last) {
+            const uint64_t still = __builtin_amdgcn_ballot_w64(has);  // (every board still held is running here)
+            const uint32_t left = (uint32_t)__popcll(still);
+            if (left <= park_at) {
+                const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(still >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)still, 0u));
+                if (has) {
+#pragma unroll
+                    for (int j = 0; j < PMAX / 4; ++j) parked.pos[j][w][e] = b.pos[j];
+                    parked.game[w][e] = game;
+                    parked.plies[w][e] = plies;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_store(&parked.count[w], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (leave() > 1u) {  // parked; somebody is still there to adopt them
+                    if (has) stepped += plies - first_ply;
+                    break;
+                }
+                // nobody is: take back what has not been adopted (an adopter that has left has finished its boards)
+                const uint32_t adopted = bump(&parked.head[w], left);
+                if (has && e < adopted) {
+                    stepped += plies - first_ply;
+                    has = false;
+                }
+                last = true;
+            }
+        }
+
+        // ---- one ply on every running board
+        if (run) {
+            if (!have_block || (plies & 3u) == 0u) {
+                blk = philox4x32_10(seed, first_game + (uint64_t)game, plies >> 2);
+                have_block = true;
+            }
+            const uint32_t mover = plies & 1u;
+            int s, t;
+            pick_from_lands<PMAX, BLOCK>(g, b, mover, mv, lands, sample_index(philox_word(blk, plies), mv.n), s, t);
+            move_piece_on(b, s, t);
+            ++plies;
+            if ((1ull << t) & (g.goal_top | g.goal_bottom)) st = mover + 1u;  // (stored and freed next iteration)
+            else search = true;
+        }
+    }
+#ifdef BGS_BOUNCE_STATS
+    if (lane == 0) {  // words 1..4 of shard 0's cache line are free
+        atomicAdd(steps + 1, (unsigned long long)stat_iters);
+        atomicAdd(steps + 2, (unsigned long long)stat_search);
+        atomicAdd(steps + 3, (unsigned long long)stat_drain_iters);
+        atomicAdd(steps + 4, (unsigned long long)mv.loops);
+    }
+#endif
+    add_steps(steps, stepped);
+}
+
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_step_actions(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
                       uint16_t* __restrict__ plies_buf, uint16_t* __restrict__ reward, int64_t n,
@@ -969,6 +1419,47 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
                            b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
                            seed, b->first_game, cap, b->d_steps, chunk, worklist, work_count, queue, (uint32_t)b->bounce_park);
     };
+    auto launch_pieces = [&](auto pmax_tag, auto block_tag) {
+        constexpr int PMAX = decltype(pmax_tag)::value;
+        constexpr int BLOCK = decltype(block_tag)::value;
+        const size_t tile = (size_t)3 * PMAX * BLOCK * sizeof(uint32_t);
+        const uint32_t chunk = (uint32_t)b->bounce_flat_chunk;
+        // Every ply costs a wave the same whatever the number of its lanes that still hold a game, so what counts is how
+        // full the waves stay: few, long-lived waves (kBounceBoardsPerWave boards each, drawn from the queue) spend most
+        // of their life refilling and little of it draining.  Measured at 2^18 boards, 16 batches in flight, tail pass
+        // on: 2048 waves 6.9, 1024 waves 7.5, 512 waves 7.9 x 10^9 env-steps/s (one launch at a time: 6.3 / 6.8 / 8.1 ms).
+        int64_t flat_waves = (int64_t)b->num_cus * 4 * b->bounce_flat_wps;
+        if (b->bounce_flat_waves > 0) flat_waves = b->bounce_flat_waves;
+        else if (b->n / kBounceBoardsPerWave < flat_waves) flat_waves = b->n / kBounceBoardsPerWave > 256 ? b->n / kBounceBoardsPerWave : 256;
+        const int64_t most = (b->n + 63) / 64;    // (never more waves than 64-board loads)
+        if (flat_waves > most) flat_waves = most;
+        constexpr int per_block = BLOCK / BGS_WAVE;
+        if (tile > 48 * 1024) {  // beyond the default dynamic-LDS limit (gfx950 has 160 KB per CU)
+            static bool raised = false;  // (per instantiation; the attribute belongs to the function, not the launch)
+            if (!raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bounce_rollout_pieces<PMAX, BLOCK>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL((k_bounce_rollout_pieces<PMAX, BLOCK>), dim3((unsigned)((flat_waves + per_block - 1) / per_block)),
+                           dim3(BLOCK), tile, b->stream, b->bg, b->d_planes, b->d_status, b->d_plies,
+                           reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps, chunk, queue,
+                           (uint32_t)b->bounce_park);
+    };
+    auto with_block = [&](auto pmax_tag) {
+        if (b->bounce_block >= 1024) launch_pieces(pmax_tag, std::integral_constant<int, 1024>{});
+        else if (b->bounce_block >= 512) launch_pieces(pmax_tag, std::integral_constant<int, 512>{});
+        else launch_pieces(pmax_tag, std::integral_constant<int, 256>{});
+    };
+    // K3p: from the start position, no work list, at most 16 pieces
+    if (group == 1 && b->bounce_flat && b->bounce_pieces && from_initial && !worklist && b->bg.piece_count >= 1 &&
+        b->n < (int64_t)0xFFFFFFFFu) {
+        if (b->bg.piece_count <= 8) with_block(std::integral_constant<int, 8>{});
+        else if (b->bg.piece_count <= 12) with_block(std::integral_constant<int, 12>{});
+        else with_block(std::integral_constant<int, 16>{});
+        return;
+    }
     auto with_group = [&](auto initial_tag) {
         if (group == 1 && b->bounce_flat) launch_flat(initial_tag);   // one lane per board, flattened search
         else if (group == 1) launch(initial_tag, std::integral_constant<int, 1>{});
@@ -997,15 +1488,35 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
         uint32_t* counts = b->d_work_count;
         uint32_t* queues = b->d_work_count + BGS_BOUNCE_MAX_PASSES;
         (void)hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * BGS_BOUNCE_MAX_PASSES, b->stream);
-        if (b->bounce_passes <= 1) {  // single launch (BGS_BOUNCE_PLAN=single, or a plan with one entry)
+        // The automatic plan.  Random Bounce games are short (mean 28 plies, 1 in 10^4 beyond 256) -- except the few per
+        // 2^18 that never end and run into max_plies.  Such a game is a chain of thousands of dependent plies; inside
+        // the bulk launch it would keep a whole wave of the one-lane-per-board kernel alive (every ply at the cost of
+        // 64 boards), so the bulk pass stops at kBounceTailCap plies and the stragglers -- compacted into a work list on
+        // the device -- are finished 8 lanes to a board, the kernel with the shortest ply, at raised wave priority.
+        int passes = b->bounce_passes;
+        uint32_t pass_cap_of[BGS_BOUNCE_MAX_PASSES];
+        int pass_group_of[BGS_BOUNCE_MAX_PASSES];
+        for (int i = 0; i < passes; ++i) {
+            pass_cap_of[i] = b->bounce_pass_cap[i];
+            pass_group_of[i] = b->bounce_pass_group[i];
+        }
+        if (b->bounce_plan_auto && b->bounce_group == 1 && b->bounce_flat && b->bounce_pieces && from_initial &&
+            b->bg.piece_count >= 1 && cap > 2u * kBounceTailCap) {
+            passes = 2;
+            pass_cap_of[0] = kBounceTailCap;
+            pass_group_of[0] = 1;
+            pass_cap_of[1] = cap;
+            pass_group_of[1] = 8;
+        }
+        if (passes <= 1) {  // single launch (BGS_BOUNCE_PLAN=single, or a plan with one entry)
             launch_rollout(b, seed, cap, from_initial, b->bounce_group, b->bounce_group == 1 ? b->rollout_wps : 8, nullptr, nullptr,
                            queues);
             return;
         }
-        for (int pass = 0; pass < b->bounce_passes; ++pass) {
-            const bool last = pass + 1 == b->bounce_passes;
-            const uint32_t pass_cap = (last || b->bounce_pass_cap[pass] > cap) ? cap : b->bounce_pass_cap[pass];
-            const int group = b->bounce_pass_group[pass];
+        for (int pass = 0; pass < passes; ++pass) {
+            const bool last = pass + 1 == passes;
+            const uint32_t pass_cap = (last || pass_cap_of[pass] > cap) ? cap : pass_cap_of[pass];
+            const int group = pass_group_of[pass];
             if (pass == 0) {
                 launch_rollout(b, seed, pass_cap, from_initial, group, group == 1 ? b->rollout_wps : 8, nullptr, nullptr, queues);
             } else {

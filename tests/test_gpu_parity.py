@@ -281,14 +281,15 @@ def test_connect_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("mode", ["1", "8", "1:nested", "passes"])
+@pytest.mark.parametrize("mode", ["1", "1:flat", "8", "1:nested", "passes"])
 def test_bounce_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
-    """Every fused Bounce rollout kernel on the same mid-size batch: one lane per board with the flattened search and
-    the work queue (default for large batches), 8 lanes per board (default for small ones), the nested-loop kernel and
-    the multi-pass plan (flat passes, then a lane-group pass over the compacted work list)."""
+    """Every fused Bounce rollout kernel on the same mid-size batch: one lane per board on the piece list (K3p, default for
+    large batches from the start position) or with the flattened cell search (K3f: boards loaded from memory), both with
+    the work queue; 8 lanes per board (default for small batches), the nested-loop kernel and the multi-pass plan (flat
+    passes, then a lane-group pass over the compacted work list)."""
     import os
 
-    env = {"1": {"BGS_BOUNCE_GROUP": "1"}, "8": {"BGS_BOUNCE_GROUP": "8"},
+    env = {"1": {"BGS_BOUNCE_GROUP": "1"}, "1:flat": {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PIECES": "0"}, "8": {"BGS_BOUNCE_GROUP": "8"},
            "1:nested": {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_FLAT": "0"},
            "passes": {"BGS_BOUNCE_PLAN": "16:1,64:1,0:8", "BGS_BOUNCE_CHUNK": "8"}}[mode]
     old = {k: os.environ.get(k) for k in env}
@@ -324,16 +325,17 @@ def test_bounce_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("pieces", ["1", "0"])
 @pytest.mark.parametrize("park,waves,chunk", [("0", "0", "32"), ("32", "0", "32"), ("32", "4", "7"), ("1", "8", "64"),
                                               ("32", "64", "1"), ("16", "3", "32")])
-def test_bounce_flat_rollout_shared_drain_protocol(batch_mod, park, waves, chunk):
+def test_bounce_flat_rollout_shared_drain_protocol(batch_mod, park, waves, chunk, pieces):
     """The flat Bounce kernel's drain: waves that run out of boards park their last ones in LDS for the waves of their
     workgroup that still run, and the last wave standing sweeps up.  Batch sizes around the wave / workgroup / chunk
     boundaries, few waves with many boards each, many waves with nothing to do, parking thresholds 0 (off), 1, 16, 32:
     every board must be finished exactly once and match the oracle, the step count included."""
     import os
 
-    env = {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PARK": park, "BGS_BOUNCE_CHUNK": chunk}
+    env = {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PARK": park, "BGS_BOUNCE_CHUNK": chunk, "BGS_BOUNCE_PIECES": pieces}
     if waves != "0":
         env["BGS_BOUNCE_FLAT_WAVES"] = waves
     old = {k: os.environ.get(k) for k in env}
@@ -455,6 +457,47 @@ def test_bounce_rollout(batch_mod, name, from_initial):
     total = orc.rollout(SEED, first_game=999, max_plies=4096)
     assert_same(dev, orc)
     assert dev.steps == total == int(orc.plies.sum())
+
+
+PIECE_LIST_GRIDS = dict(
+    BOUNCE_GRIDS,
+    fourteen=np.array([[0] * 8, [1, 2, 3, 4, 3, 2, 1, 0], [0] * 8, [0, 2, 0, 0, 5, 0, 0, 1], [0] * 8, [1, 2, 3, 1, 0, 0, 0, 1], [0] * 8],
+                      dtype=np.int8),
+    sixteen=np.array([[0] * 8, [1, 2, 3, 1, 2, 3, 1, 2], [0] * 8, [0] * 8, [0] * 8, [2, 1, 3, 2, 1, 3, 2, 1], [0] * 8], dtype=np.int8),
+    nine=np.array([[0] * 5, [1, 1, 2, 0, 3], [0, 0, 6, 0, 0], [0] * 5, [3, 0, 2, 1, 1], [0] * 5], dtype=np.int8),
+)
+
+
+@pytest.mark.parametrize("name", list(PIECE_LIST_GRIDS))
+def test_bounce_piece_list_rollout(batch_mod, name):
+    """K3p (one lane per board, the board as the cells of its pieces, every piece's segment run with a wave-uniform trip
+    count) against the oracle on grids of 2 to 16 pieces -- the 8-, 12- and 16-piece instantiations -- values up to 15,
+    a blocked start position, and grids outside its reach (40 pieces, 12 columns), which fall through to the kernels
+    they always had."""
+    import os
+
+    grid = PIECE_LIST_GRIDS[name]
+    old = os.environ.get("BGS_BOUNCE_GROUP")
+    os.environ["BGS_BOUNCE_GROUP"] = "1"
+    try:
+        for n, cap in ((6000, 4096), (333, 60)):
+            dev = batch_mod.BounceBatch(grid, n)
+            orc = oracle.BounceOracle(grid, n)
+            dev.set_first_game(5 << 32)
+            dev.rollout(SEED + 3, max_plies=cap, from_initial=True)
+            total = orc.rollout(SEED + 3, first_game=5 << 32, max_plies=cap)
+            assert_same(dev, orc, f"{name} n={n} cap={cap}")
+            assert dev.steps == total == int(orc.plies.sum())
+            # ... and on from where the cap stopped them (boards loaded from memory: K3f)
+            dev.rollout(SEED + 3, max_plies=4096)
+            orc.rollout(SEED + 3, first_game=5 << 32, max_plies=4096)
+            assert_same(dev, orc, f"{name} n={n} resumed")
+            dev.close()
+    finally:
+        if old is None:
+            del os.environ["BGS_BOUNCE_GROUP"]
+        else:
+            os.environ["BGS_BOUNCE_GROUP"] = old
 
 
 def test_bounce_rollout_max_plies_and_resume(batch_mod):

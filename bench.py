@@ -365,6 +365,50 @@ def other_configs():
     return results
 
 
+def grids_to_host(steps: int = 24):
+    """The same rollouts with the BOARDS handed over instead of the rewards: `state.grid` of every game of every step in
+    a host array int8[2^20, 6, 7] (bit-packed boards over PCIe: 16 B per game, then host expansion)."""
+    import numpy as np
+    import torch
+
+    from simulator.batch import ConnectBatch, GridSink
+    from simulator.pipeline import RolloutExecutor
+
+    n, depth = BATCH_PER_GPU, 3
+    streams = [torch.cuda.Stream(device=0) for _ in range(depth)]
+    batches = []
+    for s in streams:
+        with torch.cuda.stream(s):
+            batches.append(ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=0, use_torch=True))
+    slots = 2 * depth
+    hosts = [np.zeros((n, HEIGHT, WIDTH), dtype=np.int8) for _ in range(slots)]
+    sink = GridSink(batches[0], slots=slots, threads=int(os.environ.get("BGS_GRID_THREADS", "12")))
+    exe = RolloutExecutor(batches, sink=sink, host_arrays=hosts, seed0=SEED + 900)
+    exe.enqueue(slots)
+    exe.drain()
+    for b in batches:
+        b.reset_steps()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    exe.enqueue(steps)
+    exe.drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    env_steps = sum(b.steps for b in batches)
+    # the last step's host grids against a fresh device read of the same boards
+    ok = bool(np.array_equal(exe.last_host_array(), batches[(exe.steps - 1) % depth].grid))
+    wire = 16 * n
+    out = {"value": env_steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "host_array": f"int8[{n}, {HEIGHT}, {WIDTH}] per step", "pcie_bytes_per_step": wire,
+           "pcie_GBps": wire / (dt / steps) / 1e9, "pcie_frac": wire / (dt / steps) / 1e9 / PCIE_PEAK_GBS,
+           "host_grids_equal_device_grids": ok}
+    exe.close()
+    sink.close()
+    for b in batches:
+        b.close()
+    return out
+
+
 def gpu_single_game_latency():
     """BASELINE config 1 on the GPU: one game (N = 1) from the initial state to the end, launch + synchronise per game."""
     from simulator.batch import ConnectBatch
@@ -742,6 +786,7 @@ def main() -> int:
                 out["cpu_baseline"] = cpu_baseline(SEED + last, head)
                 out["cpu_baseline"]["gpu_single_game_latency_us"] = gpu_single_game_latency()
             if not args.no_other_configs:
+                out["grids_to_host"] = grids_to_host()
                 out["other_configs"] = other_configs()
         print(json.dumps(out), flush=True)
 

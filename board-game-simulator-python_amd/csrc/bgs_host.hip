@@ -110,6 +110,108 @@ void expand_range(const uint8_t* packed, int64_t first, int64_t count, int8_t* r
     }
 }
 
+// ---- grids: bit sets over the cells (cell = y * W + x) -> int8[n][H][W] -------------------------------------------
+// The wire format is plane-major over the batch: word j of bit set p of game i at wire[(p * nwc + j) * n + i].  A cell's
+// byte is offset + sum over the sets that contain it of the set's weight: Connect -1 + occupied + player 1's (k_connect_
+// cell_planes), Bounce the four value bit-planes with weights 1, 2, 4, 8 (the boards as the batch stores them).  No game
+// rule: a change of representation, like the copying tensor caster it stands in for (tensor.hpp:69-87).
+struct CellFormat {
+    int cells = 0;        // H * W
+    int nwc = 0;          // 64-cell words per set
+    int sets = 0;         // 2 (Connect) or 4 (Bounce); 0 = the wire IS the int8 grid (generic batches)
+    int offset = 0;
+    int weight[4] = {0, 0, 0, 0};
+};
+
+struct SpreadTable {  // bit b of a byte -> byte b of a uint64 (0 / 1)
+    uint64_t v[256];
+    SpreadTable() {
+        for (int byte = 0; byte < 256; ++byte) {
+            uint64_t w = 0;
+            for (int b = 0; b < 8; ++b) w |= (uint64_t)((byte >> b) & 1) << (8 * b);
+            v[byte] = w;
+        }
+    }
+};
+const SpreadTable g_spread;
+
+__attribute__((target("avx512f,avx512bw"))) void expand_cells_avx512(const uint64_t* wire, int64_t n, const CellFormat& f,
+                                                                      int64_t first, int64_t count, int8_t* out) {
+    const __m512i base = _mm512_set1_epi8((char)f.offset);
+    __m512i weight[4];
+    for (int p = 0; p < f.sets; ++p) weight[p] = _mm512_set1_epi8((char)f.weight[p]);
+    // Boards of up to 256 cells: 64 games at a time are expanded into a block on the stack (64 x cells bytes: whole cache
+    // lines whatever the cell count) and the block goes out with non-temporal 64-byte stores -- the grids are written once
+    // and read later by somebody else, and a 42-byte masked store per game would read every destination line first.
+    alignas(64) int8_t block[64 * 256 + 64];
+    const bool lines = f.cells <= 256 && g_stream_stores && (reinterpret_cast<uintptr_t>(out) & 63u) == 0;
+#define BGS_ONE_GAME(i_)                                                                                              \
+    do {                                                                                                                \
+        int8_t* dst_ = out + (i_)*f.cells;                                                                              \
+        for (int j = 0; j < f.nwc; ++j) {                                                                               \
+            __m512i acc = base;                                                                                         \
+            for (int p = 0; p < f.sets; ++p)                                                                            \
+                acc = _mm512_mask_add_epi8(acc, (__mmask64)wire[((int64_t)p * f.nwc + j) * n + (i_)], acc, weight[p]);  \
+            const int left = f.cells - 64 * j;                                                                          \
+            const __mmask64 keep = left >= 64 ? ~0ull : ((1ull << left) - 1ull);                                        \
+            _mm512_mask_storeu_epi8(dst_ + 64 * j, keep, acc);                                                          \
+        }                                                                                                               \
+    } while (0)
+    const int64_t end = first + count;
+    int64_t i = first;
+    if (lines) {
+        for (; i < end && (i & 63) != 0; ++i) BGS_ONE_GAME(i);   // up to the first whole block
+        for (; i + 64 <= end; i += 64) {
+            for (int64_t g = 0; g < 64; ++g) {
+                int8_t* dst = block + g * f.cells;
+                for (int j = 0; j < f.nwc; ++j) {
+                    __m512i acc = base;
+                    for (int p = 0; p < f.sets; ++p)
+                        acc = _mm512_mask_add_epi8(acc, (__mmask64)wire[((int64_t)p * f.nwc + j) * n + i + g], acc, weight[p]);
+                    _mm512_storeu_si512(dst + 64 * j, acc);  // (the tail of the last word is overwritten by the next game)
+                }
+            }
+            int8_t* to = out + i * f.cells;
+            for (int b = 0; b < f.cells; ++b)
+                _mm512_stream_si512(reinterpret_cast<__m512i*>(to + 64 * b), _mm512_load_si512(block + 64 * b));
+        }
+        _mm_sfence();
+    }
+    for (; i < end; ++i) BGS_ONE_GAME(i);
+#undef BGS_ONE_GAME
+}
+
+void expand_cells_portable(const uint64_t* wire, int64_t n, const CellFormat& f, int64_t first, int64_t count, int8_t* out) {
+    const uint64_t base = 0x0101010101010101ull * (uint8_t)f.offset;
+    for (int64_t i = first; i < first + count; ++i) {
+        int8_t* dst = out + i * f.cells;
+        for (int j = 0; j < f.nwc; ++j) {
+            uint64_t word[4] = {0, 0, 0, 0};
+            for (int p = 0; p < f.sets; ++p) word[p] = wire[((int64_t)p * f.nwc + j) * n + i];
+            const int left = f.cells - 64 * j < 64 ? f.cells - 64 * j : 64;
+            for (int c = 0; c < left; c += 8) {
+                uint64_t sum = 0;  // per byte at most 15 x 4: no carry between bytes
+                for (int p = 0; p < f.sets; ++p) sum += g_spread.v[(word[p] >> c) & 255u] * (uint64_t)f.weight[p];
+                // + offset in every byte, modulo 256 and without carries into the neighbour (offset -1 is 0xFF)
+                constexpr uint64_t low7 = 0x7F7F7F7F7F7F7F7Full;
+                const uint64_t eight = ((sum & low7) + (base & low7)) ^ ((sum ^ base) & ~low7);
+                memcpy(dst + 64 * j + c, &eight, left - c < 8 ? left - c : 8);
+            }
+        }
+    }
+}
+
+const bool g_have_avx512bw = __builtin_cpu_supports("avx512bw") && getenv("BGS_NO_AVX512") == nullptr;
+
+void expand_cells(const void* wire, int64_t n, const CellFormat& f, int64_t first, int64_t count, int8_t* out) {
+    if (f.sets == 0) {  // generic batches keep the reference layout on the device: nothing to expand
+        memcpy(out + first * f.cells, static_cast<const int8_t*>(wire) + first * f.cells, (size_t)count * f.cells);
+        return;
+    }
+    if (g_have_avx512bw) expand_cells_avx512(static_cast<const uint64_t*>(wire), n, f, first, count, out);
+    else expand_cells_portable(static_cast<const uint64_t*>(wire), n, f, first, count, out);
+}
+
 int enter_device(int device) {
     HIP_TRY(hipSetDevice(device));
     return BGS_OK;
@@ -182,9 +284,12 @@ struct bgs_reward_sink {
     std::vector<uint8_t*> mapped;     // [slots] the same buffers as the device sees them: the pack kernel stores its
                                       //         codes straight into host memory (one PCIe write per 16 B, no copy call)
     std::vector<hipEvent_t> landed;   // [slots] recorded behind the copy into pinned[slot]
+    bool grids = false;               // a grid sink: the slots carry boards in the wire format `cells` describes
+    CellFormat cells;
+    size_t slot_bytes = 0;
     struct Job {
         int64_t n_games = 0;
-        int8_t* host_reward = nullptr;
+        int8_t* host_reward = nullptr;  // (a grid sink: int8[n][H][W])
     };
     std::vector<Job> jobs;            // [slots]
     std::mutex mu;
@@ -277,7 +382,14 @@ struct bgs_reward_sink {
             const int expanders = threads > 1 ? threads - 1 : 1;
             const int share = threads > 1 ? t - 1 : 0;
             if (threads > 1 && t == 0) continue;
-            if (ok) {
+            if (ok && grids) {
+                // (shares are whole 64-game blocks: a block is what the expansion streams out in full cache lines)
+                const int64_t blocks = (job.n_games + 63) / 64;
+                const int64_t g0 = blocks * share / expanders * 64;
+                const int64_t g1 = share + 1 == expanders ? job.n_games : blocks * (share + 1) / expanders * 64;
+                static const bool skip = getenv("BGS_GRID_NO_EXPAND") != nullptr;  // (measurement knob: the copy alone)
+                if (g1 > g0 && !skip) expand_cells(pinned[slot], job.n_games, cells, g0, g1 - g0, job.host_reward);
+            } else if (ok) {
                 // shares are multiples of 4 games (one code byte), so threads never touch the same output word
                 const int64_t bytes = (job.n_games + 3) / 4;
                 const int64_t b0 = bytes * share / expanders, b1 = bytes * (share + 1) / expanders;
@@ -460,7 +572,8 @@ int bgs_rollout_to_host(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t
                  : bgs_read_reward_async(b, static_cast<int8_t*>(host_dst), done);
 }
 
-int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_reward_sink** out) {
+static int make_sink(int device, int64_t max_games, int slots, int threads, size_t slot_bytes, const CellFormat* cells,
+                     bgs_reward_sink** out) {
     NEED(out != nullptr, "out is NULL");
     *out = nullptr;
     NEED(max_games >= 1 && slots >= 1 && slots <= 64 && threads >= 1 && threads <= 256,
@@ -471,6 +584,11 @@ int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_r
     NEED(s != nullptr, "out of host memory");
     s->device = device;
     s->max_games = max_games;
+    s->slot_bytes = slot_bytes;
+    if (cells) {
+        s->grids = true;
+        s->cells = *cells;
+    }
     s->slots = slots;
     s->threads = threads;
     s->jobs.resize(slots);
@@ -484,7 +602,7 @@ int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_r
         if (v >= 0 && v <= 1000000) s->spin_us = v;
     }
     s->parts_done.assign(slots, 0);
-    const size_t bytes = (size_t)(max_games + 63) / 64 * 16;  // whole 16-byte units: kernels store codes dword- / uint4-wise
+    const size_t bytes = slot_bytes;
     hipError_t err = hipSuccess;
     for (int k = 0; k < slots && err == hipSuccess; ++k) {
         void* host = nullptr;
@@ -511,6 +629,81 @@ int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_r
     if (!(aff && atoi(aff) == 0) && device_node_cpus(device, &cpus))
         for (auto& w : s->workers) (void)pthread_setaffinity_np(w.native_handle(), sizeof cpus, &cpus);
     *out = s;
+    return BGS_OK;
+}
+
+int bgs_sink_create(int device, int64_t max_games, int slots, int threads, bgs_reward_sink** out) {
+    NEED(max_games >= 1, "max_games must be >= 1");
+    // whole 16-byte units: kernels store codes dword- / uint4-wise
+    return make_sink(device, max_games, slots, threads, (size_t)(max_games + 63) / 64 * 16, nullptr, out);
+}
+
+// bytes per board of the grid hand-over's wire format, and how the host expands it
+static CellFormat cell_format(const bgs_batch* b) {
+    CellFormat f;
+    const int h = b->generic ? b->gen_h : (b->game == BGS_GAME_CONNECT ? b->cg.h : b->bg.h);
+    const int w = b->generic ? b->gen_w : (b->game == BGS_GAME_CONNECT ? b->cg.w : b->bg.w);
+    f.cells = h * w;
+    if (b->generic) return f;  // sets = 0: the int8 grid itself crosses PCIe
+    f.nwc = (f.cells + 63) / 64;
+    if (b->game == BGS_GAME_CONNECT) {
+        f.sets = 2;
+        f.offset = -1;
+        f.weight[0] = f.weight[1] = 1;
+    } else {
+        f.sets = 4;
+        for (int p = 0; p < 4; ++p) f.weight[p] = 1 << p;
+    }
+    return f;
+}
+
+int bgs_grid_sink_create(const bgs_batch* like, int slots, int threads, bgs_reward_sink** out) {
+    NEED(like != nullptr, "batch is NULL");
+    const CellFormat f = cell_format(like);
+    const size_t per_board = f.sets ? (size_t)f.sets * f.nwc * 8 : (size_t)f.cells;
+    return make_sink(like->device, like->n, slots, threads, per_board * (size_t)like->n, &f, out);
+}
+
+// the boards of `b` in the wire format -> the ticket's slot (one asynchronous copy behind whatever the stream holds)
+static hipError_t enqueue_grids(bgs_reward_sink* s, bgs_batch* b, int slot) {
+    const void* src = b->d_planes;  // Bounce value planes and generic int8 grids cross as they are
+    if (!b->generic && b->game == BGS_GAME_CONNECT) {
+        // The conversion kernel stores straight into the page-locked slot: coalesced 512-byte runs over PCIe, 51 GB/s
+        // measured at 2^20 boards (a copy engine behind a staging buffer, BGS_GRID_COPY=1: 36 GB/s)
+        static const bool direct = getenv("BGS_GRID_COPY") == nullptr;
+        if (direct) {
+            bgs::connect_cell_planes(b, reinterpret_cast<uint64_t*>(s->mapped[slot]));
+            return hipGetLastError();
+        }
+        bgs::connect_cell_planes(b, reinterpret_cast<uint64_t*>(b->d_staging));  // (staging: ordered on the batch's stream)
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        src = b->d_staging;
+    }
+    return hipMemcpyAsync(s->pinned[slot], src, s->slot_bytes, hipMemcpyDeviceToHost, b->stream);
+}
+
+static int grid_sink_matches(const bgs_reward_sink* s, const bgs_batch* b) {
+    const CellFormat f = cell_format(b);
+    NEED(b->n == s->max_games && f.cells == s->cells.cells && f.sets == s->cells.sets,
+         "the grid sink was made for batches of %lld boards of %d cells", (long long)s->max_games, s->cells.cells);
+    NEED(f.sets == 0 || b->staging_bytes >= s->slot_bytes, "staging buffer too small");
+    return BGS_OK;
+}
+
+int bgs_expand_grid_host(const void* wire, int64_t n, int cells, int sets, int offset, const int32_t* weights, int64_t first,
+                         int64_t count, int8_t* grid, int portable) {
+    NEED(wire != nullptr && grid != nullptr && n >= 1 && cells >= 1, "bad argument");
+    NEED(sets == 0 || (sets >= 1 && sets <= 4 && weights != nullptr), "sets must be 0 (the wire is the grid) or 1..4 with weights");
+    NEED(first >= 0 && count >= 0 && first + count <= n, "games [first, first + count) must lie inside the batch");
+    CellFormat f;
+    f.cells = cells;
+    f.sets = sets;
+    f.nwc = (cells + 63) / 64;
+    f.offset = offset;
+    for (int p = 0; p < sets; ++p) f.weight[p] = weights[p];
+    if (sets && (portable || !g_have_avx512bw)) expand_cells_portable(static_cast<const uint64_t*>(wire), n, f, first, count, grid);
+    else expand_cells(wire, n, f, first, count, grid);
     return BGS_OK;
 }
 
@@ -600,10 +793,16 @@ int bgs_sink_submit(bgs_reward_sink* s, bgs_batch* b, int8_t* host_reward, int64
     NEED(b->n <= s->max_games, "batch of %lld games exceeds the sink's %lld", (long long)b->n, (long long)s->max_games);
     int rc = enter_device(s->device);
     if (rc) return rc;
+    if (s->grids && (rc = grid_sink_matches(s, b))) return rc;
     const int64_t t = claim(s);
     const int slot = (int)(t % s->slots);
-    bgs::pack_outcomes(b, s->mapped[slot]);  // the codes go straight into the page-locked slot
-    hipError_t err = hipGetLastError();
+    hipError_t err;
+    if (s->grids) {
+        err = enqueue_grids(s, b, slot);
+    } else {
+        bgs::pack_outcomes(b, s->mapped[slot]);  // the codes go straight into the page-locked slot
+        err = hipGetLastError();
+    }
     if (err == hipSuccess) err = hipEventRecord(s->landed[slot], b->stream);
     publish(s, t, b->n, host_reward, err == hipSuccess);
     if (ticket) *ticket = t;
@@ -616,12 +815,19 @@ int bgs_sink_rollout(bgs_reward_sink* s, bgs_batch* b, uint64_t seed, int32_t ma
     NEED(s != nullptr && b != nullptr && host_reward != nullptr, "NULL argument");
     NEED(b->device == s->device, "batch lives on device %d, the sink on device %d", b->device, s->device);
     NEED(b->n <= s->max_games, "batch of %lld games exceeds the sink's %lld", (long long)b->n, (long long)s->max_games);
+    if (s->grids) {
+        int rc0 = grid_sink_matches(s, b);
+        if (rc0) return rc0;
+    }
     const int64_t t = claim(s);
     const int slot = (int)(t % s->slots);
     // the rollout kernel stores the outcome codes of the games it finishes straight into the page-locked slot (or the
-    // pack kernel does, for kernels without that epilogue): when the event fires the codes are in host memory
-    int rc = bgs::rollout_with_codes(b, seed, max_plies, flags, s->mapped[slot]);
-    hipError_t err = rc ? hipSuccess : hipEventRecord(s->landed[slot], b->stream);
+    // pack kernel does, for kernels without that epilogue): when the event fires the codes are in host memory.  A grid
+    // sink: the final boards follow the rollout in the wire format, one asynchronous copy
+    int rc = s->grids ? bgs_rollout(b, seed, max_plies, flags) : bgs::rollout_with_codes(b, seed, max_plies, flags, s->mapped[slot]);
+    hipError_t err = hipSuccess;
+    if (rc == BGS_OK && s->grids) err = enqueue_grids(s, b, slot);
+    if (rc == BGS_OK && err == hipSuccess) err = hipEventRecord(s->landed[slot], b->stream);
     publish(s, t, b->n, host_reward, rc == BGS_OK && err == hipSuccess);
     if (ticket) *ticket = t;
     if (rc) return rc;
@@ -632,6 +838,7 @@ int bgs_sink_rollout(bgs_reward_sink* s, bgs_batch* b, uint64_t seed, int32_t ma
 int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* device_packed, int64_t n_games,
                            int8_t* host_reward, int64_t* ticket) {
     NEED(s != nullptr && device_packed != nullptr && host_reward != nullptr, "NULL argument");
+    NEED(!s->grids, "a grid sink takes boards (bgs_sink_submit / bgs_sink_rollout), not outcome codes");
     NEED(n_games >= 1 && n_games <= s->max_games, "n_games %lld outside 1..%lld", (long long)n_games,
          (long long)s->max_games);
     int rc = enter_device(s->device);

@@ -117,6 +117,7 @@ void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count);  //
 void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out);
 bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, uint32_t* codes_out);
 void connect_unpack_grid(const bgs_batch* b, int8_t* d_grid);
+void connect_cell_planes(const bgs_batch* b, uint64_t* d_dst);  // wire format of the grid hand-over (see the kernel)
 void connect_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies);
 void connect_legal(const bgs_batch* b, uint8_t* d_legal, int32_t* d_count);
 void connect_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_player, const int8_t* d_winner,

@@ -1406,6 +1406,41 @@ k_connect_unpack(G g, const uint64_t* __restrict__ planes, int64_t n, int8_t* __
     tile_to_global(tile, reinterpret_cast<uint8_t*>(grid) + base * hw, (uint32_t)(boards * hw));
 }
 
+// Wire format of the asynchronous grid hand-over (bgs_host.hip): per board two bit sets over the cells in the
+// REFERENCE order (cell = y * W + x, row 0 = bottom), "occupied" and "player 1's", NWC = ceil(H W / 64) words each,
+// stored plane-major over the batch like the boards themselves: word j of set q at dst[(q * NWC + j) * n + i].  The host
+// turns a word into 64 grid bytes with two masked byte adds (-1 + occupied + player 1's), 16 B per 6x7 board cross PCIe
+// instead of 42.
+template <class G>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_cell_planes(G g, const uint64_t* __restrict__ planes, int64_t n, uint64_t* __restrict__ dst, int nwc) {
+    constexpr int NW = G::NW;
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Bits<NW> p0, p1;
+    load_planes<NW>(planes, n, i, p0, p1);
+    const int h = g.h(), w = g.w();
+    uint64_t occ = 0, who = 0;
+    int cell = 0, word = 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int bit = x * (h + 1) + y;
+            const uint64_t b0 = test_bit(p0, bit), b1 = test_bit(p1, bit);
+            occ |= (b0 | b1) << (cell & 63);
+            who |= b1 << (cell & 63);
+            if ((++cell & 63) == 0) {
+                dst[(int64_t)word * n + i] = occ;
+                dst[(int64_t)(nwc + word) * n + i] = who;
+                occ = who = 0;
+                ++word;
+            }
+        }
+    if (cell & 63) {
+        dst[(int64_t)word * n + i] = occ;
+        dst[(int64_t)(nwc + word) * n + i] = who;
+    }
+}
+
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_meta(ConnectGeom cg, const uint64_t* __restrict__ planes, const uint8_t* __restrict__ status, int64_t n,
                int8_t* __restrict__ player, uint8_t* __restrict__ ended, int8_t* __restrict__ winner,
@@ -1707,6 +1742,15 @@ void connect_unpack_grid(const bgs_batch* b, int8_t* d_grid) {
         using G = decltype(g);
         hipLaunchKernelGGL((k_connect_unpack<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), lds, b->stream, g, b->d_planes,
                            b->n, d_grid);
+    });
+}
+
+void connect_cell_planes(const bgs_batch* b, uint64_t* d_dst) {
+    const int nwc = (b->cg.h * b->cg.w + 63) / 64;
+    dispatch(b->cg, [&](auto g) {
+        using G = decltype(g);
+        hipLaunchKernelGGL((k_connect_cell_planes<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g, b->d_planes, b->n,
+                           d_dst, nwc);
     });
 }
 

@@ -117,9 +117,12 @@ def expand_outcomes_host(packed, n: int, out=None, first: int = 0, count: Option
     return out
 
 
-def _reward_destination(dst, n_games: int) -> int:
-    """Address of a host array the library's worker threads will fill with int8[n_games, 2] LATER: it must be large
-    enough, of 1-byte items and writeable -- the C side cannot check any of that from a bare pointer."""
+def _reward_destination(dst, n_games: int, per_game: int = 2) -> int:
+    """Address of a host array the library's worker threads will fill with int8[n_games, per_game] LATER (rewards: 2
+    bytes per game; grids: height * width): it must be large enough, of 1-byte items and writeable -- the C side cannot
+    check any of that from a bare pointer."""
+    if per_game != 2:
+        return _reward_destination(dst, (n_games * per_game + 1) // 2)
     if isinstance(dst, PinnedArray):
         arr = dst.array
     elif isinstance(dst, np.ndarray):
@@ -157,6 +160,9 @@ class RewardSink:
         self.max_games = int(max_games)
         _abi.check(_abi.lib().bgs_sink_create(int(device), int(max_games), int(slots), int(threads), ctypes.byref(self._handle)))
 
+    def _destination(self, host_reward, n_games: int) -> int:
+        return _reward_destination(host_reward, n_games)
+
     def _keep(self, ticket: int, *objects) -> int:
         if len(self._alive) >= 64:  # (callers that never wait: forget what has been delivered, now and then)
             done = self.completed
@@ -167,7 +173,7 @@ class RewardSink:
 
     def submit(self, batch: "_Batch", host_reward) -> int:
         ticket = ctypes.c_int64(-1)
-        ptr = _reward_destination(host_reward, batch.n)
+        ptr = self._destination(host_reward, batch.n)
         try:
             _abi.check(_abi.lib().bgs_sink_submit(self._handle, batch._handle, ctypes.c_void_p(ptr), ctypes.byref(ticket)))
         finally:
@@ -180,7 +186,7 @@ class RewardSink:
         """`batch.rollout(...)` + `submit(batch, host_reward)` in one library call (bgs_sink_rollout)."""
         flags = _abi.ROLLOUT_FROM_INITIAL if from_initial else 0
         ticket = ctypes.c_int64(-1)
-        ptr = _reward_destination(host_reward, batch.n)
+        ptr = self._destination(host_reward, batch.n)
         try:
             _abi.check(
                 _abi.lib().bgs_sink_rollout(
@@ -243,6 +249,26 @@ class RewardSink:
             self.close()
         except Exception:
             pass
+
+
+class GridSink(RewardSink):
+    """Delivers the BOARDS of successive batch steps -- `state.grid` of every game, int8[n, H, W] in the reference layout --
+    into host arrays while the GPU goes on playing (bgs_grid_sink_create): the boards cross PCIe bit-packed (16 B per
+    6x7 Connect board instead of 42), worker threads expand them.  `submit` / `rollout` / `wait` / `completed` as for a
+    RewardSink, with int8[n, H, W] destinations; a `RolloutExecutor` takes one as its sink."""
+
+    def __init__(self, like: "_Batch", slots: int = 4, threads: int = 4):
+        self._handle = _abi.c_handle()
+        self._alive = {}
+        self.max_games = like.n
+        self._cells = like.height * like.width
+        _abi.check(_abi.lib().bgs_grid_sink_create(like._handle, int(slots), int(threads), ctypes.byref(self._handle)))
+
+    def _destination(self, host_grid, n_games: int) -> int:
+        return _reward_destination(host_grid, n_games, self._cells)
+
+    def submit_packed(self, *args, **kwargs):
+        raise TypeError("a grid sink takes boards, not outcome codes")
 
 
 class DeviceView:

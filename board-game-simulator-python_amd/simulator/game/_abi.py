@@ -99,6 +99,12 @@ SIGNATURES = {
     ),
     "bgs_sink_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_handle)]),
     "bgs_sink_destroy": (ctypes.c_int, [c_handle]),
+    "bgs_grid_sink_create": (ctypes.c_int, [c_handle, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_handle)]),
+    "bgs_expand_grid_host": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+         ctypes.c_int],
+    ),
     "bgs_sink_submit": (ctypes.c_int, [c_handle, c_handle, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "bgs_sink_rollout": (
         ctypes.c_int,

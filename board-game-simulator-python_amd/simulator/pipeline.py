@@ -45,7 +45,7 @@ class RolloutExecutor:
         n_games = self.batches[0].n * (gather.world if gather is not None else 1)
         ptrs = (ctypes.c_void_p * max(len(self.host), 1))()
         for k, a in enumerate(self.host):
-            ptrs[k] = None if a is None else _reward_destination(a, n_games)
+            ptrs[k] = None if a is None else (sink._destination(a, n_games) if sink is not None else _reward_destination(a, n_games))
         handles = (_abi.c_handle * len(self.batches))(*[b._handle for b in self.batches])
         self._handle = _abi.c_handle()
         _abi.check(_abi.lib().bgs_pipeline_create(

@@ -200,6 +200,21 @@ int bgs_sink_rollout(bgs_reward_sink* s, bgs_batch* b, uint64_t seed, int32_t ma
 int bgs_sink_submit_packed(bgs_reward_sink* s, void* hip_stream, const void* device_packed, int64_t n_games,
                            int8_t* host_reward, int64_t* ticket);
 int bgs_sink_wait(bgs_reward_sink* s, int64_t ticket); /* until that submission's rewards are in its host array */
+/* A GRID sink hands over the boards themselves -- State::get_grid (connect.cpp:42, bounce.cpp:39; the reference returns
+ * a host array through the copying caster tensor.hpp:69-87) for every game of a step: the boards cross PCIe bit-packed
+ * (Connect: two bit sets over the cells in reference order, 16 B per 6x7 board instead of 42; Bounce: the four value
+ * bit-planes; generic batches: the int8 grid itself), one asynchronous copy per step into a page-locked slot, and the
+ * worker threads expand them into the caller's int8[n][height][width] (AVX-512: two masked byte adds per 64 cells).
+ * Made for batches like `like` (same game, geometry and size); bgs_sink_submit / bgs_sink_rollout / bgs_sink_wait /
+ * bgs_sink_completed / bgs_sink_destroy and bgs_pipeline_* work as for a reward sink, with host_reward = the grid array. */
+int bgs_grid_sink_create(const bgs_batch* like, int slots, int threads, bgs_reward_sink** out);
+/* the host half of it, for games [first, first + count) of a batch of n: `wire` holds `sets` bit sets over the cells
+ * (cell = y * width + x), word j of set p of game i at ((uint64_t*)wire)[(p * nwc + j) * n + i], nwc = (cells + 63) / 64;
+ * a cell's byte = offset + sum of weights[p] over the sets that contain it (Connect: offset -1, weights 1, 1 for
+ * "occupied" and "player 1's"; Bounce: offset 0, weights 1, 2, 4, 8); sets = 0: the wire is the int8 grid.  A table
+ * look-up per 8 cells or two masked byte adds per 64 (AVX-512; portable != 0 forces the table), no game rule. */
+int bgs_expand_grid_host(const void* wire, int64_t n, int cells, int sets, int offset, const int32_t* weights, int64_t first,
+                         int64_t count, int8_t* grid, int portable);
 /* Submissions to one sink may come from several threads (a ticket and its slot are reserved under the sink's lock);
  * they are delivered in ticket order.  *completed = number of submissions whose rewards are in their host arrays. */
 int bgs_sink_completed(bgs_reward_sink* s, int64_t* completed);

@@ -235,3 +235,63 @@ def test_in_library_rccl_gather_with_one_rank(direct):
     env = dict(os.environ, BGS_GATHER_DIRECT=direct)
     proc = subprocess.run(["timeout", "-k", "10", "300", sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert proc.returncode == 0 and "GATHER_OK" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-3000:]
+
+
+@pytest.mark.parametrize("case", ["connect6x7", "connect12x13", "connect3x4", "bounce", "bounce_generic", "connect_generic"])
+def test_grid_sink_delivers_the_boards_of_every_step(case):
+    """The overlapped grid hand-over (State.grid of every game of a step, int8[n, H, W], reference connect.cpp:42 /
+    bounce.cpp:39): bit-packed boards cross PCIe into page-locked slots, worker threads expand them.  Host grids of the
+    last `slots` steps == oracle grids, for one- and three-word Connect boards, a tiny one, Bounce (value planes), and the
+    generic batches whose device layout is the grid itself; through the native loop and by single calls."""
+    from simulator.batch import BounceBatch, ConnectBatch, GridSink, RewardSink
+    from simulator.pipeline import RolloutExecutor
+
+    big = np.zeros((10, 8), dtype=np.int8)
+    big[1] = big[8] = [1, 2, 3, 4, 4, 3, 2, 1]
+    make, orc_of, cap = {
+        "connect6x7": (lambda n: ConnectBatch(6, 7, 4, n, use_torch=True), lambda n: oracle.ConnectOracle(6, 7, 4, n), 2**31 - 1),
+        "connect12x13": (lambda n: ConnectBatch(12, 13, 5, n, use_torch=True), lambda n: oracle.ConnectOracle(12, 13, 5, n), 2**31 - 1),
+        "connect3x4": (lambda n: ConnectBatch(3, 4, 3, n, use_torch=True), lambda n: oracle.ConnectOracle(3, 4, 3, n), 5),
+        "bounce": (lambda n: BounceBatch(DEFAULT_BOUNCE, n, use_torch=True), lambda n: oracle.BounceOracle(DEFAULT_BOUNCE, n), 300),
+        "bounce_generic": (lambda n: BounceBatch(big, n, use_torch=True), lambda n: oracle.BounceOracle(big, n), 200),
+        "connect_generic": (lambda n: ConnectBatch(20, 20, 5, n, use_torch=True), lambda n: oracle.ConnectOracle(20, 20, 5, n), 2**31 - 1),
+    }[case]
+    n, depth, slots = 3001, 2, 4
+    streams, batches = _batches(lambda: make(n), depth)
+    h, w = batches[0].height, batches[0].width
+    sink = GridSink(batches[0], slots=slots, threads=3)
+    hosts = [np.full((n, h, w), 77, dtype=np.int8) for _ in range(slots)]
+    with RolloutExecutor(batches, sink=sink, host_arrays=hosts, seed0=SEED + 7, max_plies=cap) as exe:
+        exe.enqueue(7)
+        exe.drain()
+        for j in range(7 - slots, 7):
+            orc = orc_of(n)
+            orc.rollout(SEED + 7 + j, max_plies=cap)
+            np.testing.assert_array_equal(hosts[j % slots], orc.grid, err_msg=f"{case} step {j}")
+    # single calls: the current boards (submit) and rollout + boards
+    g = np.zeros((n, h, w), dtype=np.int8)
+    t = sink.submit(batches[0], g)
+    sink.wait(t)
+    np.testing.assert_array_equal(g, batches[0].grid)
+    with pytest.raises(ValueError):
+        sink.rollout(batches[0], np.zeros((n, h, w - 1), dtype=np.int8), SEED, from_initial=True)
+    with pytest.raises(TypeError):
+        sink.submit_packed(None, n, g)
+    other = ConnectBatch(4, 4, 3, n)
+    if (h, w) != (4, 4):
+        with pytest.raises(ValueError):
+            sink.rollout(other, g, SEED, from_initial=True)   # a batch the sink was not made for
+    sink.close()
+    # a reward sink and a grid sink side by side on the same batch
+    rs, gs = RewardSink(n, slots=2, threads=2), GridSink(batches[1], slots=2, threads=2)
+    rew = np.zeros((n, 2), dtype=np.int8)
+    t1 = rs.rollout(batches[1], rew, SEED + 99, max_plies=cap, from_initial=True)
+    t2 = gs.submit(batches[1], g)
+    rs.wait(t1)
+    gs.wait(t2)
+    orc = orc_of(n)
+    orc.rollout(SEED + 99, max_plies=cap)
+    np.testing.assert_array_equal(rew, orc.reward)
+    np.testing.assert_array_equal(g, orc.grid)
+    rs.close()
+    gs.close()

@@ -4,6 +4,7 @@ The function is a table look-up in libbgs.so's host code and needs no GPU."""
 import ctypes
 
 import numpy as np
+import pytest
 
 from oracle import oracle
 
@@ -56,3 +57,37 @@ def test_expand_rejects_bad_arguments():
     assert lib.bgs_expand_outcomes_host(ctypes.c_void_p(buf.ctypes.data), 2, 4, ctypes.c_void_p(out.ctypes.data)) == _abi.BGS_ERR_ARG
     assert lib.bgs_expand_outcomes_host(None, 0, 4, ctypes.c_void_p(out.ctypes.data)) == _abi.BGS_ERR_ARG
     assert lib.bgs_expand_outcomes_host(ctypes.c_void_p(buf.ctypes.data), 0, 0, ctypes.c_void_p(out.ctypes.data)) == 0
+
+
+@pytest.mark.parametrize("portable", [0, 1])
+@pytest.mark.parametrize("cells,sets,offset,weights", [(42, 2, -1, (1, 1)), (54, 4, 0, (1, 2, 4, 8)), (156, 2, -1, (1, 1)),
+                                                       (64, 4, 0, (1, 2, 4, 8)), (7, 2, -1, (1, 1)), (129, 1, 3, (5,))])
+def test_grid_expansion_on_the_host(cells, sets, offset, weights, portable):
+    """bgs_expand_grid_host (the host half of the grid hand-over): bit sets over the cells -> int8 per cell, against a
+    numpy restatement; the AVX-512 path (where the CPU has it) and the table path; sub-ranges leave the rest alone."""
+    import ctypes
+
+    from simulator.game import _abi
+
+    rng = np.random.default_rng(cells * 10 + sets)
+    n, nwc = 300, (cells + 63) // 64   # (whole 64-game blocks go out with non-temporal stores when the array is 64-byte aligned)
+    bits = rng.integers(0, 2, size=(sets, n, cells), dtype=np.uint8)
+    wire = np.zeros((sets * nwc, n), dtype=np.uint64)
+    for p in range(sets):
+        for c in range(cells):
+            wire[p * nwc + c // 64] |= bits[p, :, c].astype(np.uint64) << np.uint64(c % 64)
+    want = (offset + sum(int(w) * bits[p].astype(np.int32) for p, w in enumerate(weights))).astype(np.int8)
+    raw = np.full(n * cells + 64, 99, dtype=np.int8)
+    shift = (-raw.ctypes.data) % 64
+    got = raw[shift : shift + n * cells].reshape(n, cells)
+    assert got.ctypes.data % 64 == 0
+    wts = (ctypes.c_int32 * sets)(*weights)
+    _abi.check(_abi.lib().bgs_expand_grid_host(ctypes.c_void_p(wire.ctypes.data), n, cells, sets, offset, wts, 5, 270,
+                                               ctypes.c_void_p(got.ctypes.data), portable))
+    np.testing.assert_array_equal(got[5:275], want[5:275])
+    assert (got[:5] == 99).all() and (got[275:] == 99).all() and (raw[:shift] == 99).all() and (raw[shift + n * cells :] == 99).all()
+    _abi.check(_abi.lib().bgs_expand_grid_host(ctypes.c_void_p(wire.ctypes.data), n, cells, sets, offset, wts, 0, n,
+                                               ctypes.c_void_p(got.ctypes.data), portable))
+    np.testing.assert_array_equal(got, want)
+    assert _abi.lib().bgs_expand_grid_host(ctypes.c_void_p(wire.ctypes.data), n, cells, sets, offset, wts, 290, 20,
+                                           ctypes.c_void_p(got.ctypes.data), portable) == _abi.BGS_ERR_ARG

@@ -1256,7 +1256,7 @@ __device__ __forceinline__ Win win_runs(const Win& m) {
     }
 }
 
-template <class G, bool CAPPED, bool CODES>
+template <class G, bool CAPPED, bool CODES, bool FROM_INITIAL>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                       int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
@@ -1279,6 +1279,7 @@ k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
     uint64_t hts = 0;                     // nibble per column: its height
     uint32_t open_lo = 0, open_hi = 0;    // nibble-spread "column open" flags (columns 0-7 / 8-15)
     uint32_t blk = 0, st = 0, game = 0, stepped = 0;
+    uint32_t skip = 0;                    // loaded boards: sub-steps to sit out in the first block (= plies already in it)
     uint32_t live = 0;                    // all ones while this lane's game is running
 
     if (avail == 0u) return;
@@ -1294,21 +1295,60 @@ k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (live == 0 && taken + rank < avail) {
                 game = taken + rank;
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int d = 0; d < 2 * NW; ++d) cell(q, PB + d) = 0u;
-                hts = 0;
-                open_lo = open_lo0;
-                open_hi = open_hi0;
-                blk = 0;
                 st = 0;
-                live = (!CAPPED || max_plies > 0u) ? ~0u : 0u;
-                if (CAPPED && live == 0) {
-                    const Bits<NW> none = zero_bits<NW>();
-                    store_planes<NW>(planes, n, begin + game, none, none);
-                    status[begin + game] = 0;
-                    reward[begin + game] = 0;
+                if (FROM_INITIAL) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int d = 0; d < 2 * NW; ++d) cell(q, PB + d) = 0u;
+                    hts = 0;
+                    open_lo = open_lo0;
+                    open_hi = open_hi0;
+                    blk = 0;
+                    live = (!CAPPED || max_plies > 0u) ? ~0u : 0u;
+                    if (CAPPED && live == 0) {
+                        const Bits<NW> none = zero_bits<NW>();
+                        store_planes<NW>(planes, n, begin + game, none, none);
+                        status[begin + game] = 0;
+                        reward[begin + game] = 0;
+                    }
+                } else {
+                    // a board from memory joins at its own ply (see k_connect_rollout_aligned): planes into the LDS
+                    // column, column heights from the occupied cells, the first (ply & 3) sub-steps of its first block
+                    // are sat out
+                    Bits<NW> p0, p1;
+                    load_planes<NW>(planes, n, begin + game, p0, p1);
+                    uint32_t ply0 = 0;
+#pragma unroll
+                    for (int wd = 0; wd < NW; ++wd) {
+                        cell(0, PB + 2 * wd) = (uint32_t)p0.w[wd];
+                        cell(0, PB + 2 * wd + 1) = (uint32_t)(p0.w[wd] >> 32);
+                        cell(1, PB + 2 * wd) = (uint32_t)p1.w[wd];
+                        cell(1, PB + 2 * wd + 1) = (uint32_t)(p1.w[wd] >> 32);
+                        ply0 += (uint32_t)__popcll(p0.w[wd]) + (uint32_t)__popcll(p1.w[wd]);
+                    }
+                    const Bits<NW> occ = p0 | p1;
+                    hts = 0;
+                    open_lo = 0;
+                    open_hi = 0;
+#pragma unroll
+                    for (int x = 0; x < W; ++x) {
+                        // the column's H cells start at bit x (H + 1): at most two words hold them
+                        constexpr uint64_t field = (1ull << H) - 1ull;
+                        const int lo_bit = x * (H + 1), wd = lo_bit >> 6, sh = lo_bit & 63;
+                        uint64_t bits = occ.w[wd] >> sh;
+                        if (sh + H > 64 && wd + 1 < NW) bits |= occ.w[wd + 1] << (64 - sh);
+                        const uint32_t hx = (uint32_t)__popcll(bits & field);
+                        hts |= (uint64_t)hx << (4 * x);
+                        const uint32_t flag = hx < (uint32_t)H ? (1u << (4 * (x & 7))) : 0u;
+                        if (x < 8) open_lo |= flag;
+                        else open_hi |= flag;
+                    }
+                    blk = ply0 >> 2;
+                    skip = ply0 & 3u;
+                    const uint32_t st0 = status[begin + game];
+                    live = (st0 == BGS_ST_RUNNING && (!CAPPED || ply0 < max_plies)) ? ~0u : 0u;
+                    if (CODES && live == 0) codes.add(game, st0);  // a board that does not play keeps its outcome
                 }
             }
             const uint32_t wanted = (uint32_t)__popcll(need);
@@ -1329,10 +1369,11 @@ k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
             const uint32_t v = (uint32_t)(hts >> (4u * col)) & 15u;
             const uint32_t at = col * (uint32_t)(H + 1) + v + 32u * PB;   // the cell's bit index in the padded column
             const int me = (int)(j & 1u);
+            const uint32_t act = (FROM_INITIAL || j >= skip) ? live : 0u;  // mask: this lane plays this sub-step
             // the stone: one LDS OR into the dword that holds the cell (nothing for a lane that is not playing)
-            atomicOr(&cell(me, at >> 5), live & (1u << (at & 31u)));
-            hts += (uint64_t)(live & 1u) << (4u * col);
-            const uint32_t filled = (live != 0 && v + 1u == (uint32_t)H) ? (1u << (4u * (col & 7u))) : 0u;
+            atomicOr(&cell(me, at >> 5), act & (1u << (at & 31u)));
+            hts += (uint64_t)(act & 1u) << (4u * col);
+            const uint32_t filled = (act != 0 && v + 1u == (uint32_t)H) ? (1u << (4u * (col & 7u))) : 0u;
             open_lo &= ~(in_lo ? filled : 0u);
             open_hi &= ~(in_lo ? 0u : filled);
             // the 128-bit window of the mover's plane that starts R bits below the stone
@@ -1344,21 +1385,27 @@ k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 4; ++i) x.d[i] = __builtin_amdgcn_alignbit(y[i + 1], y[i], shift);
             const Win r1 = win_runs<H + 1, 1, K>(x), r2 = win_runs<H + 2, 1, K>(x), r3 = win_runs<H, 1, K>(x);
+            // r marks where a run STARTS, and a run through the new stone (window bit R) starts at or below it: only the
+            // dwords that hold bits 0 .. R are looked at (a run that starts above the stone would have ended the game
+            // earlier), and the compiler drops what only the others needed -- the last doubling step shrinks from four
+            // dwords to R / 32 + 1, the one before to one more
+            constexpr int START_DWORDS = R / 32 + 1;
             uint32_t any_run = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) any_run |= r1.d[i] | r2.d[i] | r3.d[i];
+            for (int i = 0; i < START_DWORDS && i < 4; ++i) any_run |= r1.d[i] | r2.d[i] | r3.d[i];
             // the column: the stone (window bit R) and the K - 1 cells below it
             constexpr int lowest = R - (K - 1);
             constexpr uint32_t kmask = (1u << K) - 1u;
             const uint64_t pair = ((uint64_t)x.d[(lowest >> 5) + 1] << 32) | x.d[lowest >> 5];
             const uint32_t below = (uint32_t)(pair >> (lowest & 31)) & kmask;
             const bool won = any_run != 0u || below == kmask;
-            stepped -= live;
+            stepped -= act;
             st = won ? (j & 1u) + 1u : st;   // (a lane that is not playing re-finds at most its own finished game's run)
             live = (won || (open_lo | open_hi) == 0u) ? 0u : live;
             if (CAPPED) live = (4u * blk + j + 1u < max_plies) ? live : 0u;
         }
         blk += 1u;
+        skip = 0;
 
         if (was_live != 0 && live == 0) {
             const int64_t i = begin + game;
@@ -1698,25 +1745,32 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
             if (nibble_ok) { with_game(Tag<NibbleGame<G>>{}); return; }
         }
         if constexpr (LdsBoard<G>::fits && G::NW > 1) {
-            if ((flags & 1u) && !b->rollout_generic && !b->rollout_no_lds) {
-                // a compile-time multi-word geometry: boards staged in LDS, run test on the window around the stone
+            if (!b->rollout_generic && !b->rollout_no_lds) {
+                // a compile-time multi-word geometry: boards staged in LDS, run test on the window around the stone --
+                // from the initial state or from memory, with or without a ply cap
                 const size_t tile = LdsBoard<G>::lds_bytes;
-                auto launch_lds = [&](auto capped_tag) {
+                auto launch_lds = [&](auto capped_tag, auto initial_tag) {
                     constexpr bool CAPPED = decltype(capped_tag)::value;
+                    constexpr bool INITIAL = decltype(initial_tag)::value;
                     if (fuse_codes) {
-                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, true>), dim3(blocks), dim3(BGS_BLOCK),
+                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, true, INITIAL>), dim3(blocks), dim3(BGS_BLOCK),
                                            tile + code_lds, b->stream, g, b->d_planes, b->d_status,
                                            reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps,
                                            (uint32_t)per_wave, codes_out);
                         fused = true;
                     } else {
-                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, false>), dim3(blocks), dim3(BGS_BLOCK), tile,
+                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, false, INITIAL>), dim3(blocks), dim3(BGS_BLOCK), tile,
                                            b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward),
                                            b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr);
                     }
                 };
-                if (capped) launch_lds(std::true_type{});
-                else launch_lds(std::false_type{});
+                if (flags & 1u) {
+                    if (capped) launch_lds(std::true_type{}, std::true_type{});
+                    else launch_lds(std::false_type{}, std::true_type{});
+                } else {
+                    if (capped) launch_lds(std::true_type{}, std::false_type{});
+                    else launch_lds(std::false_type{}, std::false_type{});
+                }
                 return;
             }
         }

@@ -237,6 +237,57 @@ def test_connect_large_board_full_size(batch_mod):
     np.testing.assert_array_equal(dev.plies, orc.plies)
 
 
+@pytest.mark.parametrize("kernel", ["lds", "registers"])
+def test_connect_large_board_entry_states(batch_mod, kernel):
+    """Connect(12,13,5) rollouts from every entry state on the LDS-staged kernel (K2c: from the initial state, boards
+    loaded from memory at any ply of a 4-ply block, ply caps, finished boards in the batch, fused outcome codes) and on
+    the register kernel it replaces (BGS_ROLLOUT_NO_LDS): boards, rewards, plies, step counts against the oracle."""
+    import os
+
+    old = os.environ.get("BGS_ROLLOUT_NO_LDS")
+    if kernel == "registers":
+        os.environ["BGS_ROLLOUT_NO_LDS"] = "1"
+    try:
+        n = 20011
+        dev = batch_mod.ConnectBatch(12, 13, 5, n)
+        orc = oracle.ConnectOracle(12, 13, 5, n)
+        dev.set_first_game(7 << 40)
+        total = 0
+        for lead in (1, 2, 3, 6):    # boards enter the rollout 1, 3, 6, 12 plies into the game: every ply & 3
+            for _ in range(lead):
+                dev.step_random(SEED ^ 21)
+                total += orc.step_random(SEED ^ 21, first_game=7 << 40)
+            cap = int(orc.plies.max()) + 9
+            dev.rollout(SEED ^ 21, max_plies=cap)
+            total += orc.rollout(SEED ^ 21, first_game=7 << 40, max_plies=cap)
+            assert_same(dev, orc, f"{kernel}: loaded after {lead} more plies, capped at {cap}")
+            assert dev.steps == total
+        sink = batch_mod.RewardSink(n, slots=2, threads=2)
+        host = np.zeros((n, 2), dtype=np.int8)
+        sink.wait(sink.rollout(dev, host, SEED ^ 21, max_plies=60))     # from memory, capped, codes fused
+        orc.rollout(SEED ^ 21, first_game=7 << 40, max_plies=60)
+        assert_same(dev, orc, f"{kernel}: capped at 60, codes")
+        np.testing.assert_array_equal(host, orc.reward)
+        assert not orc.ended.all() and orc.ended.any()
+        sink.wait(sink.rollout(dev, host, SEED ^ 21))                   # from memory to the end, finished boards inside
+        orc.rollout(SEED ^ 21, first_game=7 << 40)
+        assert_same(dev, orc, f"{kernel}: finished")
+        np.testing.assert_array_equal(host, orc.reward)
+        assert orc.ended.all() and dev.steps == int(orc.plies.sum())
+        sink.wait(sink.rollout(dev, host, SEED ^ 22, max_plies=33, from_initial=True))   # from the initial state, capped
+        orc.reset()
+        orc.rollout(SEED ^ 22, first_game=7 << 40, max_plies=33)
+        assert_same(dev, orc, f"{kernel}: from the initial state, capped at 33")
+        np.testing.assert_array_equal(host, orc.reward)
+        sink.close()
+        dev.close()
+    finally:
+        if old is None:
+            os.environ.pop("BGS_ROLLOUT_NO_LDS", None)
+        else:
+            os.environ["BGS_ROLLOUT_NO_LDS"] = old
+
+
 @pytest.mark.parametrize("mode", ["opening0", "opening1", "opening2", "opening3", "opening4", "generic"])
 def test_connect_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
     """Every from-the-initial-state rollout kernel for one-word boards on the same batches: K2a (no opening stage), K2o

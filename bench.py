@@ -217,6 +217,10 @@ def committed_counters(build_id, stem, kernel_substring=None):
         if c.get("build_id") != build_id:
             seen.append(f"{os.path.basename(path)}: build {c.get('build_id')}")
             continue
+        if "kernels" in c and c.get("valu_wave_instructions_per_launch"):
+            # per-step totals over every kernel of the configuration's rollout (Bounce: bulk pass + compaction + tail pass)
+            return dict({k: v for k, v in c.items() if k != "kernels"}, kernel=" + ".join(n.split("(")[0].split("::")[-1] for n in c["kernels"]),
+                        file=os.path.basename(path)), None
         if "kernels" in c:  # per-kernel summaries: pick the kernel
             for name, k in c["kernels"].items():
                 if kernel_substring is None or kernel_substring in name:

@@ -492,6 +492,25 @@ int bgs_host_free(void* host_ptr) {
     return BGS_OK;
 }
 
+int bgs_stream_create(int device, void** hip_stream) {
+    NEED(hip_stream != nullptr, "hip_stream is NULL");
+    *hip_stream = nullptr;
+    int rc = enter_device(device);
+    if (rc) return rc;
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *hip_stream = s;
+    return BGS_OK;
+}
+
+int bgs_stream_destroy(int device, void* hip_stream) {
+    if (!hip_stream) return BGS_OK;
+    int rc = enter_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(hip_stream)));
+    return BGS_OK;
+}
+
 int bgs_event_create(int device, bgs_event** out) {
     NEED(out != nullptr, "out is NULL");
     *out = nullptr;

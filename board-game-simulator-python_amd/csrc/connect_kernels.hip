@@ -1256,11 +1256,69 @@ __device__ __forceinline__ Win win_runs(const Win& m) {
     }
 }
 
-template <class G, bool CAPPED, bool CODES, bool FROM_INITIAL>
+// ENTRY: how a lane's next game starts -- kEntryMemory: the board in memory, at whatever ply it holds; kEntryInitial: the
+// empty board; kEntryOpened: the board k_connect_open_lds left in memory, kOpenedPlies plies into the game, with its
+// column heights in `opened_heights`.
+enum { kEntryMemory = 0, kEntryInitial = 1, kEntryOpened = 2 };
+constexpr uint32_t kOpenedBlocks = 2, kOpenedPlies = 4 * kOpenedBlocks;
+
+// The opening of K2c.  In the first 2 K - 2 plies of a game nobody can have K stones, and no column of height >= 8 can
+// fill in 8 plies: for Connect(12,13,5) the first two 4-ply blocks are "column = floor(draw * W / 2^32), drop", a dozen
+// instructions a ply against ~125 for a full one.  Inside the rollout kernel that saving is lost again -- lanes start
+// their games at different times, so a wave would run the cheap code AND the full code every iteration -- and a pool of
+// pre-opened boards (K2o's way) would double the LDS tile and halve the occupancy.  So the opening is its own launch:
+// every lane opens one game, all lanes busy, boards and column heights go to memory, and the rollout kernel's lanes
+// pick them up from there: one 64-byte record a game (2 x 3 plane words, the column heights), i.e. one cache line, four
+// 16-byte loads (the batch's own plane arrays would be six lines a game).
+struct OpenedBoard {
+    uint64_t w[8];  // [0, 2 NW): the planes of player 0, then player 1; [6]: column heights, a nibble each; [7]: unused
+};
+static_assert(sizeof(OpenedBoard) == 64, "one cache line");
+
+template <class G>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_open_lds(G g, OpenedBoard* __restrict__ opened, int64_t n, uint64_t seed, uint64_t first_game,
+                   unsigned long long* __restrict__ steps) {
+    constexpr int NW = G::NW, H = G::STATIC_H, W = G::STATIC_W;
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    uint32_t stepped = 0;
+    if (i < n) {
+        Bits<NW> p[2] = {zero_bits<NW>(), zero_bits<NW>()};
+        uint64_t hts = 0;
+#pragma unroll
+        for (uint32_t blk = 0; blk < kOpenedBlocks; ++blk) {
+            const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)i, blk);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t col = sample_index(draws.v[j], (uint32_t)W);   // every column is open
+                const uint32_t v = (uint32_t)(hts >> (4u * col)) & 15u;
+                set_bit(p[j & 1u], (int)(col * (uint32_t)(H + 1) + v));
+                hts += 1ull << (4u * col);
+            }
+        }
+        static_assert(2 * NW <= 6, "the record holds at most three words a plane");
+        uint4* out = reinterpret_cast<uint4*>(opened + i);
+        uint64_t w[8] = {0, 0, 0, 0, 0, 0, hts, 0};
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            w[k] = p[0].w[k];
+            w[NW + k] = p[1].w[k];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            out[q] = make_uint4((uint32_t)w[2 * q], (uint32_t)(w[2 * q] >> 32), (uint32_t)w[2 * q + 1], (uint32_t)(w[2 * q + 1] >> 32));
+        stepped = kOpenedPlies;
+    }
+    add_steps(steps, stepped);
+}
+
+template <class G, bool CAPPED, bool CODES, int ENTRY>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                       int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
-                      unsigned long long* __restrict__ steps, uint32_t games_per_wave, uint32_t* __restrict__ codes_out) {
+                      unsigned long long* __restrict__ steps, uint32_t games_per_wave, uint32_t* __restrict__ codes_out,
+                      const OpenedBoard* __restrict__ opened) {
+    constexpr bool FROM_INITIAL = ENTRY != kEntryMemory;   // (no plies to sit out in a game's first block)
     using L = LdsBoard<G>;
     constexpr int NW = G::NW, H = L::H, W = L::W, K = L::K, R = L::R, PB = L::PB, ND = L::ND;
     constexpr uint32_t ONES = 0x11111111u;
@@ -1289,14 +1347,58 @@ k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
         for (int d = 0; d < ND; ++d) cell(q, d) = 0u;   // padding (and planes) start out empty
     WaveCodes codes;
     if (CODES) codes.init(lds_tile + 2 * ND * BGS_BLOCK, games_per_wave, avail);
+    // kEntryOpened: a lane's next board is REQUESTED (four 16-byte loads into registers) at the end of the iteration in
+    // which its game ended, and installed in LDS at the top of the next one: the loads have a whole 4-ply block to arrive
+    // in, instead of stalling the wave inside the refill.
+    uint4 pre[4];
+    pre[0] = pre[1] = pre[2] = pre[3] = make_uint4(0, 0, 0, 0);
+    uint32_t next_game = 0;
+    bool fetched = false;
+    auto request = [&]() {
+        if constexpr (ENTRY == kEntryOpened) {
+            const uint64_t need = __builtin_amdgcn_ballot_w64(live == 0 && !fetched);
+            if (need && taken < avail) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                if (live == 0 && !fetched && taken + rank < avail) {
+                    next_game = taken + rank;
+                    const uint4* rec = reinterpret_cast<const uint4*>(opened + (begin + next_game));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pre[q] = rec[q];
+                    fetched = true;
+                }
+                const uint32_t wanted = (uint32_t)__popcll(need);
+                taken = avail - taken < wanted ? avail : taken + wanted;
+            }
+        }
+    };
+    request();
     do {
-        const uint64_t need = __builtin_amdgcn_ballot_w64(live == 0);
+        if constexpr (ENTRY == kEntryOpened) {
+            if (live == 0 && fetched) {
+                const uint32_t dw[16] = {pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, pre[1].z, pre[1].w,
+                                         pre[2].x, pre[2].y, pre[2].z, pre[2].w, pre[3].x, pre[3].y, pre[3].z, pre[3].w};
+#pragma unroll
+                for (int k = 0; k < 2 * NW; ++k) {
+                    cell(0, PB + k) = dw[k];
+                    cell(1, PB + k) = dw[2 * NW + k];
+                }
+                hts = ((uint64_t)dw[13] << 32) | dw[12];
+                game = next_game;
+                st = 0;
+                open_lo = open_lo0;
+                open_hi = open_hi0;
+                blk = kOpenedBlocks;
+                live = ~0u;
+                fetched = false;
+            }
+        }
+        const uint64_t need = ENTRY == kEntryOpened ? 0ull : __builtin_amdgcn_ballot_w64(live == 0);
         if (need && taken < avail) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (live == 0 && taken + rank < avail) {
                 game = taken + rank;
                 st = 0;
-                if (FROM_INITIAL) {
+                if (ENTRY == kEntryInitial) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -1421,7 +1523,8 @@ k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
             reward[i] = reward_pair(code);
             if (CODES) codes.add(game, code);
         }
-    } while (__builtin_amdgcn_ballot_w64(live != 0) || taken < avail);
+        request();
+    } while (__builtin_amdgcn_ballot_w64(live != 0 || fetched) || taken < avail);
     if (CODES) codes.flush(codes_out, begin);
     add_steps(steps, stepped);
 }
@@ -1749,27 +1852,36 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
                 // a compile-time multi-word geometry: boards staged in LDS, run test on the window around the stone --
                 // from the initial state or from memory, with or without a ply cap
                 const size_t tile = LdsBoard<G>::lds_bytes;
-                auto launch_lds = [&](auto capped_tag, auto initial_tag) {
+                const OpenedBoard* heights = reinterpret_cast<const OpenedBoard*>(b->d_staging);
+                auto launch_lds = [&](auto capped_tag, auto entry_tag) {
                     constexpr bool CAPPED = decltype(capped_tag)::value;
-                    constexpr bool INITIAL = decltype(initial_tag)::value;
+                    constexpr int ENTRY = decltype(entry_tag)::value;
                     if (fuse_codes) {
-                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, true, INITIAL>), dim3(blocks), dim3(BGS_BLOCK),
+                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, true, ENTRY>), dim3(blocks), dim3(BGS_BLOCK),
                                            tile + code_lds, b->stream, g, b->d_planes, b->d_status,
                                            reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps,
-                                           (uint32_t)per_wave, codes_out);
+                                           (uint32_t)per_wave, codes_out, heights);
                         fused = true;
                     } else {
-                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, false, INITIAL>), dim3(blocks), dim3(BGS_BLOCK), tile,
+                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, false, ENTRY>), dim3(blocks), dim3(BGS_BLOCK), tile,
                                            b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward),
-                                           b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr);
+                                           b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr, heights);
                     }
                 };
-                if (flags & 1u) {
-                    if (capped) launch_lds(std::true_type{}, std::true_type{});
-                    else launch_lds(std::false_type{}, std::true_type{});
+                // the opening as a launch of its own: nobody can win and no column can fill in the first kOpenedPlies plies
+                constexpr bool can_open = G::STATIC_K > 0 && 2 * G::STATIC_K - 2 >= (int)kOpenedPlies &&
+                                          G::STATIC_H >= (int)kOpenedPlies && G::STATIC_H <= 15;
+                if ((flags & 1u) && !capped && can_open && G::NW <= 3 && b->rollout_opening &&
+                    b->staging_bytes >= (size_t)b->n * sizeof(OpenedBoard)) {
+                    hipLaunchKernelGGL((k_connect_open_lds<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g,
+                                       reinterpret_cast<OpenedBoard*>(b->d_staging), b->n, seed, b->first_game, b->d_steps);
+                    launch_lds(std::false_type{}, std::integral_constant<int, kEntryOpened>{});
+                } else if (flags & 1u) {
+                    if (capped) launch_lds(std::true_type{}, std::integral_constant<int, kEntryInitial>{});
+                    else launch_lds(std::false_type{}, std::integral_constant<int, kEntryInitial>{});
                 } else {
-                    if (capped) launch_lds(std::true_type{}, std::false_type{});
-                    else launch_lds(std::false_type{}, std::false_type{});
+                    if (capped) launch_lds(std::true_type{}, std::integral_constant<int, kEntryMemory>{});
+                    else launch_lds(std::false_type{}, std::integral_constant<int, kEntryMemory>{});
                 }
                 return;
             }

@@ -51,6 +51,8 @@ SIGNATURES = {
     ),
     "bgs_destroy": (ctypes.c_int, [c_handle]),
     "bgs_set_stream": (ctypes.c_int, [c_handle, ctypes.c_void_p]),
+    "bgs_stream_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "bgs_stream_destroy": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "bgs_set_first_game": (ctypes.c_int, [c_handle, ctypes.c_uint64]),
     "bgs_synchronize": (ctypes.c_int, [c_handle]),
     "bgs_info": (

@@ -11,6 +11,7 @@ an empty cell, otherwise the piece's step count.
 
 from __future__ import annotations
 
+import ctypes
 import os
 import threading
 from typing import Any, ClassVar, Dict, List, Tuple
@@ -34,23 +35,25 @@ def _as_cell(value, what: str) -> Cell:
 
 
 class _Engine:
-    """One-board device batch per start grid (shared, locked)."""
+    """One-board device batch per start grid AND per calling thread, each on a HIP stream of its own (see connect.py)."""
 
-    _cache: Dict[Tuple[Tuple[int, int], bytes], "_Engine"] = {}
-    _cache_lock = threading.Lock()
+    _local = threading.local()
 
     def __init__(self, grid: np.ndarray):
         self.batch = BounceBatch(grid, 1, device=_DEVICE, use_torch=False)
-        self.lock = threading.Lock()
+        self.lock = threading.Lock()  # (uncontended: the engine belongs to one thread)
+        stream = ctypes.c_void_p()
+        _abi.check(_abi.lib().bgs_stream_create(_DEVICE, ctypes.byref(stream)))
+        self.batch.set_stream(stream.value)
 
     @classmethod
     def get(cls, grid: np.ndarray) -> "_Engine":
+        cache = cls._local.__dict__.setdefault("engines", {})
         key = (grid.shape, grid.tobytes())
-        with cls._cache_lock:
-            eng = cls._cache.get(key)
-            if eng is None:
-                eng = cls._cache[key] = _Engine(grid)
-            return eng
+        eng = cache.get(key)
+        if eng is None:
+            eng = cache[key] = _Engine(grid)
+        return eng
 
     def _round_trip(self, grid=None, player=0, winner=-1, plies=0, move=None):
         """One fused call (bgs_transition): optional load, optional move, then the observations a State needs."""

@@ -25,24 +25,27 @@ _DEVICE = int(os.environ.get("BGS_DEVICE", "0"))
 
 
 class _Engine:
-    """One-board device batch that evaluates transitions for the object API (one per geometry, shared, locked:
-    callers do use worker threads -- textual/examples/agent.py:61,71)."""
+    """One-board device batch that evaluates transitions for the object API: one per geometry AND per calling thread,
+    each on a HIP stream of its own, so the thread pools the reference's callers use (8 boards at once in
+    textual/examples/arena.py:53, agent.py:61,71) run their round trips side by side instead of queueing on one lock."""
 
-    _cache: Dict[Tuple[int, int, int], "_Engine"] = {}
-    _cache_lock = threading.Lock()
+    _local = threading.local()
 
     def __init__(self, height: int, width: int, count: int):
         self.batch = ConnectBatch(height, width, count, 1, device=_DEVICE, use_torch=False)
-        self.lock = threading.Lock()
+        self.lock = threading.Lock()  # (uncontended: the engine belongs to one thread; States may cross threads, engines do not)
+        stream = ctypes.c_void_p()
+        _abi.check(_abi.lib().bgs_stream_create(_DEVICE, ctypes.byref(stream)))
+        self.batch.set_stream(stream.value)
 
     @classmethod
     def get(cls, height: int, width: int, count: int) -> "_Engine":
+        cache = cls._local.__dict__.setdefault("engines", {})
         key = (height, width, count)
-        with cls._cache_lock:
-            eng = cls._cache.get(key)
-            if eng is None:
-                eng = cls._cache[key] = _Engine(height, width, count)
-            return eng
+        eng = cache.get(key)
+        if eng is None:
+            eng = cache[key] = _Engine(height, width, count)
+        return eng
 
     def _round_trip(self, grid=None, player=0, winner=-1, column=None):
         """One fused call (bgs_transition): optional load, optional move, then the observations a State needs."""

@@ -83,6 +83,10 @@ int bgs_destroy(bgs_batch* b);
  * anything enqueued on the new one (event + stream wait), so a batch may be created under one stream and used on
  * another without a host synchronisation. */
 int bgs_set_stream(bgs_batch* b, void* hip_stream);
+/* a HIP stream of the library's own (non-blocking), for hosts without torch: batches that should overlap -- one per
+ * host thread, say -- each get one.  Destroy it after the batches bound to it. */
+int bgs_stream_create(int device, void** hip_stream);
+int bgs_stream_destroy(int device, void* hip_stream);
 int bgs_set_first_game(bgs_batch* b, uint64_t first_game); /* global id of board 0 (sharding across GPUs) */
 int bgs_synchronize(bgs_batch* b);
 int bgs_info(const bgs_batch* b, int* game, int* height, int* width, int* count, int64_t* n, int* planes);

@@ -155,3 +155,39 @@ def test_json_of_terminal_and_illegal_inputs():
         State.from_json({"grid": [[0]], "player": 0, "winner": -1}, config)
     with pytest.raises(RuntimeError):
         Action.from_json({"col": 1}, config.sample_initial_state())
+
+
+def test_object_api_from_a_thread_pool():
+    """The reference's callers play boards from worker threads (textual/examples/arena.py:53: eight at once).  Each thread
+    gets a one-board engine and a HIP stream of its own; every game played that way must be the game the oracle plays
+    when it is given the same columns, and states created on one thread keep working on another."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle
+    from simulator.game.connect import Config
+
+    config = Config(6, 7, 4)
+
+    def play(k):
+        rng = random.Random(k)
+        s = config.sample_initial_state()
+        columns = []
+        while not s.has_ended:
+            a = rng.choice(s.actions)
+            columns.append(a.column)
+            s = a.sample_next_state()
+        return columns, s
+
+    with ThreadPoolExecutor(8) as pool:
+        games = list(pool.map(play, range(24)))
+        for columns, final in games:
+            orc = oracle.ConnectOracle(6, 7, 4, 1)
+            for c in columns:
+                assert orc.step_actions(np.array([c], dtype=np.int32))[0] == 0
+            np.testing.assert_array_equal(final.grid, orc.grid[0])
+            np.testing.assert_array_equal(final.reward, orc.reward[0])
+            assert bool(orc.ended[0]) and final.has_ended
+        # a state made on a pool thread, continued on this one
+        start = pool.submit(config.sample_initial_state).result()
+    nxt = start.action_at(3).sample_next_state()
+    assert nxt.player == 1 and nxt.grid[0, 3] == 0

@@ -224,17 +224,31 @@ def test_connect_full_size_batch(batch_mod):
     np.testing.assert_array_equal(plies, orc.plies)
 
 
-def test_connect_large_board_full_size(batch_mod):
-    """BASELINE config 3: Connect4(12,13,5), batch 2^18."""
-    n = 1 << 18
-    dev = batch_mod.ConnectBatch(12, 13, 5, n)
-    dev.rollout(SEED, from_initial=True)
-    orc = oracle.ConnectOracle(12, 13, 5, n)
-    total = orc.rollout(SEED)
-    assert dev.steps == total
-    np.testing.assert_array_equal(dev.grid, orc.grid)
-    np.testing.assert_array_equal(dev.reward, orc.reward)
-    np.testing.assert_array_equal(dev.plies, orc.plies)
+@pytest.mark.parametrize("opening", ["3", "0"])
+def test_connect_large_board_full_size(batch_mod, opening):
+    """BASELINE config 3: Connect4(12,13,5), batch 2^18 -- with the opening launch (k_connect_open_lds: the first 8 plies
+    of every game, then the LDS-staged kernel picks the boards up from memory) and without it."""
+    import os
+
+    old = os.environ.get("BGS_ROLLOUT_OPENING")
+    os.environ["BGS_ROLLOUT_OPENING"] = opening
+    try:
+        n = 1 << 18
+        dev = batch_mod.ConnectBatch(12, 13, 5, n)
+        dev.set_first_game(3 << 20)
+        dev.rollout(SEED, from_initial=True)
+        orc = oracle.ConnectOracle(12, 13, 5, n)
+        total = orc.rollout(SEED, first_game=3 << 20)
+        assert dev.steps == total
+        np.testing.assert_array_equal(dev.grid, orc.grid)
+        np.testing.assert_array_equal(dev.reward, orc.reward)
+        np.testing.assert_array_equal(dev.plies, orc.plies)
+        dev.close()
+    finally:
+        if old is None:
+            del os.environ["BGS_ROLLOUT_OPENING"]
+        else:
+            os.environ["BGS_ROLLOUT_OPENING"] = old
 
 
 @pytest.mark.parametrize("kernel", ["lds", "registers"])

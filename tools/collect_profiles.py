@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_* (tools/profile_all.sh) -> profiles/r02_*.json, including profiles/r02_rollout_counters.json, the
+"""gpurun_out/prof_* (tools/profile_all.sh) -> profiles/r03_*.json, including profiles/r03_rollout_counters.json, the
 per-launch PMC figures of the bench kernel that bench.py quotes when its build id matches the running library."""
 import json, os, subprocess, sys
 
@@ -24,22 +24,39 @@ def main():
     build = _abi.build_id()
     method = ("tools/profile_all.sh: rocprofv3 --kernel-trace --stats, then --pmc in separate passes (SQ_*; FETCH_SIZE; "
               "WRITE_SIZE), per-dispatch means; FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads), KiB -> B")
-    for tag, want, name in (("bench", "k_connect_rollout_opened", "r02_bench_kernel.json"), ("k1", "step_random", "r02_k1.json"),
-                            ("k2c", "k_connect_rollout_lds", "r02_k2c.json"), ("k2b", "k_connect_rollout_aligned_wide", "r02_k2b.json"),
-                            ("bounce", "k_bounce_rollout", "r02_bounce.json"), ("bounce8", "k_bounce_rollout", "r02_bounce_lane_groups.json")):
-        s = summary(tag, want)
+    for tag, want, name in (("bench", "k_connect_rollout_opened", "r03_bench_kernel.json"), ("k1", "step_random", "r03_k1.json"),
+                            ("k2c", "k_connect_rollout_lds", "r03_k2c.json"), ("k2b", "k_connect_rollout_aligned_wide", "r03_k2b.json"),
+                            ("bounce", "k_bounce", "r03_bounce.json"), ("bounce_k3f", "k_bounce", "r03_bounce_k3f.json"),
+                            ("bounce8", "k_bounce_rollout", "r03_bounce_lane_groups.json")):
+        try:
+            s = summary(tag, want)
+        except Exception as exc:  # a tag that was not profiled in this pass
+            print(f"skipping {tag}: {exc}", file=sys.stderr)
+            continue
+        if not s:
+            continue
         for k in s.values():
             k["hbm_bytes_per_launch"] = hbm_bytes(k)
             if "SQ_THREAD_CYCLES_VALU" in k and k.get("SQ_ACTIVE_INST_VALU"):
                 k["active_lanes_per_valu_instruction"] = k["SQ_THREAD_CYCLES_VALU"] / k["SQ_ACTIVE_INST_VALU"]
+        # one rollout = every kernel of the tag, once per step (Bounce: bulk pass, compaction, tail pass): the per-step
+        # totals are what bench.py quotes for the configuration
+        per_step = max(k.get("dispatches", 1) for k in s.values())
+        total = {"valu_wave_instructions_per_launch": sum(k.get("SQ_INSTS_VALU", 0.0) * k.get("dispatches", per_step) / per_step for k in s.values()),
+                 "hbm_bytes_per_launch": sum(k["hbm_bytes_per_launch"] * k.get("dispatches", per_step) / per_step for k in s.values()),
+                 "kernel_us_per_launch": sum(k.get("mean_us", 0.0) * k.get("dispatches", per_step) / per_step for k in s.values())}
+        lanes = sum(k.get("SQ_THREAD_CYCLES_VALU", 0.0) * k.get("dispatches", 1) for k in s.values())
+        insts = sum(k.get("SQ_ACTIVE_INST_VALU", 0.0) * k.get("dispatches", 1) for k in s.values())
+        if insts:
+            total["active_lanes_per_valu_instruction"] = lanes / insts
         with open(os.path.join(OUT, name), "w") as fh:
-            json.dump({"build_id": build, "method": method, "kernels": s}, fh, indent=1)
+            json.dump(dict({"build_id": build, "method": method}, **total, kernels=s), fh, indent=1)
     misc = summary("misc")
-    with open(os.path.join(OUT, "r02_misc_kernel_stats.json"), "w") as fh:
+    with open(os.path.join(OUT, "r03_misc_kernel_stats.json"), "w") as fh:
         json.dump({"build_id": build, "command": "rocprofv3 --kernel-trace --stats -- python3 tools/measure_all.py", "kernels": misc}, fh, indent=1)
     mfile = os.path.join(ROOT, "gpurun_out", "measure_all.json")
     if os.path.exists(mfile) and os.path.getsize(mfile):
-        with open(mfile) as fh, open(os.path.join(OUT, "r02_secondary_measurements.json"), "w") as out:
+        with open(mfile) as fh, open(os.path.join(OUT, "r03_secondary_measurements.json"), "w") as out:
             out.write(fh.read())
     bench = summary("bench", "k_connect_rollout_opened")
     k = next(iter(bench.values()))
@@ -65,10 +82,10 @@ def main():
         "hbm_bytes_per_launch": hbm_bytes(k),
         "mix_cycles_per_instruction": mix_cpi,
         "mix": mix,
-        "method": method + "; command: python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-device-resident; "
+        "method": method + "; command: python3 bench.py --steps 10 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-device-resident --no-other-configs --no-repeats; "
         "mix_cycles_per_instruction from tools/valu_mix.py",
     }
-    with open(os.path.join(OUT, "r02_rollout_counters.json"), "w") as fh:
+    with open(os.path.join(OUT, "r03_rollout_counters.json"), "w") as fh:
         json.dump(counters, fh, indent=1)
     print(json.dumps({kk: counters[kk] for kk in ("build_id", "valu_wave_instructions_per_launch", "hbm_bytes_per_launch",
                                                   "active_lanes_per_valu_instruction", "mean_us")}))

@@ -1,18 +1,20 @@
 #!/bin/bash
-# Round-2 profiles of every kernel of the path, one command (on the GPU box):  bash tools/profile_all.sh
+# Round-3 profiles of every kernel of the path, one command (on the GPU box):  bash tools/profile_all.sh
 # Each kernel gets rocprofv3 --kernel-trace --stats, an SQ counter pass and separate FETCH_SIZE / WRITE_SIZE passes
 # (tools/profile_kernel.sh: the program directly after "--"); tools/collect_profiles.py turns the CSVs into
-# profiles/r02_*.json and the counters file bench.py reads (keyed by the library's build id).
+# profiles/r03_*.json and the counters file bench.py reads (keyed by the library's build id).
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 # K2a: the bench itself (hand-over included), 12 timed launches in the counter passes
-bash tools/profile_kernel.sh bench python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-device-resident
+bash tools/profile_kernel.sh bench python3 bench.py --steps 10 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-device-resident --no-other-configs --no-repeats
 # K1s: the HBM-bound per-ply kernel at 2^24 boards
 bash tools/profile_kernel.sh k1 python3 tools/k1_steps.py
 # K2c: Connect(12,13,5), 2^18 boards
 bash tools/profile_kernel.sh k2c python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9
-# K3: Bounce 9x6, 2^18 boards, max_plies 4096: the flat kernel (default at this size) and lane-group mode
+# K3: Bounce 9x6, 2^18 boards, max_plies 4096: the piece-list kernel + tail pass (default at this size), the flat cell
+# search it replaces (K3f, one launch) and lane-group mode
 bash tools/profile_kernel.sh bounce python3 tools/rollout_rate.py bounce --depth 1 --reps 6
+BGS_BOUNCE_PIECES=0 BGS_BOUNCE_PLAN=single bash tools/profile_kernel.sh bounce_k3f python3 tools/rollout_rate.py bounce --depth 1 --reps 6
 BGS_BOUNCE_GROUP=8 bash tools/profile_kernel.sh bounce8 python3 tools/rollout_rate.py bounce --depth 1 --reps 6
 # K2b: the register kernel K2c replaced on 12x13x5, for the instruction-count comparison
 BGS_ROLLOUT_NO_LDS=1 bash tools/profile_kernel.sh k2b python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9

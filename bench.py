@@ -52,6 +52,7 @@ import argparse
 import glob
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -219,8 +220,8 @@ def committed_counters(build_id, stem, kernel_substring=None):
             continue
         if "kernels" in c and c.get("valu_wave_instructions_per_launch"):
             # per-step totals over every kernel of the configuration's rollout (Bounce: bulk pass + compaction + tail pass)
-            return dict({k: v for k, v in c.items() if k != "kernels"}, kernel=" + ".join(n.split("(")[0].split("::")[-1] for n in c["kernels"]),
-                        file=os.path.basename(path)), None
+            names = sorted({m.group(0) for n in c["kernels"] for m in [re.search(r"k_[a-z0-9_]+", n)] if m})
+            return dict({k: v for k, v in c.items() if k != "kernels"}, kernel=" + ".join(names), file=os.path.basename(path)), None
         if "kernels" in c:  # per-kernel summaries: pick the kernel
             for name, k in c["kernels"].items():
                 if kernel_substring is None or kernel_substring in name:
@@ -254,7 +255,8 @@ def valu_issue_block(counters, why_not, seconds_per_launch, build):
         out["mix_ceiling"] = {"Ginstr_per_s": mix_peak, "frac": rate / mix_peak,
                               "cycles_per_instruction": counters["mix_cycles_per_instruction"],
                               "basis": "the SIMD-32 peak with this kernel's measured cycles per instruction (tools/valu_mix.py: "
-                              "instruction mix x tools/ubench.hip issue costs) -- a builder model, not a guide figure"}
+                              "instruction mix x tools/ubench.hip issue costs at 4 waves per SIMD) -- a builder model, not a guide "
+                              "figure; a fraction above 1 says the model's per-instruction costs are pessimistic at this occupancy"}
     out["basis"] = ("achieved = wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU on build " + build + ") / the time a "
                     "launch takes in the pipelined loop (ms_per_step: launches overlap); peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 "
                     "cycles per wave64 instruction (MI355X_MICROARCH.md)")
@@ -666,8 +668,9 @@ def main() -> int:
                 break
     run_steps(args.warmup, True)
     drain()
-    # HIP-event pairs bracket a sample of the launches on the launch stream: about 32 pairs
-    stride = max(1, args.steps // 32)
+    # HIP-event pairs bracket a sample of the launches on the launch stream: about 32 pairs (at least every other launch
+    # stays unbracketed: a pair is two marker packets on the stream)
+    stride = max(2, args.steps // int(os.environ.get("BGS_BENCH_PAIRS", "32")))
     elapsed, steps_total, steps_local, kernel_ms = timed_region(args.steps, True, stride)
     last = steps_done() - 1  # index (= seed offset) of the last timed step
 
@@ -713,7 +716,8 @@ def main() -> int:
         build = _abi.build_id()
         counters, why_not = committed_counters(build, "rollout_counters") if n == BATCH_PER_GPU else (None, "counters are for batch 2^20")
         roof = valu_issue_block(counters, why_not, ms_per_step * 1e-3, build)
-        roof["kernel"] = counters["kernel"].split("(")[0].split("::")[-1] if counters and counters.get("kernel") else "k_connect_rollout_opened"
+        named = re.search(r"k_[a-z0-9_]+", counters["kernel"]) if counters and counters.get("kernel") else None
+        roof["kernel"] = named.group(0) if named else "k_connect_rollout_opened"
         roof["kernel_ms_per_launch"] = kernel_ms
         roof["event_pairs"] = len(range(0, args.steps, stride))
         roof["launches_in_flight"] = depth

@@ -11,10 +11,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _line(name):
+    with open(os.path.join(ROOT, "profiles", name)) as fh:
+        return json.loads([ln for ln in fh.read().splitlines() if ln.startswith("{")][-1])
+
+
 def test_committed_bench_line_has_every_contract_field():
-    with open(os.path.join(ROOT, "profiles", "r02_bench.json")) as fh:
-        line = [ln for ln in fh.read().splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    d = _line("r03_bench.json")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -22,28 +25,53 @@ def test_committed_bench_line_has_every_contract_field():
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "u64" and d["n_gpus"] == 1
     assert "Connect4(6,7,4)" in d["metric"] and "workload" in d["config"] and "model" not in d["config"]
     assert d["config"]["rewards_to_host"] is True  # the metric ends with the rewards in a host array
+    assert d["config"]["gather"] == "none" and d["config"]["loop"].startswith("native")
     roof = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
-    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
-    assert 0 < roof["frac"] <= 1.0  # a physical fraction: bytes the kernel really moves over its duration
-    assert roof["pcie"]["frac"] <= 1.0
+    # the binding resource is VALU instruction issue (round-2 review): wave-instructions per second against the SIMD-32 peak
+    assert roof["bound"] == "valu_issue" and roof["unit"] == "Ginstr/s" and roof["peak"] == pytest.approx(1228.8)
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0.3 < roof["frac"] <= 1.0
+    assert roof["kernel"] == "k_connect_rollout_opened" and roof["traffic"] > 1e7
+    assert 0 < roof["hbm"]["frac"] < 0.2 and roof["pcie"]["frac"] <= 1.0 and roof["algorithmic"]["bytes_per_env_step"] == 32
     cpu = d["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "single_game_latency_us"):
         assert key in cpu, key
-    assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1
+    assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and "restatement" in cpu["sample"]
     assert cpu["parity_with_host_rewards"] is True
     assert d["value"] > 1e9  # the north star's floor was 1e9 env-steps/s on EIGHT GPUs
-    assert d["device_resident"]["value"] >= d["value"] * 0.9
-    assert d["value"] >= 0.8 * d["device_resident"]["value"]  # hand-over within 20 % of the device-resident rate
+    assert d["value"] >= 0.9 * d["device_resident"]["value"]  # the hand-over costs less than 10 % of the device-resident rate
+    assert len(d["values_of_3"]) == 3 and d["value"] == d["values_of_3"][0]
+    assert min(d["values_of_3"]) <= d["value_median_of_3"] <= max(d["values_of_3"])
+    for name, floor in (("connect_12x13x5", 1e11), ("bounce_default", 5e9)):   # BASELINE configs 3 and 4 in the same line
+        o = d["other_configs"][name]
+        assert o["parity_with_oracle"] is True and o["value"] > floor and o["solo"]["value"] > 0
+        assert o["valu_issue"]["frac"] is not None and o["valu_issue"]["counters_file"].startswith("r03_")
+    assert d["grids_to_host"]["value"] > 2e10 and d["grids_to_host"]["host_grids_equal_device_grids"] is True
+
+
+def test_short_run_stays_close_to_the_long_one():
+    """The driver times 20 steps: pre-warm, the native loop and the polled last delivery keep that figure within 20 % of
+    the 200-step one (round 2: 13 % below at 5.7e11, with outliers to -40 %), and its three regions within 8 % of each other."""
+    long, short = _line("r03_bench.json"), _line("r03_bench_steps20.json")
+    assert short["steps"] == 20 and short["value"] > 0.8 * long["value"]
+    assert max(short["values_of_3"]) / min(short["values_of_3"]) < 1.08
 
 
 def test_counters_file_names_its_build():
-    with open(os.path.join(ROOT, "profiles", "r02_rollout_counters.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r03_rollout_counters.json")) as fh:
         c = json.load(fh)
     assert len(c["build_id"]) == 16 and c["valu_wave_instructions_per_launch"] > 1e6
     assert 2.0 < c["mix_cycles_per_instruction"] < 6.0
+
+
+def test_sharded_loops_with_one_rank_over_rccl_are_within_reach_of_the_plain_loop():
+    """The N > 1 code paths over the real RCCL with a one-rank world (all a one-GPU box can run): the shared host array
+    costs nothing, the in-library RCCL gather stays within 15 % of it."""
+    plain, shm, rccl = _line("r03_bench.json"), _line("r03_dist_shm.json"), _line("r03_dist_rccl.json")
+    assert shm["config"]["gather"] == "shm" and rccl["config"]["gather"] == "rccl"
+    assert shm["config"]["gathered_rewards_verified"] is True and rccl["config"]["gathered_rewards_verified"] is True
+    assert shm["value"] > 0.95 * plain["value"] and rccl["value"] > 0.85 * shm["value"]
 
 
 def test_bench_starts_ranks_itself_and_relays_their_failure():

@@ -25,7 +25,7 @@ def main():
     method = ("tools/profile_all.sh: rocprofv3 --kernel-trace --stats, then --pmc in separate passes (SQ_*; FETCH_SIZE; "
               "WRITE_SIZE), per-dispatch means; FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads), KiB -> B")
     for tag, want, name in (("bench", "k_connect_rollout_opened", "r03_bench_kernel.json"), ("k1", "step_random", "r03_k1.json"),
-                            ("k2c", "k_connect_rollout_lds", "r03_k2c.json"), ("k2b", "k_connect_rollout_aligned_wide", "r03_k2b.json"),
+                            ("k2c", "_lds", "r03_k2c.json"), ("k2b", "k_connect_rollout_aligned_wide", "r03_k2b.json"),
                             ("bounce", "k_bounce", "r03_bounce.json"), ("bounce_k3f", "k_bounce", "r03_bounce_k3f.json"),
                             ("bounce8", "k_bounce_rollout", "r03_bounce_lane_groups.json")):
         try:

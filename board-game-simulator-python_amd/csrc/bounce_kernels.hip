@@ -856,14 +856,24 @@ __device__ __forceinline__ void move_piece_on(PieceBoard<PMAX>& b, int src_cell,
         b.pos[j] = (k >> 2) == (uint32_t)j ? (b.pos[j] & ~(255u << sh)) | ((uint32_t)dst_cell << sh) : b.pos[j];
 }
 
-// phase A: the landing cells of every piece's segment for `player`, into the lane's LDS column (dwords 3k, 3k + 1 of a
-// [dword][STRIDE lanes] tile; dword 3k + 2: the pieces standing on them)
-template <int PMAX, int STRIDE>
-__device__ __forceinline__ void land_all(const BounceGeom& g, const PieceBoard<PMAX>& b, uint32_t player, uint32_t* lands) {
+// what phase A leaves in REGISTERS (the piece loops are unrolled, so every index below is static): the landing cells of
+// every piece's segment and, per piece, the set of pieces standing on them -- a 16 x 16 bit matrix, two rows to a dword
+template <int PMAX>
+struct Lands {
+    uint64_t v[PMAX];
+    uint32_t adj[PMAX / 2];   // row k (16 bits): bit j = piece j stands on a landing cell of piece k
+};
+
+// phase A: the landing cells of every piece's segment for `player`, and who stands on them
+template <int PMAX>
+__device__ __forceinline__ void land_all(const BounceGeom& g, const PieceBoard<PMAX>& b, uint32_t player, Lands<PMAX>& L) {
     const uint64_t empty_interior = ~b.occ & g.interior;
     const uint32_t up = player ? 0u : (uint32_t)g.w, down = player ? (uint32_t)g.w : 0u;
 #pragma unroll
-    for (int k = 0; k < PMAX; ++k)
+    for (int j = 0; j < PMAX / 2; ++j) L.adj[j] = 0;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k) {
+        L.v[k] = 0;
         if (k < (int)g.piece_count) {
             const uint32_t c = (b.pos[k >> 2] >> (8 * (k & 3))) & 63u;
             const uint32_t v = g.piece_value[k];  // wave-uniform: the step loop below does not diverge
@@ -881,15 +891,27 @@ __device__ __forceinline__ void land_all(const BounceGeom& g, const PieceBoard<P
                     land = nf | nl | nr;
                 }
             }
-            lands[(3 * k) * STRIDE] = (uint32_t)land;
-            lands[(3 * k + 1) * STRIDE] = (uint32_t)(land >> 32);
-            // ... and the pieces it lands ON (a walk that lands on a piece goes on with that piece's segment): bit j =
-            // piece j stands on a landing cell.  The closure of a source is then a search over 16-bit piece sets.
+            L.v[k] = land;
+            // the pieces it lands ON (a walk that lands on a piece goes on with that piece's segment)
             uint32_t hits = 0;
 #pragma unroll
             for (int j = 0; j < PMAX; ++j)
                 if (j < (int)g.piece_count) hits |= (uint32_t)((land >> ((b.pos[j >> 2] >> (8 * (j & 3))) & 63u)) & 1ull) << j;
-            lands[(3 * k + 2) * STRIDE] = hits;
+            L.adj[k >> 1] |= hits << (16 * (k & 1));
+        }
+    }
+}
+
+// phase B, part 1: the transitive closure of "lands on" -- Warshall on the packed rows: for every pivot k, every row
+// that has bit k takes row k in.  A row lives in a 16-bit field, so (fields with bit k) x row_k is one multiply per dword.
+template <int PMAX>
+__device__ __forceinline__ void close_over_bounces(const BounceGeom& g, Lands<PMAX>& L) {
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        if (k < (int)g.piece_count) {
+            const uint32_t row = (L.adj[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+#pragma unroll
+            for (int d = 0; d < PMAX / 2; ++d) L.adj[d] |= ((L.adj[d] >> k) & 0x00010001u) * row;
         }
 }
 
@@ -900,63 +922,53 @@ struct PieceMoves {
     uint32_t reach[kMaxTrackedColumns / 2];
     uint32_t n;
     uint32_t row_base;
-#ifdef BGS_BOUNCE_STATS
-    uint32_t loops;
-#endif
 };
 
-// phase B: counts and closures of `player` for the lanes with `want` set (phase A must have run for this board and
-// player); the other lanes idle through the loops.  The lanes walk their sources in lock step -- trip s of the outer
-// loop is every lane's s-th source -- so that booking a source and opening the next one (25 + 15 instructions) run once
-// per source, not once per closure cell as in one flat loop over (source, cell) pairs.
-template <int PMAX, int STRIDE>
+template <int PMAX>
+__device__ __forceinline__ uint64_t landed_by(const BounceGeom& g, const Lands<PMAX>& L, uint32_t members) {
+    uint64_t targets = 0;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        if (k < (int)g.piece_count) targets |= ((members >> k) & 1u) ? L.v[k] : 0ull;
+    return targets;
+}
+
+// phase B, part 2: per column of the active row, the source's closure and the number of its targets -- for the lanes
+// with `want` set (phases A and B1 must have run for this board and player).  No loop whose trip count depends on the
+// board: every lane does the same work for every column.
+template <int PMAX>
 __device__ __forceinline__ void count_from_lands(const BounceGeom& g, const PieceBoard<PMAX>& b, uint32_t player, bool want,
-                                                 const uint32_t* lands, PieceMoves& m) {
+                                                 const Lands<PMAX>& L, PieceMoves& m) {
     const uint64_t occ = b.occ;
     const uint64_t landing = (~occ & g.interior) | (player ? g.goal_bottom : g.goal_top);
-    uint64_t rem = want ? movable(g, occ, player) : 0ull;   // sources still to search
+    const uint64_t rem = want ? movable(g, occ, player) : 0ull;   // the sources
     const int first = rem ? __ffsll((unsigned long long)rem) - 1 : 0;
     m.row_base = (uint32_t)((int)(((uint32_t)first * g.inv_w) >> 16) * g.w);
     m.counts = 0;
     m.n = 0;
 #pragma unroll
     for (int j = 0; j < kMaxTrackedColumns / 2; ++j) m.reach[j] = 0;
-    while (__builtin_amdgcn_ballot_w64(rem != 0)) {
-        const bool open = rem != 0;
-        const int cell = open ? __ffsll((unsigned long long)rem) - 1 : 0;
-        rem &= rem - 1;
-        const uint32_t x = ((uint32_t)cell - m.row_base) & 7u;
-        uint32_t pending = open ? 1u << piece_on(b, cell) : 0u, members = 0;   // sets of piece indices
-        uint64_t targets = 0;
-        while (__builtin_amdgcn_ballot_w64(pending != 0)) {
-#ifdef BGS_BOUNCE_STATS
-            ++m.loops;
-#endif
-            if (pending) {  // one piece of the closure: its landing cells, and the pieces standing on them
-                const uint32_t k = (uint32_t)__ffs((int)pending) - 1u;
-                pending &= pending - 1u;
-                members |= 1u << k;
-                const uint32_t* entry = lands + (3u * k) * STRIDE;
-                const uint64_t land = ((uint64_t)entry[STRIDE] << 32) | entry[0];
-                targets |= land;
-                pending |= entry[2 * STRIDE] & ~members;
-            }
-        }
-        if (open) {  // book the source
-            const uint32_t cnt = (uint32_t)__popcll(targets & landing);
-            m.counts |= (uint64_t)cnt << (8u * x);
-            m.n += cnt;
-            const uint32_t field = members << (16u * (x & 1u));
 #pragma unroll
-            for (int j = 0; j < kMaxTrackedColumns / 2; ++j) m.reach[j] |= (x >> 1) == (uint32_t)j ? field : 0u;
+    for (int x = 0; x < kMaxTrackedColumns; ++x)
+        if (x < g.w) {
+            const int cell = (int)((m.row_base + (uint32_t)x) & 63u);
+            const bool is_source = (rem >> cell) & 1ull;
+            const uint32_t i = piece_on(b, cell);
+            uint32_t word = 0;
+#pragma unroll
+            for (int d = 0; d < PMAX / 2; ++d) word = (i >> 1) == (uint32_t)d ? L.adj[d] : word;
+            const uint32_t members = is_source ? (((word >> (16u * (i & 1u))) & 0xFFFFu) | (1u << i)) : 0u;
+            const uint32_t cnt = (uint32_t)__popcll(landed_by(g, L, members) & landing);
+            m.counts |= (uint64_t)cnt << (8 * x);
+            m.n += cnt;
+            m.reach[x >> 1] |= members << (16 * (x & 1));
         }
-    }
 }
 
 // the idx-th action of the canonical list: the column from the packed counts, its targets from the closure's landing masks
-template <int PMAX, int STRIDE>
+template <int PMAX>
 __device__ __forceinline__ void pick_from_lands(const BounceGeom& g, const PieceBoard<PMAX>& b, uint32_t player,
-                                                const PieceMoves& m, const uint32_t* lands, uint32_t idx, int& src_cell,
+                                                const PieceMoves& m, const Lands<PMAX>& L, uint32_t idx, int& src_cell,
                                                 int& dst_cell) {
     uint32_t col = 0;
     bool found = false;
@@ -973,15 +985,8 @@ __device__ __forceinline__ void pick_from_lands(const BounceGeom& g, const Piece
 #pragma unroll
     for (int j = 0; j < kMaxTrackedColumns / 2; ++j) word = (col >> 1) == (uint32_t)j ? m.reach[j] : word;
     const uint32_t members = (word >> (16u * (col & 1u))) & 0xFFFFu;
-    uint64_t targets = 0;
-#pragma unroll
-    for (int k = 0; k < PMAX; ++k)
-        if (k < (int)g.piece_count) {
-            const uint64_t land = ((uint64_t)lands[(3 * k + 1) * STRIDE] << 32) | lands[(3 * k) * STRIDE];
-            targets |= ((members >> k) & 1u) ? land : 0ull;
-        }
     const uint64_t landing = (~b.occ & g.interior) | (player ? g.goal_bottom : g.goal_top);
-    dst_cell = (int)select_bit64(targets & landing, idx);
+    dst_cell = (int)select_bit64(landed_by(g, L, members) & landing, idx);
 }
 
 template <int PMAX, int BLOCK>
@@ -1002,9 +1007,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                         uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
                         unsigned long long* __restrict__ steps, uint32_t chunk, uint32_t* __restrict__ queue, uint32_t park_at) {
-    extern __shared__ uint32_t land_tile[];               // [3 * PMAX dwords][BLOCK lanes]
     __shared__ ParkedPieces<PMAX, BLOCK> parked;
-    uint32_t* const lands = land_tile + threadIdx.x;      // this lane's dword column
+    Lands<PMAX> lands;   // (registers; valid from a ply's search to its move)
     constexpr uint32_t WAVES = ParkedPieces<PMAX, BLOCK>::WAVES;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1048,7 +1052,6 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
 
 #ifdef BGS_BOUNCE_STATS
     uint32_t stat_iters = 0, stat_search = 0, stat_drain_iters = 0;
-    mv.loops = 0;
 #endif
     for (;;) {
 #ifdef BGS_BOUNCE_STATS
@@ -1130,18 +1133,20 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
 #ifdef BGS_BOUNCE_STATS
             ++stat_search;
 #endif
-            land_all<PMAX, BLOCK>(g, b, plies & 1u, lands);
-            count_from_lands<PMAX, BLOCK>(g, b, plies & 1u, search, lands, mv);
+            land_all<PMAX>(g, b, plies & 1u, lands);
+            close_over_bounces<PMAX>(g, lands);
+            count_from_lands<PMAX>(g, b, plies & 1u, search, lands, mv);
             const bool blocked = search && mv.n == 0u;
             if (__builtin_amdgcn_ballot_w64(blocked)) {
-                // the other side wins if IT could move, else a draw (Appendix B rule 7)
+                // the other side wins if IT could move, else a draw (Appendix B rule 7).  Rare (1.2 % of the games end
+                // that way), so the other lanes' masks are simply recomputed afterwards: the move below needs them
                 PieceMoves other;
-                land_all<PMAX, BLOCK>(g, b, 1u - (plies & 1u), lands);
-                count_from_lands<PMAX, BLOCK>(g, b, 1u - (plies & 1u), blocked, lands, other);
+                land_all<PMAX>(g, b, 1u - (plies & 1u), lands);
+                close_over_bounces<PMAX>(g, lands);
+                count_from_lands<PMAX>(g, b, 1u - (plies & 1u), blocked, lands, other);
                 if (blocked) st = other.n ? (1u - (plies & 1u)) + 1u : BGS_ST_DRAW;
-                // (a blocked board stops here, and the others' landing masks are recomputed: phase A of the side to
-                // move must be in LDS when the move is picked)
-                land_all<PMAX, BLOCK>(g, b, plies & 1u, lands);
+                land_all<PMAX>(g, b, plies & 1u, lands);
+                close_over_bounces<PMAX>(g, lands);
             }
             search = false;
         }
@@ -1199,7 +1204,7 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
             }
             const uint32_t mover = plies & 1u;
             int s, t;
-            pick_from_lands<PMAX, BLOCK>(g, b, mover, mv, lands, sample_index(philox_word(blk, plies), mv.n), s, t);
+            pick_from_lands<PMAX>(g, b, mover, mv, lands, sample_index(philox_word(blk, plies), mv.n), s, t);
             move_piece_on(b, s, t);
             ++plies;
             if ((1ull << t) & (g.goal_top | g.goal_bottom)) st = mover + 1u;  // (stored and freed next iteration)
@@ -1211,7 +1216,6 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
         atomicAdd(steps + 1, (unsigned long long)stat_iters);
         atomicAdd(steps + 2, (unsigned long long)stat_search);
         atomicAdd(steps + 3, (unsigned long long)stat_drain_iters);
-        atomicAdd(steps + 4, (unsigned long long)mv.loops);
     }
 #endif
     add_steps(steps, stepped);
@@ -1422,7 +1426,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
     auto launch_pieces = [&](auto pmax_tag, auto block_tag) {
         constexpr int PMAX = decltype(pmax_tag)::value;
         constexpr int BLOCK = decltype(block_tag)::value;
-        const size_t tile = (size_t)3 * PMAX * BLOCK * sizeof(uint32_t);
+        const size_t tile = 0;  // (the landing masks live in registers; LDS only holds the parked boards)
         const uint32_t chunk = (uint32_t)b->bounce_flat_chunk;
         // Every ply costs a wave the same whatever the number of its lanes that still hold a game, so what counts is how
         // full the waves stay: few, long-lived waves (kBounceBoardsPerWave boards each, drawn from the queue) spend most

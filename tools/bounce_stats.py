@@ -18,6 +18,6 @@ for i in range(3):
     w = b.steps_tensor().cpu().numpy()
     steps = int(w[::8].sum())
     out.append({"env_steps": steps, "wave_iterations": int(w[1]), "with_search": int(w[2]), "draining": int(w[3]),
-                "closure_loop_trips": int(w[4]), "boards_per_iteration": steps / max(int(w[1]), 1),
-                "closure_trips_per_search": int(w[4]) / max(int(w[2]), 1)})
+                "boards_per_iteration": steps / max(int(w[1]), 1),
+                "searches_per_iteration": int(w[2]) / max(int(w[1]), 1)})
 print(json.dumps(out, indent=1))

@@ -249,6 +249,7 @@ def valu_issue_block(counters, why_not, seconds_per_launch, build):
         "wave_instr_per_launch": instr,
         "active_lanes_per_valu_instruction": counters.get("active_lanes_per_valu_instruction"),
         "counters_file": counters.get("file"),
+        "kernels": counters.get("kernel"),
     }
     if counters.get("mix_cycles_per_instruction"):
         mix_peak = VALU_PEAK_SIMD32 * 2.0 / counters["mix_cycles_per_instruction"]
@@ -544,7 +545,8 @@ def main() -> int:
     # Shared array: the consumer rank's launch loop also waits for EVERY rank's delivery of hand-over j - lag before it
     # enqueues hand-over j, so it runs `lag`, not `host_slots`, steps ahead of the deliveries: one more array per stream
     # keeps lag at 3 per stream (a delivery -> futex wake-up -> enqueue chain takes ~100 us, 3 steps' worth).
-    factor = int(os.environ.get("BGS_BENCH_SLOT_FACTOR", "4" if ring_mode else "3"))
+    # (the in-library gather sends the codes of slots / 2 steps in one group of point-to-point calls: 12 arrays, groups of 6)
+    factor = int(os.environ.get("BGS_BENCH_SLOT_FACTOR", "4" if ring_mode or lib_gather else "3"))
     host_slots = max(2, factor * depth)
     ring = None
     if ring_mode:

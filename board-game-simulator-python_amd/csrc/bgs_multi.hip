@@ -196,7 +196,8 @@ struct bgs_gather {
     size_t code_bytes = 0;    // n / 4: what a rank contributes per step
     bool direct = true;       // rank 0 receives straight into the sink's device-mapped slot; BGS_GATHER_DIRECT=0: into
                               // device memory, and a copy kernel takes the gathered codes to the slot
-    int batch = 3;            // steps per group of point-to-point calls (BGS_GATHER_BATCH; at most `slots`)
+    int batch = 0;            // steps per group of point-to-point calls: slots / 2 (BGS_GATHER_BATCH overrides; the launching
+                              // thread runs `slots` steps ahead, so half of them can wait for their group to fill)
     int64_t flush_upto = 0;   // somebody waits for a step below this: send partial groups
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;        // everything RCCL does for this rank is enqueued here
@@ -322,7 +323,9 @@ int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_
         const int v = atoi(e);
         if (v >= 1) g->batch = v;
     }
+    if (g->batch <= 0) g->batch = slots / 2;
     if (g->batch > slots) g->batch = slots;
+    if (g->batch < 1) g->batch = 1;
     g->host.assign(slots, nullptr);
     int rc = BGS_OK;
     hipError_t he = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);

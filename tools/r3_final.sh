@@ -13,11 +13,12 @@ env $D MASTER_PORT=$((29500 + RANDOM % 400)) python bench.py --gpus 1 --gather $
 done
 env $D MASTER_PORT=$((29500 + RANDOM % 400)) BGS_GATHER_BATCH=6 BGS_BENCH_SLOT_FACTOR=4 python bench.py --gpus 1 --gather rccl --no-cpu-baseline > gpurun_out/r03_dist_rccl_batch6.json 2> gpurun_out/r03_dist_rccl_batch6.err
 BGS_DIST_BACKEND=gloo python bench.py --gpus 3 --steps 40 --batch 262144 > gpurun_out/r03_selfstart_gloo3.json 2> gpurun_out/r03_selfstart_gloo3.err
+BGS_DIST_BACKEND=gloo python bench.py --gpus 6 --steps 40 --batch 131072 --host-threads 2 > gpurun_out/r03_selfstart_gloo6.json 2> gpurun_out/r03_selfstart_gloo6.err
 python tools/object_latency.py > gpurun_out/r03_object_latency.json 2>/dev/null
 ( echo "["; python tools/rollout_rate.py connect6x7 --depth 3 --reps 90 2>/dev/null; echo ","; python tools/rollout_rate.py connect12x13 --depth 3 --reps 60 2>/dev/null; echo ","; python tools/rollout_rate.py bounce --depth 16 --reps 64 2>/dev/null; echo ","; BGS_BOUNCE_PIECES=0 BGS_BOUNCE_PLAN=single python tools/rollout_rate.py bounce --depth 16 --reps 64 2>/dev/null; echo "]" ) > gpurun_out/r03_rollout_rates.json
 python - <<'PY'
 import json
-for f in ("r03_bench","r03_bench_steps20","r03_dist_shm","r03_dist_rccl","r03_dist_rccl_batch6","r03_selfstart_gloo3"):
+for f in ("r03_bench","r03_bench_steps20","r03_dist_shm","r03_dist_rccl","r03_dist_rccl_batch6","r03_selfstart_gloo3","r03_selfstart_gloo6"):
     try:
         d=json.loads([l for l in open(f"gpurun_out/{f}.json") if l.startswith("{")][-1])
         print(f, "%.3e"%d["value"], d["ms_per_step"], d.get("values_of_3"), d["roofline"].get("frac"), d["config"].get("gather"), d["config"].get("gathered_rewards_verified"))

@@ -477,6 +477,9 @@ def main() -> int:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         return launch_ranks(args.gpus)  # (before anything here has touched the GPU)
 
+    from simulator.game import _abi  # (first: asks for more hardware queues before torch brings the HIP runtime up)
+
+    _abi._more_hardware_queues()
     import numpy as np
     import torch
 
@@ -502,7 +505,6 @@ def main() -> int:
     sharded = world > 1 or os.environ.get("BGS_FORCE_DIST") == "1"
 
     from simulator.batch import ConnectBatch, RewardSink, expand_outcomes_host
-    from simulator.game import _abi
     from simulator.pipeline import RolloutExecutor
     from simulator.sharding import RewardGather, SharedRewardRing, gather_outcomes_to, shard_range, sum_steps
 

@@ -200,15 +200,29 @@ def _more_hardware_queues() -> None:
     global hw_queues_too_late
     if "GPU_MAX_HW_QUEUES" in os.environ:
         return
-    torch = sys.modules.get("torch")
-    try:
-        initialised = torch is not None and torch.cuda.is_initialized()
-    except Exception:  # noqa: BLE001
-        initialised = False
-    if initialised:
+    if _gpu_runtime_is_up():
         hw_queues_too_late = True
     else:
         os.environ["GPU_MAX_HW_QUEUES"] = str(HW_QUEUES_WANTED)
+
+
+def _gpu_runtime_is_up() -> bool:
+    """Has anything in this process initialised the HIP / HSA runtime yet?  The runtime opens /dev/kfd when it comes up
+    (`torch.cuda.is_available()` is enough; torch's own `is_initialized()` does not tell)."""
+    try:
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                if os.readlink(f"/proc/self/fd/{fd}") == "/dev/kfd":
+                    return True
+            except OSError:
+                continue
+    except OSError:
+        pass
+    torch = sys.modules.get("torch")
+    try:
+        return torch is not None and torch.cuda.is_initialized()
+    except Exception:  # noqa: BLE001
+        return False
 
 
 def hardware_queues() -> int:

@@ -295,3 +295,43 @@ def test_grid_sink_delivers_the_boards_of_every_step(case):
     np.testing.assert_array_equal(g, orc.grid)
     rs.close()
     gs.close()
+
+
+def test_rollout_pipeline_refuses_a_depth_it_cannot_deliver():
+    """More than 4 batches in flight need more than the HIP runtime's default 4 hardware queues, which can only be asked
+    for before the runtime comes up: a process that initialised HIP first gets a loud error for depth 16, not 4-wide
+    execution; importing `simulator` first (what every other test process does) makes the default Bounce depth work."""
+    code_late = (
+        "import sys, os; sys.path[:0] = [%r, %r]\n"
+        "os.environ.pop('GPU_MAX_HW_QUEUES', None)\n"
+        "import torch; assert torch.cuda.is_available()\n"          # the HIP runtime is up, with 4 queues
+        "import numpy as np\n"
+        "from simulator.batch import BounceBatch\n"
+        "from simulator.pipeline import RolloutPipeline\n"
+        "from simulator.game import _abi\n"
+        "assert _abi.hw_queues_too_late and _abi.hardware_queues() == 4\n"
+        "g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]\n"
+        "try:\n"
+        "    RolloutPipeline(BounceBatch, (g,), 512)\n"
+        "    raise SystemExit('depth 16 on 4 hardware queues was accepted')\n"
+        "except RuntimeError as exc:\n"
+        "    assert 'GPU_MAX_HW_QUEUES' in str(exc)\n"
+        "with RolloutPipeline(BounceBatch, (g,), 512, depth=3, max_plies=200) as pipe:\n"
+        "    assert len(list(pipe.run(range(4)))) == 4\n"
+        "print('LATE_OK')\n" % (ROOT, PKG))
+    code_early = (
+        "import sys, os; sys.path[:0] = [%r, %r]\n"
+        "os.environ.pop('GPU_MAX_HW_QUEUES', None)\n"
+        "import numpy as np\n"
+        "import simulator\n"                                          # asks for 32 queues before anything touches the GPU
+        "from simulator.batch import BounceBatch\n"
+        "from simulator.pipeline import RolloutPipeline\n"
+        "from simulator.game import _abi\n"
+        "assert os.environ['GPU_MAX_HW_QUEUES'] == '32' and not _abi.hw_queues_too_late\n"
+        "g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]\n"
+        "with RolloutPipeline(BounceBatch, (g,), 512, max_plies=200) as pipe:\n"
+        "    assert pipe.depth == 16 and len(list(pipe.run(range(20)))) == 20\n"
+        "print('EARLY_OK')\n" % (ROOT, PKG))
+    for code, word in ((code_late, "LATE_OK"), (code_early, "EARLY_OK")):
+        proc = subprocess.run(["timeout", "-k", "10", "300", sys.executable, "-c", code], capture_output=True, text=True)
+        assert proc.returncode == 0 and word in proc.stdout, proc.stdout[-1500:] + proc.stderr[-3000:]

@@ -144,3 +144,50 @@ def test_bounce_random_grid(case):
     again = BounceBatch(grid, n)
     assert (again.write_state(orc.grid, orc.player, orc.winner, orc.plies) == 0).all()
     same(again, orc, what + " reloaded")
+
+
+def random_piece_list_grid(rng):
+    """A start grid the piece-list kernel takes: at most 8 columns and 16 pieces (values 1..15, a few cells each)."""
+    while True:
+        h, w = int(rng.integers(3, 12)), int(rng.integers(1, 9))
+        if h * w <= 64:
+            break
+    grid = np.zeros((h, w), dtype=np.int8)
+    cells = [(y, x) for y in range(1, h - 1) for x in range(w)]
+    pieces = int(rng.integers(1, min(16, len(cells)) + 1))
+    max_value = int(rng.choice([1, 2, 3, 3, 3, 4, 6, 15]))
+    for k in rng.choice(len(cells), size=pieces, replace=False):
+        y, x = cells[int(k)]
+        grid[y, x] = int(rng.integers(1, max_value + 1))
+    return grid
+
+
+@pytest.mark.parametrize("case", range(max(24, EXTRA)))
+def test_bounce_piece_list_random_grid(case):
+    """K3p (one lane per board on the piece list; the 8-, 12- and 16-piece instantiations, the bulk + tail plan for caps
+    beyond 768 plies, parked boards) against the oracle on random start grids, batch sizes around the wave / workgroup
+    boundaries, random first-game offsets."""
+    from simulator.batch import BounceBatch
+
+    rng = np.random.default_rng(9000 + case)
+    grid = random_piece_list_grid(rng)
+    n = int(rng.choice([1, 63, 64, 65, 255, 257, 1000, 2500, 6000]))
+    first = int(rng.integers(0, 1 << 40))
+    cap = int(rng.choice([0, 1, 7, 60, 500, 769, 2000]))
+    old = os.environ.get("BGS_BOUNCE_GROUP")
+    os.environ["BGS_BOUNCE_GROUP"] = "1"
+    try:
+        dev = BounceBatch(grid, n)
+        orc = oracle.BounceOracle(grid, n)
+        dev.set_first_game(first)
+        what = f"piece-list bounce {grid.shape} {int((grid > 0).sum())} pieces n={n} cap={cap} case {case}"
+        dev.rollout(SEED ^ case, max_plies=cap, from_initial=True)
+        total = orc.rollout(SEED ^ case, first_game=first, max_plies=cap)
+        same(dev, orc, what)
+        assert dev.steps == total, what
+        dev.close()
+    finally:
+        if old is None:
+            del os.environ["BGS_BOUNCE_GROUP"]
+        else:
+            os.environ["BGS_BOUNCE_GROUP"] = old

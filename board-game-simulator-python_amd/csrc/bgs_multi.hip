@@ -109,77 +109,123 @@ __global__ void __launch_bounds__(256) k_codes_to_slot(const uint4* __restrict__
 
 }  // namespace
 
-extern "C" int bgs_multi_connect_rollout(const int* devices, int n_devices, int height, int width, int count,
-                                         int64_t n_per_device, uint64_t seed, int8_t* host_reward, uint64_t* steps) {
-    NEED(devices != nullptr && host_reward != nullptr, "NULL argument");
+// Several GPUs of one node from ONE process: batches, streams, code buffers and the communicators (ncclCommInitAll) live
+// as long as the handle; a rollout is launches on every device, one group of point-to-point calls, one copy, one host
+// expansion.
+struct bgs_multi {
+    std::vector<int> devices;
+    int64_t n = 0;               // games per device
+    size_t code_bytes = 0;
+    std::vector<bgs_batch*> batch;
+    std::vector<hipStream_t> stream;
+    std::vector<uint8_t*> codes;      // per device: this device's outcome codes
+    std::vector<ncclComm_t> comm;
+    uint8_t* gathered = nullptr;      // on devices[0]: the codes of all devices, in global game order
+    uint8_t* host_codes = nullptr;    // page-locked
+    bool have_comms = false;
+};
+
+extern "C" int bgs_multi_destroy(bgs_multi* m) {
+    if (!m) return BGS_OK;
+    for (size_t r = 0; r < m->devices.size(); ++r) {
+        (void)hipSetDevice(m->devices[r]);
+        if (r < m->stream.size() && m->stream[r]) (void)hipStreamSynchronize(m->stream[r]);
+        if (m->have_comms && r < m->comm.size() && m->comm[r]) (void)rccl().CommDestroy(m->comm[r]);
+        if (r < m->batch.size() && m->batch[r]) (void)bgs_destroy(m->batch[r]);
+        if (r < m->codes.size() && m->codes[r]) (void)hipFree(m->codes[r]);
+        if (r < m->stream.size() && m->stream[r]) (void)hipStreamDestroy(m->stream[r]);
+    }
+    if (!m->devices.empty()) (void)hipSetDevice(m->devices[0]);
+    if (m->gathered) (void)hipFree(m->gathered);
+    if (m->host_codes) (void)hipHostFree(m->host_codes);
+    delete m;
+    return BGS_OK;
+}
+
+extern "C" int bgs_multi_create(const int* devices, int n_devices, int height, int width, int count, int64_t n_per_device,
+                                bgs_multi** out) {
+    NEED(out != nullptr && devices != nullptr, "NULL argument");
+    *out = nullptr;
     NEED(n_devices >= 1 && n_devices <= 64, "n_devices must be in 1..64");
     NEED(n_per_device >= 4 && (n_per_device & 3) == 0, "n_per_device must be a positive multiple of 4 (4 outcome codes per byte)");
     NEED(rccl().ok, "RCCL (librccl.so) is not available: %s", rccl().why.c_str());
-    const size_t code_bytes = (size_t)n_per_device / 4;
-    std::vector<bgs_batch*> batch(n_devices, nullptr);
-    std::vector<hipStream_t> stream(n_devices, nullptr);
-    std::vector<uint8_t*> codes(n_devices, nullptr);
-    std::vector<ncclComm_t> comm(n_devices, nullptr);
-    uint8_t* gathered = nullptr;   // on devices[0]: the codes of all devices, in global game order
-    uint8_t* host_codes = nullptr; // page-locked
-    bool have_comms = false;
-    uint64_t total = 0;
+    bgs_multi* m = new (std::nothrow) bgs_multi();
+    NEED(m != nullptr, "out of host memory");
+    m->devices.assign(devices, devices + n_devices);
+    m->n = n_per_device;
+    m->code_bytes = (size_t)n_per_device / 4;
+    m->batch.assign(n_devices, nullptr);
+    m->stream.assign(n_devices, nullptr);
+    m->codes.assign(n_devices, nullptr);
+    m->comm.assign(n_devices, nullptr);
     int rc = BGS_OK;
-
-    for (int r = 0; r < n_devices && rc == BGS_OK; ++r) {
+    for (int r = 0; r < n_devices; ++r) {
         HIP_GO(hipSetDevice(devices[r]));
-        HIP_GO(hipStreamCreateWithFlags(&stream[r], hipStreamNonBlocking));
-        rc = bgs_connect_create(height, width, count, n_per_device, devices[r], nullptr, 0, &batch[r]);
-        if (rc) goto done;
-        if ((rc = bgs_set_stream(batch[r], stream[r]))) goto done;
-        if ((rc = bgs_set_first_game(batch[r], (uint64_t)r * (uint64_t)n_per_device))) goto done;
-        HIP_GO(hipMalloc(reinterpret_cast<void**>(&codes[r]), code_bytes));
+        HIP_GO(hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking));
+        if ((rc = bgs_connect_create(height, width, count, n_per_device, devices[r], nullptr, 0, &m->batch[r]))) goto done;
+        if ((rc = bgs_set_stream(m->batch[r], m->stream[r]))) goto done;
+        if ((rc = bgs_set_first_game(m->batch[r], (uint64_t)r * (uint64_t)n_per_device))) goto done;
+        HIP_GO(hipMalloc(reinterpret_cast<void**>(&m->codes[r]), (size_t)(n_per_device + 63) / 64 * 16));
     }
     HIP_GO(hipSetDevice(devices[0]));
-    HIP_GO(hipMalloc(reinterpret_cast<void**>(&gathered), code_bytes * n_devices));
-    HIP_GO(hipHostMalloc(reinterpret_cast<void**>(&host_codes), code_bytes * n_devices, hipHostMallocDefault));
-    NCCL_TRY(rccl().CommInitAll(comm.data(), n_devices, devices));
-    have_comms = true;
+    HIP_GO(hipMalloc(reinterpret_cast<void**>(&m->gathered), m->code_bytes * n_devices));
+    HIP_GO(hipHostMalloc(reinterpret_cast<void**>(&m->host_codes), m->code_bytes * n_devices, hipHostMallocDefault));
+    NCCL_TRY(rccl().CommInitAll(m->comm.data(), n_devices, devices));
+    m->have_comms = true;
+done:
+    if (rc != BGS_OK) {
+        (void)bgs_multi_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return BGS_OK;
+}
 
-    // every device plays its shard and packs its outcomes; all launches are enqueued before anything is waited for
+extern "C" int bgs_multi_rollout(bgs_multi* m, uint64_t seed, int8_t* host_reward, uint64_t* steps) {
+    NEED(m != nullptr && host_reward != nullptr, "NULL argument");
+    const int n_devices = (int)m->devices.size();
+    uint64_t total = 0;
+    int rc = BGS_OK;
+    // every device plays its shard (the rollout kernel writes the outcome codes itself); all launches are enqueued before
+    // anything is waited for
     for (int r = 0; r < n_devices; ++r) {
-        if ((rc = bgs_rollout(batch[r], seed, 0x7FFFFFFF, BGS_ROLLOUT_FROM_INITIAL))) goto done;
-        if ((rc = bgs_pack_outcomes(batch[r], codes[r]))) goto done;
+        if ((rc = bgs_reset_steps(m->batch[r]))) goto done;
+        if ((rc = bgs_rollout_pack(m->batch[r], seed, 0x7FFFFFFF, BGS_ROLLOUT_FROM_INITIAL, m->codes[r]))) goto done;
     }
     // the gather: one group of point-to-point calls, device r -> device 0, each on its own stream behind its rollout
     NCCL_TRY(rccl().GroupStart());
     for (int r = 0; r < n_devices; ++r) {
-        HIP_GO(hipSetDevice(devices[r]));
-        NCCL_TRY(rccl().Send(codes[r], code_bytes, kNcclUint8, 0, comm[r], stream[r]));
+        HIP_GO(hipSetDevice(m->devices[r]));
+        NCCL_TRY(rccl().Send(m->codes[r], m->code_bytes, kNcclUint8, 0, m->comm[r], m->stream[r]));
     }
-    HIP_GO(hipSetDevice(devices[0]));
+    HIP_GO(hipSetDevice(m->devices[0]));
     for (int r = 0; r < n_devices; ++r)
-        NCCL_TRY(rccl().Recv(gathered + (size_t)r * code_bytes, code_bytes, kNcclUint8, r, comm[0], stream[0]));
+        NCCL_TRY(rccl().Recv(m->gathered + (size_t)r * m->code_bytes, m->code_bytes, kNcclUint8, r, m->comm[0], m->stream[0]));
     NCCL_TRY(rccl().GroupEnd());
-    HIP_GO(hipMemcpyAsync(host_codes, gathered, code_bytes * n_devices, hipMemcpyDeviceToHost, stream[0]));
+    HIP_GO(hipMemcpyAsync(m->host_codes, m->gathered, m->code_bytes * n_devices, hipMemcpyDeviceToHost, m->stream[0]));
     for (int r = 0; r < n_devices; ++r) {
-        HIP_GO(hipSetDevice(devices[r]));
-        HIP_GO(hipStreamSynchronize(stream[r]));
+        HIP_GO(hipSetDevice(m->devices[r]));
+        HIP_GO(hipStreamSynchronize(m->stream[r]));
     }
-    if ((rc = bgs_expand_outcomes_host(host_codes, 0, n_per_device * n_devices, host_reward))) goto done;
+    if ((rc = bgs_expand_outcomes_host(m->host_codes, 0, m->n * n_devices, host_reward))) goto done;
     for (int r = 0; r < n_devices; ++r) {
         uint64_t s = 0;
-        if ((rc = bgs_steps(batch[r], &s))) goto done;
+        if ((rc = bgs_steps(m->batch[r], &s))) goto done;
         total += s;
     }
     if (steps) *steps = total;
-
 done:
-    for (int r = 0; r < n_devices; ++r) {
-        (void)hipSetDevice(devices[r]);
-        if (have_comms && comm[r]) (void)rccl().CommDestroy(comm[r]);
-        if (batch[r]) (void)bgs_destroy(batch[r]);
-        if (codes[r]) (void)hipFree(codes[r]);
-        if (stream[r]) (void)hipStreamDestroy(stream[r]);
-    }
-    (void)hipSetDevice(devices[0]);
-    if (gathered) (void)hipFree(gathered);
-    if (host_codes) (void)hipHostFree(host_codes);
+    return rc;
+}
+
+extern "C" int bgs_multi_connect_rollout(const int* devices, int n_devices, int height, int width, int count,
+                                         int64_t n_per_device, uint64_t seed, int8_t* host_reward, uint64_t* steps) {
+    NEED(host_reward != nullptr, "NULL argument");
+    bgs_multi* m = nullptr;
+    int rc = bgs_multi_create(devices, n_devices, height, width, count, n_per_device, &m);
+    if (rc) return rc;
+    rc = bgs_multi_rollout(m, seed, host_reward, steps);
+    (void)bgs_multi_destroy(m);
     return rc;
 }
 

@@ -155,6 +155,12 @@ SIGNATURES = {
         [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,
          ctypes.c_void_p, _u64p],
     ),
+    "bgs_multi_create": (
+        ctypes.c_int,
+        [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(c_handle)],
+    ),
+    "bgs_multi_rollout": (ctypes.c_int, [c_handle, ctypes.c_uint64, ctypes.c_void_p, _u64p]),
+    "bgs_multi_destroy": (ctypes.c_int, [c_handle]),
     "bgs_write_state": (ctypes.c_int, [c_handle, _i8p, _i8p, _i8p, _i32p, _i32p]),
 }
 

@@ -266,6 +266,43 @@ def sum_steps(dist, local_steps: int, device) -> int:
     return int(t.item())
 
 
+class MultiDeviceRollout:
+    """Connect rollouts sharded over several GPUs of this node from ONE process, without torch.distributed, with the
+    batches, streams and RCCL communicators kept between steps (`bgs_multi_create / rollout / destroy`)."""
+
+    def __init__(self, devices, height: int, width: int, count: int, n_per_device: int):
+        import ctypes
+
+        self.devices = [int(d) for d in devices]
+        self.n_per_device = int(n_per_device)
+        devs = (ctypes.c_int * len(self.devices))(*self.devices)
+        self._handle = _abi.c_handle()
+        _abi.check(_abi.lib().bgs_multi_create(devs, len(self.devices), height, width, count, self.n_per_device, ctypes.byref(self._handle)))
+
+    def rollout(self, seed: int, out=None):
+        """One step: returns (reward int8[len(devices) * n_per_device, 2] in global game order, env-steps)."""
+        import ctypes
+
+        import numpy as np
+
+        if out is None:
+            out = np.empty((len(self.devices) * self.n_per_device, 2), dtype=np.int8)
+        steps = ctypes.c_uint64(0)
+        _abi.check(_abi.lib().bgs_multi_rollout(self._handle, ctypes.c_uint64(seed), ctypes.c_void_p(out.ctypes.data), ctypes.byref(steps)))
+        return out, steps.value
+
+    def close(self) -> None:
+        if self._handle:
+            _abi.lib().bgs_multi_destroy(self._handle)
+            self._handle = _abi.c_handle()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def multi_device_rollout(devices, height: int, width: int, count: int, n_per_device: int, seed: int):
     """Connect rollouts sharded over several GPUs of this node from ONE process, without torch.distributed:
     `bgs_multi_connect_rollout` (RCCL point-to-point gather of the outcome codes to devices[0], one copy to the host).

@@ -300,6 +300,13 @@ int bgs_pipeline_destroy(bgs_pipeline* p);
  * streams and communicators live for the call.  RCCL is loaded on first use (dlopen "librccl.so.1"). */
 int bgs_multi_connect_rollout(const int* devices, int n_devices, int height, int width, int count, int64_t n_per_device,
                               uint64_t seed, int8_t* host_reward, uint64_t* steps);
+/* the same with everything kept between calls -- batches, streams, code buffers and the communicators (ncclCommInitAll)
+ * live as long as the handle: bgs_multi_rollout plays one step (seed) on every device and returns with host_reward
+ * int8[n_devices * n_per_device][2] filled and *steps = the step's env-steps */
+typedef struct bgs_multi bgs_multi;
+int bgs_multi_create(const int* devices, int n_devices, int height, int width, int count, int64_t n_per_device, bgs_multi** out);
+int bgs_multi_rollout(bgs_multi* m, uint64_t seed, int8_t* host_reward, uint64_t* steps);
+int bgs_multi_destroy(bgs_multi* m);
 
 /* ---- loading boards (State::from_json, connect.cpp:46 / bounce.cpp:45; policy-driven stepping) ---- */
 /* grid int8[n][h][w]; player int8[n] (Connect: may be NULL, derived from the stone counts); winner int8[n]

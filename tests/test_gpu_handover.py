@@ -199,7 +199,7 @@ sys.path[:0] = [{root!r}, {pkg!r}]
 import numpy as np
 from oracle import oracle
 from simulator.game import _abi
-from simulator.sharding import multi_device_rollout
+from simulator.sharding import MultiDeviceRollout, multi_device_rollout
 devices = list(range(min(_abi.device_count(), 2)))
 n, seed = 40000, 0x0123456789ABCDEF + 5
 reward, steps = multi_device_rollout(devices, 6, 7, 4, n, seed)
@@ -211,6 +211,14 @@ try:
     raise SystemExit("n_per_device = 1001 was accepted")
 except ValueError:
     pass
+# the same with batches, streams and communicators kept between steps
+multi = MultiDeviceRollout(devices, 6, 7, 4, n)
+for k in range(4):
+    reward, steps = multi.rollout(seed + 10 + k)
+    whole.reset()
+    assert whole.rollout(seed + 10 + k) == steps
+    assert np.array_equal(reward, whole.reward), k
+multi.close()
 print("MULTI_OK", len(devices), steps)
 """
 

@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
 import numpy as np
 import torch
-from simulator.batch import BounceBatch, ConnectBatch, HostEvent, PinnedArray, RewardSink
+from simulator.batch import BounceBatch, ConnectBatch, GridSink, HostEvent, PinnedArray, RewardSink
+from simulator.pipeline import RolloutExecutor
 
 SEED = 0x0123456789ABCDEF
 g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]
@@ -28,7 +29,14 @@ for it in range(160):
     sink.wait(ticket)
     c.read_reward_async(pin, ev); ev.synchronize()
     assert np.array_equal(pin.array, host) and np.array_equal(c.reward, host)
-    for obj in (sink, ev, pin, c, b):
+    # round 3: the native loop, a grid sink, a library stream
+    gsink = GridSink(c, slots=2, threads=2)
+    grids = [np.empty((n, 6, 7), dtype=np.int8) for _ in range(2)]
+    exe = RolloutExecutor([c], sink=gsink, host_arrays=grids, seed0=SEED + it)
+    exe.enqueue(3)
+    exe.drain()
+    assert np.array_equal(exe.last_host_array(), c.grid)
+    for obj in (exe, gsink, sink, ev, pin, c, b):
         obj.close()
 torch.cuda.synchronize()
 torch.cuda.empty_cache()  # use_torch batches live in torch's caching allocator

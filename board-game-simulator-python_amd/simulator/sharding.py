@@ -52,8 +52,17 @@ class SharedRewardRing:
     is left behind however the processes end.  `dist` (torch.distributed, initialised) only carries the name and one
     barrier at construction; the data path has no collective."""
 
-    def __init__(self, dist, per_rank: int, slots: int, directory: str = "/dev/shm"):
+    def __init__(self, dist, per_rank: int, slots: int, directory=None):
+        """`directory`: where rank 0 creates the segment's file -- a path, or a list of candidates tried in order
+        (default: /dev/shm, then the temporary directory: a container's /dev/shm may be a few dozen MiB, and a file
+        mapping in /tmp is shared between the ranks just the same, only with the page cache behind it)."""
+        import tempfile
+
         import numpy as np
+
+        if directory is None:
+            directory = ["/dev/shm", tempfile.gettempdir()]
+        directories = [directory] if isinstance(directory, str) else list(directory)
 
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.per_rank, self.slots = int(per_rank), int(slots)
@@ -68,17 +77,32 @@ class SharedRewardRing:
         # callers can fall back to the collective gather consistently.
         name, fd, error = [None], -1, None
         if self.rank == 0:
-            try:
-                st = os.statvfs(directory)
-                if st.f_bavail * st.f_frsize < total + (64 << 20):
-                    raise OSError(f"{directory} has {st.f_bavail * st.f_frsize >> 20} MiB free, the reward ring needs {total >> 20}")
-                path = os.path.join(directory, f"bgs_rewards_{os.getpid()}_{uuid.uuid4().hex}")
-                fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
-                name[0] = path
-                os.ftruncate(fd, total)
-            except OSError as exc:
-                error = f"rank 0: {exc}"
+            problems = []
+            for where in directories:
+                try:
+                    st = os.statvfs(where)
+                    if st.f_bavail * st.f_frsize < total + (64 << 20):
+                        raise OSError(f"{where} has {st.f_bavail * st.f_frsize >> 20} MiB free, the reward ring needs {total >> 20}")
+                    path = os.path.join(where, f"bgs_rewards_{os.getpid()}_{uuid.uuid4().hex}")
+                    fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                    name[0] = path
+                    os.ftruncate(fd, total)
+                    break
+                except OSError as exc:
+                    problems.append(str(exc))
+                    if fd >= 0:
+                        os.close(fd)
+                        fd = -1
+                    if name[0] is not None:
+                        try:
+                            os.unlink(name[0])
+                        except OSError:
+                            pass
+                        name[0] = None
+            if name[0] is None:
+                error = "rank 0: " + "; ".join(problems)
         dist.broadcast_object_list(name, src=0)
+        self.path = name[0]  # (unlinked below: kept for diagnostics only)
         self._map = None
         if name[0] is not None:
             try:

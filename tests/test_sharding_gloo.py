@@ -145,6 +145,16 @@ RING_WORKER = textwrap.dedent(
         raise SystemExit("a ring in a missing directory was accepted")
     except RuntimeError:
         pass
+    # a list of candidates: the first that works is taken (a container's /dev/shm may be tiny: the temporary directory
+    # serves as well), and the file is gone from there too once everybody has mapped it
+    import tempfile
+    second = SharedRewardRing(dist, per_rank, slots, directory=["/nonexistent-directory", tempfile.gettempdir()])
+    assert second.path.startswith(tempfile.gettempdir()) and not os.path.exists(second.path)
+    second.mine(0)[...] = rank + 1
+    dist.barrier()
+    assert all((second.array(0)[r * per_rank] == r + 1).all() for r in range(world))
+    dist.barrier()
+    second.close()
     if rank == 0:
         t0 = time.monotonic()
         try:

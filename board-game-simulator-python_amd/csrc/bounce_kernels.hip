@@ -1207,8 +1207,20 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
             pick_from_lands<PMAX>(g, b, mover, mv, lands, sample_index(philox_word(blk, plies), mv.n), s, t);
             move_piece_on(b, s, t);
             ++plies;
-            if ((1ull << t) & (g.goal_top | g.goal_bottom)) st = mover + 1u;  // (stored and freed next iteration)
-            else search = true;
+            if ((1ull << t) & (g.goal_top | g.goal_bottom)) {
+                // a piece in the goal row ends the game (98.8 % of the games end this way): to memory at once, so that
+                // the lane takes its next board at the top of the next iteration instead of idling through it
+                st = mover + 1u;
+                const int64_t i = game;
+                store_board(planes, n, i, pieces_to_planes(g, b));
+                status[i] = (uint8_t)st;
+                plies_buf[i] = (uint16_t)plies;
+                reward[i] = reward_pair(st);
+                stepped += plies - first_ply;
+                has = false;
+            } else {
+                search = true;
+            }
         }
     }
 #ifdef BGS_BOUNCE_STATS

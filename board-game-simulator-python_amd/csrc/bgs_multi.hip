@@ -232,9 +232,10 @@ extern "C" int bgs_multi_connect_rollout(const int* devices, int n_devices, int 
 
 // ------------------------------------------------------------------------------------------------
 // bgs_gather: one process per GPU, persistent communicator, communication thread
-// Measured with a one-rank world (the gather is then a self send / receive, which RCCL turns into ~25 small fill / copy
-// dispatches per group on the communication stream): 1 step per group 0.85 of the device-resident rate, 3 per group
-// 0.87, 6 per group 0.96; receiving into device memory + copy kernel instead of straight into the sink's slot: -7 %.
+// Rank 0's own codes are not transported: its rollout kernel writes them where they belong among the gathered codes.
+// (Round 3 first sent them to itself like everybody else's: RCCL turns a self send / receive into ~25 small fill / copy
+// dispatches per group on the communication stream, and a one-rank world read 0.6-0.93 of the shared-memory loop
+// depending on the box.)
 // ------------------------------------------------------------------------------------------------
 struct bgs_gather {
     int device = 0, rank = 0, world = 1, slots = 0;
@@ -289,18 +290,22 @@ struct bgs_gather {
             int ne = 0;
             for (int i = 0; i < k; ++i) {
                 const int slot = (int)((t + i) % slots);
-                if (rank == 0) st[i] = bgs::sink_claim(sink);  // (blocks while every sink slot is still being expanded)
+                st[i] = t + i;  // rank 0: the launching thread claimed the sink ticket of this step (same numbers)
                 if (ok && (he = hipStreamWaitEvent(stream, rolled[slot], 0)) != hipSuccess) ok = false;
             }
-            if (ok) {
-                // the gather: one group of point-to-point calls, every rank -> rank 0
+            // The gather: one group of point-to-point calls, every OTHER rank -> rank 0.  Rank 0's own codes need no
+            // transport: its rollout kernel wrote them where the gathered codes of its games belong (bgs_gather_rollout).
+            if (ok && world > 1) {
                 if ((ne = api.GroupStart()) == 0) {
                     for (int i = 0; i < k && ne == 0; ++i) {
                         const int slot = (int)((t + i) % slots);
-                        ne = api.Send(codes[slot], code_bytes, kNcclUint8, 0, comm, stream);
-                        uint8_t* dst = rank != 0 ? nullptr : direct ? bgs::sink_slot_device(sink, st[i]) : gathered[slot];
-                        for (int r = 0; r < world && rank == 0 && ne == 0; ++r)
-                            ne = api.Recv(dst + (size_t)r * code_bytes, code_bytes, kNcclUint8, r, comm, stream);
+                        if (rank != 0) {
+                            ne = api.Send(codes[slot], code_bytes, kNcclUint8, 0, comm, stream);
+                        } else {
+                            uint8_t* dst = direct ? bgs::sink_slot_device(sink, st[i]) : gathered[slot];
+                            for (int r = 1; r < world && ne == 0; ++r)
+                                ne = api.Recv(dst + (size_t)r * code_bytes, code_bytes, kNcclUint8, r, comm, stream);
+                        }
                     }
                     const int ge = api.GroupEnd();
                     if (ne == 0) ne = ge;
@@ -309,15 +314,16 @@ struct bgs_gather {
             }
             for (int i = 0; i < k; ++i) {
                 const int slot = (int)((t + i) % slots);
-                if (ok && (he = hipEventRecord(sent[slot], stream)) != hipSuccess) ok = false;
-                if (rank != 0) continue;
-                if (ok && !direct) {
+                if (rank == 0 && ok && !direct) {
                     const size_t units = (code_bytes * (size_t)world + 15) / 16;  // (both buffers are whole 16-byte units)
                     hipLaunchKernelGGL(k_codes_to_slot, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream,
                                        reinterpret_cast<const uint4*>(gathered[slot]),
                                        reinterpret_cast<uint4*>(bgs::sink_slot_device(sink, st[i])), units);
                     if ((he = hipGetLastError()) != hipSuccess) ok = false;
                 }
+                // `sent`: this step's code buffer (rank 0: its gathered codes) may be written again
+                if (ok && (he = hipEventRecord(sent[slot], stream)) != hipSuccess) ok = false;
+                if (rank != 0) continue;
                 if (ok && (he = hipEventRecord(bgs::sink_slot_event(sink, st[i]), stream)) != hipSuccess) ok = false;
                 bgs::sink_publish(sink, st[i], n * world, host[slot], ok);
             }
@@ -426,8 +432,26 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
     }
     const int slot = (int)(t % g->slots);
     if (t >= g->slots) HIP_TRY(hipStreamWaitEvent(b->stream, g->sent[slot], 0));
-    int rc = bgs::rollout_with_codes(b, seed, max_plies, flags, g->codes[slot]);
-    if (rc) return rc;
+    // Rank 0 needs no transport for its own codes: its rollout kernel writes them straight to where the gathered codes of
+    // games [0, n) belong -- the sink's device-mapped slot (or the device buffer the copy kernel reads).  The sink ticket
+    // is claimed here, by the launching thread (claim blocks while the slot's previous job is still being expanded: the
+    // same back-pressure as before), and carries the gather's own ticket number.
+    uint8_t* codes_out = g->codes[slot];
+    if (g->rank == 0) {
+        const int64_t st = bgs::sink_claim(g->sink);
+        NEED(st == t, "the gather's sink handed out ticket %lld for step %lld", (long long)st, (long long)t);
+        codes_out = g->direct ? bgs::sink_slot_device(g->sink, st) : g->gathered[slot];
+    }
+    int rc = bgs::rollout_with_codes(b, seed, max_plies, flags, codes_out);
+    if (rc) {
+        if (g->rank == 0) {  // the claimed ticket must not stall the sink; the gather itself is beyond repair
+            bgs::sink_publish(g->sink, t, 0, host_reward, false);
+            std::lock_guard<std::mutex> lock(g->mu);
+            g->failed = true;
+            g->error = "a rollout could not be enqueued";
+        }
+        return rc;
+    }
     HIP_TRY(hipEventRecord(g->rolled[slot], b->stream));
     {
         std::lock_guard<std::mutex> lock(g->mu);

@@ -719,6 +719,10 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
         }
         if (!__builtin_amdgcn_ballot_w64(has)) {
             if (!draining) continue;    // (a chunk of boards that were not running: draw the next one)
+            // The last wave leaves only after an adoption attempt with ALL its lanes idle has found nothing: if its
+            // lanes were busy at the top of this iteration and their boards all stopped in it (a ply cap does that), the
+            // boards other waves parked meanwhile would otherwise never be played.
+            if (last && need != ~0ull) continue;
             if (last) break;
             if (leave() > 1u) break;    // others are still running: whatever gets parked later is theirs
             last = true;                // everybody else has left: sweep up what they parked
@@ -1164,6 +1168,10 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
         }
         if (!__builtin_amdgcn_ballot_w64(has)) {
             if (!draining) continue;    // (a chunk of boards that were not running: draw the next one)
+            // The last wave leaves only after an adoption attempt with ALL its lanes idle has found nothing: if its
+            // lanes were busy at the top of this iteration and their boards all stopped in it (a ply cap does that), the
+            // boards other waves parked meanwhile would otherwise never be played.
+            if (last && need != ~0ull) continue;
             if (last) break;
             if (leave() > 1u) break;    // others are still running: whatever gets parked later is theirs
             last = true;                // everybody else has left: sweep up what they parked

@@ -432,6 +432,52 @@ def test_bounce_flat_rollout_shared_drain_protocol(batch_mod, park, waves, chunk
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("pieces", ["1", "0"])
+def test_bounce_short_caps_leave_no_parked_board_behind(batch_mod, pieces):
+    """With a ply cap every board of a wave stops in the same iteration.  The last wave of a workgroup used to leave then --
+    all its lanes had been busy, so it had not looked at the parked boards in that iteration -- and the boards another wave
+    had parked meanwhile stayed at the state memory held (round 3: seen as a step count that was off in one run of eight
+    at 20011 boards; found through the boards with plies = 0).  Repeated, because it is a race: capped rollouts from the
+    start position (K3p / K3f) and capped-then-finished rollouts from memory (K3f), every board and the step counter."""
+    import os
+
+    env = {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PARK": "32", "BGS_BOUNCE_CHUNK": "32", "BGS_BOUNCE_PIECES": pieces}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        n = 20011
+        want = {}
+        for cap in (5, 2, 9):
+            orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+            want[cap] = (orc.rollout(SEED ^ n, first_game=n, max_plies=cap), orc.plies.copy(), orc.grid.copy())
+        full = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+        full_steps = full.rollout(SEED ^ n, first_game=n, max_plies=3000)
+        for rep in range(10):
+            for cap in (5, 2, 9):
+                dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+                dev.set_first_game(n)
+                dev.rollout(SEED ^ n, max_plies=cap, from_initial=True)
+                np.testing.assert_array_equal(dev.plies, want[cap][1], err_msg=f"rep {rep} cap {cap} from the start position")
+                np.testing.assert_array_equal(dev.grid, want[cap][2])
+                assert dev.steps == want[cap][0]
+                dev.reset()
+                dev.reset_steps()
+                dev.rollout(SEED ^ n, max_plies=cap)        # boards from memory: K3f
+                np.testing.assert_array_equal(dev.plies, want[cap][1], err_msg=f"rep {rep} cap {cap} from memory")
+                assert dev.steps == want[cap][0]
+                if cap == 5:
+                    dev.rollout(SEED ^ n, max_plies=3000)
+                    assert dev.steps == full_steps
+                    np.testing.assert_array_equal(dev.grid, full.grid)
+                dev.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
 def test_unsupported_geometry_is_an_error(batch_mod):
     """Beyond the bit-packed limits the generic kernels take over (tests/test_gpu_generic.py); beyond THEIR limits the
     library refuses, loudly and before touching the GPU."""

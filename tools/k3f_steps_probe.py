@@ -1,0 +1,27 @@
+"""Probe for a step-count mismatch of the flat Bounce kernel (K3f) on boards resumed from memory with parking on."""
+import os, sys, collections
+os.environ.update({"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PARK": os.environ.get("PARK", "32"), "BGS_BOUNCE_CHUNK": "32", "BGS_BOUNCE_PIECES": "0"})
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
+import numpy as np
+from oracle import oracle
+from simulator.batch import BounceBatch
+g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]
+SEED = 0x0123456789ABCDEF
+n = 20011
+orc5 = oracle.BounceOracle(g, n); want5 = orc5.rollout(SEED ^ n, first_game=n, max_plies=5)
+bad = 0
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
+    dev = BounceBatch(g, n)
+    dev.set_first_game(n)
+    dev.reset_steps()
+    dev.rollout(SEED ^ n, max_plies=5)
+    s5 = dev.steps
+    plies = dev.plies
+    if s5 != want5 or not np.array_equal(plies, orc5.plies):
+        bad += 1
+        wrong = np.flatnonzero(plies != orc5.plies)
+        print(f"rep {rep}: steps {s5} vs {want5}; boards with wrong plies: {len(wrong)}", collections.Counter(zip(plies[wrong].tolist(), orc5.plies[wrong].tolist())).most_common(5),
+              "first ids", wrong[:12].tolist(), "grids equal", np.array_equal(dev.grid, orc5.grid))
+    dev.close()
+print("mismatches:", bad)

@@ -508,17 +508,19 @@ def main() -> int:
     from simulator.pipeline import RolloutExecutor
     from simulator.sharding import RewardGather, SharedRewardRing, gather_outcomes_to, shard_range, sum_steps
 
-    bound_cpus = 0
-    if sharded:
-        import ctypes
+    # next to the GPU: launching thread, sink workers (they inherit the mask) and first-touch pages on the NUMA node the
+    # device hangs off (a no-op where the topology is unknown; the grid hand-over is the part that feels it at N = 1)
+    import ctypes
 
+    bound_cpus = 0
+    free_cpus = os.sched_getaffinity(0)  # (the CPU baseline gets the whole allowance back)
+    if os.environ.get("BGS_BIND_NUMA", "1") != "0":
+        got = ctypes.c_int(0)
+        _abi.check(_abi.lib().bgs_bind_host_thread(local_rank, ctypes.byref(got)))
+        bound_cpus = got.value
+    if sharded:
         import torch.distributed as dist
 
-        # every rank next to its GPU: launching thread, sink workers (they inherit the mask) and first-touch pages
-        if os.environ.get("BGS_BIND_NUMA", "1") != "0":
-            got = ctypes.c_int(0)
-            _abi.check(_abi.lib().bgs_bind_host_thread(local_rank, ctypes.byref(got)))
-            bound_cpus = got.value
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -779,7 +781,7 @@ def main() -> int:
                              f"({code_bytes} B per rank) to rank 0 (rehearsal of the RCCL gather on host copies)" if torch_gather else
                              "single GPU"),
                 "gathered_rewards_verified": gather_ok,
-                "numa_bound_cpus": bound_cpus if sharded else None,
+                "numa_bound_cpus": bound_cpus,
                 "inflight_batches": depth,
                 "prewarm": {"ms": args.prewarm_ms, "steps": prewarm_steps},
                 "host_arrays": host_slots,
@@ -794,6 +796,7 @@ def main() -> int:
             out["device_resident"] = device_resident
         if world == 1 and not sharded:
             if not args.no_cpu_baseline:
+                os.sched_setaffinity(0, free_cpus)
                 head = final_host[:65536] if final_host is not None else batches[last % depth].reward[:65536]
                 out["cpu_baseline"] = cpu_baseline(SEED + last, head)
                 out["cpu_baseline"]["gpu_single_game_latency_us"] = gpu_single_game_latency()

@@ -623,6 +623,14 @@ static int make_sink(int device, int64_t max_games, int slots, int threads, size
     s->parts_done.assign(slots, 0);
     const size_t bytes = slot_bytes;
     hipError_t err = hipSuccess;
+    // The page-locked slots are written by the GPU and read by the workers, which sit on the GPU's NUMA node: allocate
+    // (= first-touch) them from there too, whatever node the calling thread happens to run on (grid hand-over at 2^20
+    // boards: 5.4-5.8 against 4.5-5.5 x 10^10 env-steps/s), then give the caller its affinity back.
+    const char* aff0 = getenv("BGS_SINK_AFFINITY");
+    const bool place = !(aff0 && atoi(aff0) == 0);
+    cpu_set_t node_cpus, caller_cpus;
+    const bool moved = place && device_node_cpus(device, &node_cpus) && sched_getaffinity(0, sizeof caller_cpus, &caller_cpus) == 0 &&
+                       sched_setaffinity(0, sizeof node_cpus, &node_cpus) == 0;
     for (int k = 0; k < slots && err == hipSuccess; ++k) {
         void* host = nullptr;
         void* dev = nullptr;
@@ -634,6 +642,7 @@ static int make_sink(int device, int64_t max_games, int slots, int threads, size
         if (err == hipSuccess) err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (err == hipSuccess) s->landed.push_back(ev);
     }
+    if (moved) (void)sched_setaffinity(0, sizeof caller_cpus, &caller_cpus);
     if (err != hipSuccess) {
         for (auto p : s->pinned) (void)hipHostFree(p);
         for (auto e : s->landed) (void)hipEventDestroy(e);

@@ -303,7 +303,7 @@ def run_other_config(name: str, steps: int) -> int:
         dt = time.perf_counter() - t0
         return sum(b.steps for b in batches) / dt, dt / count * 1e3
 
-    slots = 2 * depth
+    slots = min(64, int(os.environ.get("BGS_BENCH_OTHER_SLOT_FACTOR", "2")) * depth)
     streams, batches = make(depth)
     hosts = [np.zeros((n, 2), dtype=np.int8) for _ in range(slots)]
     sink = RewardSink(n, slots=slots, threads=4, device=0)
@@ -359,7 +359,7 @@ def other_configs():
     """Run configs 3 and 4 as child processes (their own HIP queue settings; the GPU is idle meanwhile)."""
     results = {}
     for name in OTHER_CONFIGS:
-        steps = 48 if name == "connect_12x13x5" else 32  # (Bounce: two launches per stream)
+        steps = 48  # (Bounce: three launches per stream; with two the pipeline's two ends are a fifth of the region)
         cmd = [sys.executable, os.path.abspath(__file__), "--only", name, "--steps", str(steps)]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BGS_FORCE_DIST", "BGS_ROLLOUT_WPS")}
         try:

@@ -16,7 +16,6 @@ Every step plays all `n` boards from the initial state to the end with uniformly
 from __future__ import annotations
 
 import ctypes
-import os
 from typing import Iterable, Iterator, Optional, Sequence, Tuple
 
 import numpy as np

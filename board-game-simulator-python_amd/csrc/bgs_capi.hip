@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include "bgs_capi_util.h"
 #include "bgs_common.h"
@@ -483,6 +485,74 @@ int rollout_with_codes(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t 
 }
 }  // namespace bgs
 
+
+// ---- bgs_transition on small batches (the object API's one-board engines) ---------------------------------------
+// The staged form of the call costs two copies, a memset and a device-to-device copy around five kernels.  For a
+// batch of at most kSmallTransition boards the in-block and the out-block live in page-locked host memory that the
+// kernels read and write in place (a few hundred bytes over PCIe).  Optionally the launch sequence -- it depends only
+// on which of grid / plies / actions the caller passed -- is captured once per combination and replayed as a HIP graph.
+// Measured (tools/object_latency.py, tools/r3_transition.sh; Connect 6x7x4 / default Bounce, one thread, with the
+// engines leaving out the load of a board the device already holds): staged 53 / 63 us per transition, in place 28 / 46,
+// graph 35 / 52 -- hipGraphLaunch costs more than the five launches it replaces.  From 8 threads the order of in place
+// and graph changed between runs (30 vs 42 and 48 vs 38 thousand Connect transitions per second), so in place is the
+// default and BGS_TRANSITION=staged | graph select the other two; all three run the same kernels.
+namespace {
+constexpr int64_t kSmallTransition = 64;
+constexpr size_t kSmallBlock = 64u << 10;
+
+struct SmallTransition {
+    uint8_t* h_in = nullptr;
+    uint8_t* h_out = nullptr;
+    uint8_t* d_in = nullptr;   // the same blocks in the device's address space
+    uint8_t* d_out = nullptr;
+    hipGraphExec_t exec[8] = {};
+    bool graph_failed = false;
+};
+std::mutex g_small_mu;
+std::unordered_map<const bgs_batch*, SmallTransition> g_small;
+
+int transition_mode() {
+    static const int mode = [] {
+        const char* e = getenv("BGS_TRANSITION");
+        if (e && !strcmp(e, "staged")) return 0;
+        if (e && !strcmp(e, "graph")) return 2;
+        return 1;
+    }();
+    return mode;
+}
+
+__global__ void k_copy_small(const uint8_t* __restrict__ src, size_t bytes, uint8_t* __restrict__ dst) {
+    for (size_t i = threadIdx.x; i < bytes; i += blockDim.x) dst[i] = src[i];
+}
+
+int small_transition(const bgs_batch* b, SmallTransition** out) {
+    std::lock_guard<std::mutex> hold(g_small_mu);
+    SmallTransition& t = g_small[b];
+    if (!t.h_in) {
+        void *hi = nullptr, *ho = nullptr, *di = nullptr, *dv = nullptr;
+        HIP_TRY(hipHostMalloc(&hi, kSmallBlock, hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc(&ho, kSmallBlock, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(&di, hi, 0));
+        HIP_TRY(hipHostGetDevicePointer(&dv, ho, 0));
+        t.h_in = static_cast<uint8_t*>(hi); t.h_out = static_cast<uint8_t*>(ho);
+        t.d_in = static_cast<uint8_t*>(di); t.d_out = static_cast<uint8_t*>(dv);
+    }
+    *out = &t;
+    return BGS_OK;
+}
+
+void drop_small_transition(const bgs_batch* b) {
+    std::lock_guard<std::mutex> hold(g_small_mu);
+    auto it = g_small.find(b);
+    if (it == g_small.end()) return;
+    for (hipGraphExec_t e : it->second.exec)
+        if (e) (void)hipGraphExecDestroy(e);
+    if (it->second.h_in) (void)hipHostFree(it->second.h_in);
+    if (it->second.h_out) (void)hipHostFree(it->second.h_out);
+    g_small.erase(it);
+}
+}  // namespace
+
 extern "C" {
 
 int bgs_version(void) { return 200; }
@@ -624,6 +694,7 @@ int bgs_destroy(bgs_batch* b) {
     if (!b) return BGS_OK;
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
+    drop_small_transition(b);
     if (b->owns_arena && b->arena) (void)hipFree(b->arena);
     for (int k = 0; k < 2; ++k) {
         if (b->pinned[k]) (void)hipHostFree(b->pinned[k]);
@@ -1006,71 +1077,115 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
                 
                  out_player = up8(out_grid + n * hw), out_winner = out_player + up8(n), out_plies = out_winner + up8(n),
                  out_reward = out_plies + 4 * n, out_bytes = out_reward + 2 * n;
-    Stage st(b);
-    uint8_t* d_in = st.take<uint8_t>(in_bytes);
-    uint8_t* d_out = st.take<uint8_t>(out_bytes);
-    NEED(d_in && d_out, "staging buffer too small");
-    if (!b->pinned[0]) {
-        HIP_TRY(hipHostMalloc(&b->pinned[0], kPinnedChunk, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(&b->pinned[1], kPinnedChunk, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&b->pinned_done[0], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&b->pinned_done[1], hipEventDisableTiming));
-    }
-    NEED(in_bytes <= kPinnedChunk && out_bytes <= kPinnedChunk,
-         "batch too large for bgs_transition (%zu bytes per call): use fewer boards per call", out_bytes);
-    uint8_t* h_in = static_cast<uint8_t*>(b->pinned[0]);
-    uint8_t* h_out = static_cast<uint8_t*>(b->pinned[1]);
     const bool load = grid != nullptr;
+    if (load) NEED(player != nullptr && winner != nullptr, "player and winner are required with a grid");
+    // small batches: blocks in host memory the device addresses, launches replayed from a graph (see SmallTransition)
+    const int mode = (b->n <= kSmallTransition && in_bytes <= kSmallBlock && out_bytes <= kSmallBlock) ? transition_mode() : 0;
+    SmallTransition* small = nullptr;
+    uint8_t *d_in, *d_out, *h_in, *h_out;
+    if (mode) {
+        rc = small_transition(b, &small);
+        if (rc) return rc;
+        d_in = small->d_in; d_out = small->d_out; h_in = small->h_in; h_out = small->h_out;
+    } else {
+        Stage st(b);
+        d_in = st.take<uint8_t>(in_bytes);
+        d_out = st.take<uint8_t>(out_bytes);
+        NEED(d_in && d_out, "staging buffer too small");
+        if (!b->pinned[0]) {
+            HIP_TRY(hipHostMalloc(&b->pinned[0], kPinnedChunk, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(&b->pinned[1], kPinnedChunk, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&b->pinned_done[0], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->pinned_done[1], hipEventDisableTiming));
+        }
+        NEED(in_bytes <= kPinnedChunk && out_bytes <= kPinnedChunk,
+             "batch too large for bgs_transition (%zu bytes per call): use fewer boards per call", out_bytes);
+        h_in = static_cast<uint8_t*>(b->pinned[0]);
+        h_out = static_cast<uint8_t*>(b->pinned[1]);
+    }
     if (load) {
-        NEED(player != nullptr && winner != nullptr, "player and winner are required with a grid");
         memcpy(h_in + in_grid, grid, n * hw);
         memcpy(h_in + in_player, player, n);
         memcpy(h_in + in_winner, winner, n);
         if (plies) memcpy(h_in + in_plies, plies, 4 * n);
     }
     if (actions) memcpy(h_in + in_actions, actions, 4 * n * per_action);
-    if (load || actions) HIP_TRY(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, b->stream));
-    int32_t* d_load = reinterpret_cast<int32_t*>(d_out + out_load);
-    int32_t* d_step = reinterpret_cast<int32_t*>(d_out + out_step);
-    HIP_TRY(hipMemsetAsync(d_out, 0, 8 * n, b->stream));
-    if (load) {
-        const int8_t* dg = reinterpret_cast<const int8_t*>(d_in + in_grid);
-        const int8_t* dp = reinterpret_cast<const int8_t*>(d_in + in_player);
-        const int8_t* dw = reinterpret_cast<const int8_t*>(d_in + in_winner);
-        const int32_t* dl = plies ? reinterpret_cast<const int32_t*>(d_in + in_plies) : nullptr;
-        if (b->generic) bgs::generic_pack(b, dg, dp, dw, dl, d_load);
-        else if (connect) bgs::connect_pack(b, dg, dp, dw, d_load);
-        else bgs::bounce_pack(b, dg, dp, dw, dl, d_load);
-    }
-    if (actions) {
-        const int32_t* da = reinterpret_cast<const int32_t*>(d_in + in_actions);
-        if (b->generic) bgs::generic_step_actions(b, da, d_step);
-        else if (connect) bgs::connect_step_actions(b, da, d_step);
-        else bgs::bounce_step_actions(b, da, d_step);
-    }
-    int8_t* og = reinterpret_cast<int8_t*>(d_out + out_grid);
-    int8_t* op = reinterpret_cast<int8_t*>(d_out + out_player);
-    int8_t* ow = reinterpret_cast<int8_t*>(d_out + out_winner);
-    int32_t* ol = reinterpret_cast<int32_t*>(d_out + out_plies);
-    if (b->generic) {
-        bgs::generic_unpack_grid(b, og);
-        bgs::generic_meta(b, op, nullptr, ow, ol);
-        if (connect) bgs::generic_connect_legal(b, d_out + out_legal, nullptr);
-        else bgs::generic_bounce_targets(b, d_out + out_legal, nullptr);
-    } else if (connect) {
-        bgs::connect_unpack_grid(b, og);
-        bgs::connect_meta(b, op, nullptr, ow, ol);
-        bgs::connect_legal(b, d_out + out_legal, nullptr);
+    if (mode) {
+        memset(h_out, 0, 8 * n);  // the two status words per board
     } else {
-        bgs::bounce_unpack_grid(b, og);
-        bgs::bounce_meta(b, op, nullptr, ow, ol);
-        bgs::bounce_targets(b, reinterpret_cast<uint64_t*>(d_out + out_legal), nullptr);
+        if (load || actions) HIP_TRY(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemsetAsync(d_out, 0, 8 * n, b->stream));
     }
-    // the reward pairs as the kernels wrote them (State::get_reward): no host-side rule
-    HIP_TRY(hipMemcpyAsync(d_out + out_reward, b->d_reward, 2 * n, hipMemcpyDeviceToDevice, b->stream));
-    rc = finish_launch();
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, b->stream));
+    auto launch_all = [&]() -> int {
+        int32_t* d_load = reinterpret_cast<int32_t*>(d_out + out_load);
+        int32_t* d_step = reinterpret_cast<int32_t*>(d_out + out_step);
+        if (load) {
+            const int8_t* dg = reinterpret_cast<const int8_t*>(d_in + in_grid);
+            const int8_t* dp = reinterpret_cast<const int8_t*>(d_in + in_player);
+            const int8_t* dw = reinterpret_cast<const int8_t*>(d_in + in_winner);
+            const int32_t* dl = plies ? reinterpret_cast<const int32_t*>(d_in + in_plies) : nullptr;
+            if (b->generic) bgs::generic_pack(b, dg, dp, dw, dl, d_load);
+            else if (connect) bgs::connect_pack(b, dg, dp, dw, d_load);
+            else bgs::bounce_pack(b, dg, dp, dw, dl, d_load);
+        }
+        if (actions) {
+            const int32_t* da = reinterpret_cast<const int32_t*>(d_in + in_actions);
+            if (b->generic) bgs::generic_step_actions(b, da, d_step);
+            else if (connect) bgs::connect_step_actions(b, da, d_step);
+            else bgs::bounce_step_actions(b, da, d_step);
+        }
+        int8_t* og = reinterpret_cast<int8_t*>(d_out + out_grid);
+        int8_t* op = reinterpret_cast<int8_t*>(d_out + out_player);
+        int8_t* ow = reinterpret_cast<int8_t*>(d_out + out_winner);
+        int32_t* ol = reinterpret_cast<int32_t*>(d_out + out_plies);
+        if (b->generic) {
+            bgs::generic_unpack_grid(b, og);
+            bgs::generic_meta(b, op, nullptr, ow, ol);
+            if (connect) bgs::generic_connect_legal(b, d_out + out_legal, nullptr);
+            else bgs::generic_bounce_targets(b, d_out + out_legal, nullptr);
+        } else if (connect) {
+            bgs::connect_unpack_grid(b, og);
+            bgs::connect_meta(b, op, nullptr, ow, ol);
+            bgs::connect_legal(b, d_out + out_legal, nullptr);
+        } else {
+            bgs::bounce_unpack_grid(b, og);
+            bgs::bounce_meta(b, op, nullptr, ow, ol);
+            bgs::bounce_targets(b, reinterpret_cast<uint64_t*>(d_out + out_legal), nullptr);
+        }
+        // the reward pairs as the kernels wrote them (State::get_reward): no host-side rule
+        if (mode) hipLaunchKernelGGL(k_copy_small, dim3(1), dim3(64), 0, b->stream, reinterpret_cast<const uint8_t*>(b->d_reward), 2 * n, d_out + out_reward);
+        else HIP_TRY(hipMemcpyAsync(d_out + out_reward, b->d_reward, 2 * n, hipMemcpyDeviceToDevice, b->stream));
+        return finish_launch();
+    };
+    bool replayed = false;
+    if (mode == 2 && b->stream != nullptr && !small->graph_failed) {
+        const int key = (load ? 1 : 0) | (plies ? 2 : 0) | (actions ? 4 : 0);
+        if (!small->exec[key]) {
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                const int launched = launch_all();
+                e = hipStreamEndCapture(b->stream, &graph);
+                if (e == hipSuccess && launched) e = hipErrorLaunchFailure;
+            }
+            if (e == hipSuccess && graph) e = hipGraphInstantiate(&small->exec[key], graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) {  // this runtime does not capture the sequence: launch it directly from now on
+                small->exec[key] = nullptr;
+                small->graph_failed = true;
+                (void)hipGetLastError();
+            }
+        }
+        if (small->exec[key]) {
+            HIP_TRY(hipGraphLaunch(small->exec[key], b->stream));
+            replayed = true;
+        }
+    }
+    if (!replayed) {
+        rc = launch_all();
+        if (rc) return rc;
+    }
+    if (!mode) HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     // a malformed board was left untouched and an illegal move changed nothing: report the first problem per board
     const int32_t* load_status = reinterpret_cast<const int32_t*>(h_out + out_load);

@@ -508,6 +508,9 @@ class _Batch:
         )
         return status, grid_out, player_out, winner_out, plies_out, legal_out, reward_out
 
+    def one_board_call(self) -> "OneBoardCall":
+        return OneBoardCall(self)
+
     # ---- device-side hand-over (torch / RCCL plumbing) -----------------------------------------------
     def buffer(self, buffer_id: int):
         """(device pointer, bytes) of one of the batch's buffers (see bgs_buffer_id in include/bgs.h)."""
@@ -640,6 +643,61 @@ def expand_outcomes(packed, n: int, out=None):
     return out
 
 
+class OneBoardCall:
+    """`bgs_transition` on a one-board batch with everything that does not change between calls made once: the input
+    and output arrays, their ctypes pointers and the bound function.  The object API makes one such call per State;
+    building seven arrays and thirteen pointer objects per call cost as much as the device round trip."""
+
+    def __init__(self, batch: "GameBatch"):
+        if batch.n != 1:
+            raise ValueError("OneBoardCall serves one-board batches")
+        self.batch = batch
+        h, w = batch.height, batch.width
+        self.grid_in = np.empty((h, w), dtype=np.int8)
+        self.player_in = np.zeros(1, dtype=np.int8)
+        self.winner_in = np.zeros(1, dtype=np.int8)
+        self.plies_in = np.zeros(1, dtype=np.int32)
+        self.action_in = np.zeros(batch._action_width, dtype=np.int32)
+        self.status = np.zeros(1, dtype=np.int32)
+        self.grid_out = np.empty((h, w), dtype=np.int8)
+        self.player_out = np.empty(1, dtype=np.int8)
+        self.winner_out = np.empty(1, dtype=np.int8)
+        self.plies_out = np.empty(1, dtype=np.int32)
+        self.legal_out = batch._empty_legal()
+        self.reward_out = np.empty(2, dtype=np.int8)
+        i8, i32 = ctypes.c_int8, ctypes.c_int32
+        self._load = (_ptr(self.grid_in, i8), _ptr(self.player_in, i8), _ptr(self.winner_in, i8))
+        self._plies = _ptr(self.plies_in, i32)
+        self._action = _ptr(self.action_in, i32)
+        self._out = (
+            _ptr(self.status, i32), _ptr(self.grid_out, i8), _ptr(self.player_out, i8), _ptr(self.winner_out, i8),
+            _ptr(self.plies_out, i32), ctypes.c_void_p(self.legal_out.ctypes.data), _ptr(self.reward_out, i8),
+        )
+        self._fn = _abi.lib().bgs_transition
+        self._none3 = (None, None, None)
+
+    def __call__(self, grid=None, player: int = 0, winner: int = -1, plies=None, action=None) -> int:
+        """Optional load (grid int8[h, w] + player + winner [+ plies]), optional move (an int or a sequence of
+        `_action_width` ints), then observe into the `*_out` arrays.  Returns the board's status (0, or a BGS_ERR_*)."""
+        load = self._none3
+        if grid is not None:
+            self.grid_in[...] = grid
+            self.player_in[0] = player
+            self.winner_in[0] = winner
+            load = self._load
+            if plies is not None:
+                self.plies_in[0] = plies
+        if action is not None:
+            self.action_in[...] = action
+        rc = self._fn(
+            self.batch._handle, *load, None if grid is None or plies is None else self._plies,
+            None if action is None else self._action, *self._out,
+        )
+        if rc:
+            _abi.check(rc)
+        return int(self.status[0])
+
+
 class ConnectBatch(_Batch):
     """N Connect-k boards: ``Config(height, width, count)`` (reference connect.cpp:26) times n."""
 
@@ -708,17 +766,18 @@ class BounceBatch(_Batch):
                 for c in np.flatnonzero(flags[x]):
                     moves.append(((x, row), (int(c) % width, int(c) // width)))
             return tuple(moves)
-        row = int(legal_row[width])
+        masks = legal_row.tolist()
+        row = masks[width]
         if row >= height:  # all ones: nothing can move
             return ()
+        cells = self._cells  # cell index -> (x, y), built once
         for x in range(width):
-            m = int(legal_row[x])
-            c = 0
+            m = masks[x]
+            source = (x, row)
             while m:
-                if m & 1:
-                    moves.append(((x, row), (c % width, c // width)))
-                m >>= 1
-                c += 1
+                low = m & -m
+                moves.append((source, cells[low.bit_length() - 1]))
+                m ^= low
         return tuple(moves)
 
     def __init__(self, grid, n: int, device: int = 0, use_torch: Optional[bool] = None):
@@ -740,6 +799,7 @@ class BounceBatch(_Batch):
                 _ptr(cfg, ctypes.c_int8), self.height, self.width, self.n, self.device, arena, arena_bytes, ctypes.byref(self._handle)
             )
         )
+        self._cells = tuple((c % self.width, c // self.width) for c in range(self.height * self.width))
         self._after_create()
 
     def step_actions(self, moves, want_status: bool = True):

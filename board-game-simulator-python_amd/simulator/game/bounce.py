@@ -45,6 +45,8 @@ class _Engine:
         stream = ctypes.c_void_p()
         _abi.check(_abi.lib().bgs_stream_create(_DEVICE, ctypes.byref(stream)))
         self.batch.set_stream(stream.value)
+        self.call = self.batch.one_board_call()
+        self.held = None  # (grid bytes, player, winner, plies) of the board the device batch holds, when known
 
     @classmethod
     def get(cls, grid: np.ndarray) -> "_Engine":
@@ -56,24 +58,25 @@ class _Engine:
         return eng
 
     def _round_trip(self, grid=None, player=0, winner=-1, plies=0, move=None):
-        """One fused call (bgs_transition): optional load, optional move, then the observations a State needs."""
-        b = self.batch
-        status, g, p, w, l, masks, reward = b.transition(
-            None if grid is None else grid[None],
-            None if grid is None else np.array([player], dtype=np.int8),
-            None if grid is None else np.array([winner], dtype=np.int8),
-            None if grid is None else np.array([plies], dtype=np.int32),
-            None if move is None else np.array([move], dtype=np.int32),
-        )
-        if status[0] == _abi.BGS_ERR_ILLEGAL:
+        """One fused call (bgs_transition): optional load, optional move, then the observations a State needs.  The
+        load is left out when the device batch already holds exactly that board (see connect.py)."""
+        call = self.call
+        if grid is not None and self.held == (grid.tobytes(), player, winner, plies):
+            grid = None
+        self.held = None
+        status = call(grid, player, winner, plies, move)
+        if status == _abi.BGS_ERR_ILLEGAL:
             raise RuntimeError(f"illegal action: {tuple(move[:2])} -> {tuple(move[2:])}")
-        if status[0] != 0:
+        if status != 0:
             raise RuntimeError("malformed Bounce state")
-        grid_out, player_out, winner_out, plies_out = g[0], int(p[0]), int(w[0]), int(l[0])
-        return grid_out, player_out, winner_out, plies_out, b.decode_moves(masks[0], winner_out), reward[0]
+        grid_out, player_out, winner_out, plies_out = call.grid_out.copy(), int(call.player_out[0]), int(call.winner_out[0]), int(call.plies_out[0])
+        self.held = (grid_out.tobytes(), player_out, winner_out, plies_out)
+        moves = self.batch.decode_moves(call.legal_out[0], winner_out)
+        return grid_out, player_out, winner_out, plies_out, moves, call.reward_out.copy()
 
     def initial(self):
         with self.lock:
+            self.held = None
             self.batch.reset()
             return self._round_trip()
 

@@ -37,6 +37,8 @@ class _Engine:
         stream = ctypes.c_void_p()
         _abi.check(_abi.lib().bgs_stream_create(_DEVICE, ctypes.byref(stream)))
         self.batch.set_stream(stream.value)
+        self.call = self.batch.one_board_call()
+        self.held = None  # (grid bytes, player, winner) of the board the device batch holds, when known
 
     @classmethod
     def get(cls, height: int, width: int, count: int) -> "_Engine":
@@ -48,23 +50,26 @@ class _Engine:
         return eng
 
     def _round_trip(self, grid=None, player=0, winner=-1, column=None):
-        """One fused call (bgs_transition): optional load, optional move, then the observations a State needs."""
-        b = self.batch
-        status, g, p, w, _, legal, reward = b.transition(
-            None if grid is None else grid[None],
-            None if grid is None else np.array([player], dtype=np.int8),
-            None if grid is None else np.array([winner], dtype=np.int8),
-            None,
-            None if column is None else np.array([column], dtype=np.int32),
-        )
-        if status[0] == _abi.BGS_ERR_ILLEGAL:
+        """One fused call (bgs_transition): optional load, optional move, then the observations a State needs.  The
+        load is left out when the device batch already holds exactly that board (the usual case: a game played move by
+        move), which saves the pack kernel and the grid's trip to the device."""
+        call = self.call
+        if grid is not None and self.held == (grid.tobytes(), player, winner):
+            grid = None
+        self.held = None
+        status = call(grid, player, winner, None, column)
+        if status == _abi.BGS_ERR_ILLEGAL:
             raise RuntimeError(f"illegal action: column {column}")
-        if status[0] != 0:
+        if status != 0:
             raise RuntimeError("malformed Connect state")
-        return g[0], int(p[0]), int(w[0]), tuple(int(c) for c in np.flatnonzero(legal[0])), reward[0]
+        legal = tuple(c for c, open_ in enumerate(call.legal_out[0].tolist()) if open_)
+        grid_out, player_out, winner_out = call.grid_out.copy(), int(call.player_out[0]), int(call.winner_out[0])
+        self.held = (grid_out.tobytes(), player_out, winner_out)
+        return grid_out, player_out, winner_out, legal, call.reward_out.copy()
 
     def initial(self):
         with self.lock:
+            self.held = None
             self.batch.reset()
             return self._round_trip()
 

@@ -134,3 +134,36 @@ def test_json_of_terminal_states(fx):
         Action.from_json({"source": [0, 1], "target": [0, 2]}, back)
     with pytest.raises(RuntimeError):
         State.from_json({"grid": [[0, 0, 0]], "player": 0, "winner": -1}, state.config)
+
+
+def test_branching_from_one_state_reloads_the_board(fx):
+    """As in test_dropin_connect: actions taken from an older state, in both orders, against the oracle."""
+    from oracle import oracle
+    from simulator.game.bounce import Config
+
+    grid = np.array(fx["tests"][1]["positions"][0]["grid"], dtype=np.int8)
+    rnd = random.Random(5)
+    state, history = Config(grid).sample_initial_state(), []
+    for _ in range(6):
+        if state.has_ended:
+            break
+        actions = state.actions
+        sample = actions if len(actions) <= 6 else rnd.sample(actions, 6)
+        children = {}
+        for order in (sample, sample[::-1]):
+            for action in order:
+                move = [*action.source, *action.target]
+                orc = oracle.BounceOracle(grid, 1)
+                for past in history + [move]:
+                    orc.step_actions([past])
+                child = action.sample_next_state()
+                np.testing.assert_array_equal(child.grid, orc.grid[0])
+                assert child.has_ended == bool(orc.ended[0])
+                assert child.player == orc.player[0] or child.has_ended
+                np.testing.assert_array_equal(child.reward, orc.reward[0])
+                if not child.has_ended:
+                    assert [(tuple(a.source), tuple(a.target)) for a in child.actions] == orc.actions(0)
+                assert children.setdefault(tuple(move), child) == child
+        move = rnd.choice(sorted(children))
+        history.append(list(move))
+        state = children[move]

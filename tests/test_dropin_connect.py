@@ -191,3 +191,72 @@ def test_object_api_from_a_thread_pool():
         start = pool.submit(config.sample_initial_state).result()
     nxt = start.action_at(3).sample_next_state()
     assert nxt.player == 1 and nxt.grid[0, 3] == 0
+
+
+def test_branching_from_one_state_reloads_the_board():
+    """The engine skips the load when its device board already is the state being stepped; a second action taken from
+    an OLDER state must put that state back first.  Every child of every state of a short game, visited in both orders,
+    against the oracle."""
+    from oracle import oracle
+    from simulator.game.connect import Config
+
+    config = Config(5, 4, 3)
+    rnd = random.Random(11)
+    state, history = config.sample_initial_state(), []
+    while not state.has_ended:
+        children = {}
+        for order in (state.actions, state.actions[::-1]):
+            for action in order:
+                orc = oracle.ConnectOracle(5, 4, 3, 1)
+                for column in history + [action.column]:
+                    orc.step_actions([column])
+                child = action.sample_next_state()
+                np.testing.assert_array_equal(child.grid, orc.grid[0])
+                assert child.has_ended == bool(orc.ended[0])
+                np.testing.assert_array_equal(child.reward, orc.reward[0])
+                assert [a.column for a in child.actions] == (np.flatnonzero(orc.legal()[0]).tolist() if not orc.ended[0] else [])
+                assert children.setdefault(action.column, child) == child
+        column = rnd.choice(sorted(children))
+        history.append(column)
+        state = children[column]
+
+
+_PLAYTHROUGH = r"""
+import hashlib, random, sys
+sys.path[:0] = [{root!r}, {pkg!r}]
+import numpy as np
+from simulator.game.connect import Config as Connect
+from simulator.game.bounce import Config as Bounce
+grid = np.zeros((9, 6), dtype=np.int64); grid[1] = grid[7] = [1, 2, 3, 3, 2, 1]
+h = hashlib.sha256()
+for config, cap in ((Connect(6, 7, 4), 100), (Connect(12, 13, 5), 60), (Bounce(grid), 80)):
+    rnd = random.Random(17)
+    for _ in range(3):
+        s = config.sample_initial_state()
+        first, n = s, 0
+        while not s.has_ended and n < cap:
+            a = rnd.choice(s.actions)
+            s = a.sample_next_state()
+            h.update(s.grid.tobytes()); h.update(bytes([s.player, s.has_ended])); h.update(s.reward.tobytes())
+            h.update(repr(len(s.actions)).encode())
+            n += 1
+        h.update(first.actions[0].sample_next_state().grid.tobytes())  # an older state again: the board is reloaded
+print(h.hexdigest())
+"""
+
+
+def test_the_three_forms_of_the_round_trip_agree():
+    """bgs_transition on a one-board batch: staged copies, blocks the device addresses in host memory (the default),
+    and the same launches replayed from a HIP graph (BGS_TRANSITION) -- one digest over three playthroughs."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _PLAYTHROUGH.format(root=root, pkg=os.path.join(root, "board-game-simulator-python_amd"))
+    digests = {}
+    for form in ("staged", "mapped", "graph"):
+        env = dict(os.environ, BGS_TRANSITION=form)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[form] = out.stdout.strip().splitlines()[-1]
+    assert len(set(digests.values())) == 1, digests

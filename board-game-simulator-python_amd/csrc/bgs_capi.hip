@@ -300,6 +300,7 @@ int device_facts(bgs_batch* b) {
         const int v = atoi(env);
         if (v >= 0 && v <= 32) b->bounce_park = v;
     }
+    b->launches_in_flight = 1;
     b->bounce_flat_waves = 0;
     if (const char* env = getenv("BGS_BOUNCE_FLAT_WAVES")) {
         const int v = atoi(env);
@@ -702,6 +703,13 @@ int bgs_destroy(bgs_batch* b) {
     }
     if (b->order_event) (void)hipEventDestroy(b->order_event);
     delete b;
+    return BGS_OK;
+}
+
+int bgs_set_launches_in_flight(bgs_batch* b, int32_t launches) {
+    NEED(b != nullptr, "batch handle is NULL");
+    NEED(launches >= 1 && launches <= 1024, "launches in flight %d outside 1..1024", (int)launches);
+    b->launches_in_flight = launches;
     return BGS_OK;
 }
 

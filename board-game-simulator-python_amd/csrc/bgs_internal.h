@@ -55,8 +55,24 @@ constexpr int kRolloutOpeningBlocks = 3;    // K2o: 4-ply blocks played in lock 
 constexpr int kGamesPerLaneOneWord = 8;     // one-word Connect boards: games per lane a launch aims for (512 per wave at 2^20)
 constexpr int kGamesPerLane = 4;            // every other rollout
 constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBoards (0 = every wave drains alone)
-constexpr int kBounceTailCap = 384;         // K3p, automatic plan: games longer than this are finished by the tail pass
-constexpr int kBounceBoardsPerWave = 512;   // K3p: boards a wave plays in a launch (fewer, longer-lived waves drain less)
+// K3p, automatic plan: the shape of a launch follows the number of launches the caller keeps in flight on the device
+// (bgs_set_launches_in_flight; the rollout executor passes its depth).  tail_cap: games longer than this are finished
+// by the tail pass; boards_per_wave: boards a wave of the bulk pass plays.  Alone on the chip a launch is bound by its
+// longest chain of dependent plies (17 us a ply on the piece-list kernel, 0.65 us on the 8-lanes-per-board kernel of
+// the tail) and by how many SIMDs it reaches, so: short bulk, many waves.  With 16 launches sharing the chip what counts
+// is instructions per ply, so: few long-lived waves that stay full, and a bulk pass long enough to keep the tail small.
+// 2^18 boards, 10^9 env-steps/s (tools/r3_bounce_solo.sh, r3_bounce_depth.sh, r3_bounce_depth2.sh):
+//   in flight        1      4      8      16
+//   {384, 512}     1.11   2.16   6.05   9.7      (round 3's only shape until then)
+//   {64, 128}      1.92   3.10   6.53   7.7
+//   {128, 256}     1.63   2.92   6.85   8.8
+//   {160, 512}     1.12    --     --   10.2
+struct BounceShape { int tail_cap; int boards_per_wave; };
+inline BounceShape bounce_shape(int launches_in_flight) {
+    if (launches_in_flight >= 12) return {160, 512};
+    if (launches_in_flight >= 6) return {128, 256};
+    return {64, 128};
+}
 
 struct bgs_batch {
     int game;
@@ -80,6 +96,7 @@ struct bgs_batch {
     int bounce_flat_waves;   // > 0: that many waves per launch instead (BGS_BOUNCE_FLAT_WAVES)
     int bounce_park;         // flat rollout: a draining wave parks its boards for its workgroup at this many or fewer (0..32; BGS_BOUNCE_PARK)
     int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (BGS_BOUNCE_CHUNK)
+    int launches_in_flight;  // the caller's hint (bgs_set_launches_in_flight), 1 = one launch at a time: see bounce_shape()
     int bounce_plan_auto;    // 1: the library chooses between one launch and bulk + tail passes (BGS_BOUNCE_PLAN unset or "auto")
     int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board
     uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];

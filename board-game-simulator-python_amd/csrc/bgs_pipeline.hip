@@ -66,6 +66,7 @@ int bgs_pipeline_create(bgs_batch* const* batches, int depth, bgs_reward_sink* s
     NEED(p != nullptr, "out of host memory");
     p->device = batches[0]->device;
     p->batches.assign(batches, batches + depth);
+    for (bgs_batch* b : p->batches) b->launches_in_flight = depth;  // (the launch shape follows it: bgs_set_launches_in_flight)
     p->sink = sink;
     p->gather = gather;
     for (int h = 0; h < n_host; ++h) p->host.push_back(host_rewards[h]);

@@ -1449,12 +1449,13 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         const size_t tile = 0;  // (the landing masks live in registers; LDS only holds the parked boards)
         const uint32_t chunk = (uint32_t)b->bounce_flat_chunk;
         // Every ply costs a wave the same whatever the number of its lanes that still hold a game, so what counts is how
-        // full the waves stay: few, long-lived waves (kBounceBoardsPerWave boards each, drawn from the queue) spend most
-        // of their life refilling and little of it draining.  Measured at 2^18 boards, 16 batches in flight, tail pass
-        // on: 2048 waves 6.9, 1024 waves 7.5, 512 waves 7.9 x 10^9 env-steps/s (one launch at a time: 6.3 / 6.8 / 8.1 ms).
+        // full the waves stay: few, long-lived waves (boards_per_wave boards each, drawn from the queue) spend most
+        // of their life refilling and little of it draining -- when many launches share the chip.  A launch that is
+        // alone wants more, shorter-lived waves: see bounce_shape().
+        const int64_t per_wave = bounce_shape(b->launches_in_flight).boards_per_wave;
         int64_t flat_waves = (int64_t)b->num_cus * 4 * b->bounce_flat_wps;
         if (b->bounce_flat_waves > 0) flat_waves = b->bounce_flat_waves;
-        else if (b->n / kBounceBoardsPerWave < flat_waves) flat_waves = b->n / kBounceBoardsPerWave > 256 ? b->n / kBounceBoardsPerWave : 256;
+        else if (b->n / per_wave < flat_waves) flat_waves = b->n / per_wave > 256 ? b->n / per_wave : 256;
         const int64_t most = (b->n + 63) / 64;    // (never more waves than 64-board loads)
         if (flat_waves > most) flat_waves = most;
         constexpr int per_block = BLOCK / BGS_WAVE;
@@ -1515,8 +1516,8 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
         // The automatic plan.  Random Bounce games are short (mean 28 plies, 1 in 10^4 beyond 256) -- except the few per
         // 2^18 that never end and run into max_plies.  Such a game is a chain of thousands of dependent plies; inside
         // the bulk launch it would keep a whole wave of the one-lane-per-board kernel alive (every ply at the cost of
-        // 64 boards), so the bulk pass stops at kBounceTailCap plies and the stragglers -- compacted into a work list on
-        // the device -- are finished 8 lanes to a board, the kernel with the shortest ply, at raised wave priority.
+        // 64 boards), so the bulk pass stops at bounce_shape().tail_cap plies and the stragglers -- compacted into a work
+        // list on the device -- are finished 8 lanes to a board, the kernel with the shortest ply, at raised wave priority.
         int passes = b->bounce_passes;
         uint32_t pass_cap_of[BGS_BOUNCE_MAX_PASSES];
         int pass_group_of[BGS_BOUNCE_MAX_PASSES];
@@ -1525,9 +1526,9 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
             pass_group_of[i] = b->bounce_pass_group[i];
         }
         if (b->bounce_plan_auto && b->bounce_group == 1 && b->bounce_flat && b->bounce_pieces && from_initial &&
-            b->bg.piece_count >= 1 && cap > 2u * kBounceTailCap) {
+            b->bg.piece_count >= 1 && cap > 2u * (uint32_t)bounce_shape(b->launches_in_flight).tail_cap) {
             passes = 2;
-            pass_cap_of[0] = kBounceTailCap;
+            pass_cap_of[0] = (uint32_t)bounce_shape(b->launches_in_flight).tail_cap;
             pass_group_of[0] = 1;
             pass_cap_of[1] = cap;
             pass_group_of[1] = 8;

@@ -338,6 +338,12 @@ class _Batch:
         """Global id of board 0: RNG streams are keyed by global game id, so shards reproduce the unsharded run."""
         _abi.check(_abi.lib().bgs_set_first_game(self._handle, ctypes.c_uint64(first_game)))
 
+    def set_launches_in_flight(self, launches: int) -> None:
+        """A hint: how many rollout launches the caller keeps in flight on the device (1, the default: one at a time).
+        Results never depend on it; the Bounce rollout shapes its launch by it (bgs_set_launches_in_flight).  The
+        rollout executor and `RolloutPipeline` pass their depth."""
+        _abi.check(_abi.lib().bgs_set_launches_in_flight(self._handle, int(launches)))
+
     def synchronize(self) -> None:
         _abi.check(_abi.lib().bgs_synchronize(self._handle))
 

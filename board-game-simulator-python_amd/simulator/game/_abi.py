@@ -54,6 +54,7 @@ SIGNATURES = {
     "bgs_stream_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "bgs_stream_destroy": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "bgs_set_first_game": (ctypes.c_int, [c_handle, ctypes.c_uint64]),
+    "bgs_set_launches_in_flight": (ctypes.c_int, [c_handle, ctypes.c_int32]),
     "bgs_synchronize": (ctypes.c_int, [c_handle]),
     "bgs_info": (
         ctypes.c_int,

@@ -151,6 +151,7 @@ class RolloutPipeline:
             with torch.cuda.stream(s):  # the batch binds to the stream that is current when it is created
                 b = batch_cls(*config_args, self.n, device=device, use_torch=True)
                 b.set_first_game(first_game)
+                b.set_launches_in_flight(self.depth)
                 self.batches.append(b)
         self.slots = max(1, int(arrays_per_stream)) * self.depth
         if host_arrays is None:

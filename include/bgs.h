@@ -88,6 +88,12 @@ int bgs_set_stream(bgs_batch* b, void* hip_stream);
 int bgs_stream_create(int device, void** hip_stream);
 int bgs_stream_destroy(int device, void* hip_stream);
 int bgs_set_first_game(bgs_batch* b, uint64_t first_game); /* global id of board 0 (sharding across GPUs) */
+/* A hint, not a rule of the game: how many rollout launches the caller keeps in flight on this batch's device (its own
+ * included; 1 = one launch at a time, the default).  Results never depend on it.  The Bounce rollout shapes its launch
+ * by it -- alone on the chip: a short bulk pass on many waves (shortest time to the last reward); among 16: few
+ * long-lived waves (fewest instructions per ply).  bgs_pipeline_create passes its depth to its batches.  The reference
+ * has no counterpart (one board per call: bounce.cpp:51). */
+int bgs_set_launches_in_flight(bgs_batch* b, int32_t launches);
 int bgs_synchronize(bgs_batch* b);
 int bgs_info(const bgs_batch* b, int* game, int* height, int* width, int* count, int64_t* n, int* planes);
 /* Geometries beyond the bit-packed kernels' limits (Connect: height > 15, width > 16 or width * (height + 1) > 192;

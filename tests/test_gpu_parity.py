@@ -611,6 +611,25 @@ def test_bounce_piece_list_rollout(batch_mod, name):
             os.environ["BGS_BOUNCE_GROUP"] = old
 
 
+@pytest.mark.parametrize("launches", [1, 4, 8, 16, 64])
+def test_bounce_launch_shape_follows_the_hint_and_the_boards_do_not(batch_mod, launches):
+    """`set_launches_in_flight` only shapes the launch (bulk-pass ply cap, boards per wave: bounce_shape() in
+    bgs_internal.h): one launch at a time, 4, 8, 16 in flight -- the same boards as the oracle's, ply caps either side of
+    every shape's bulk cap included."""
+    for n, cap in ((40000, 4096), (3000, 100), (3000, 200), (3000, 400)):
+        dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+        orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+        dev.set_launches_in_flight(launches)
+        dev.set_first_game(9 << 32)
+        dev.rollout(SEED + launches, max_plies=cap, from_initial=True)
+        total = orc.rollout(SEED + launches, first_game=9 << 32, max_plies=cap)
+        assert_same(dev, orc, f"in flight {launches}: n={n} cap={cap}")
+        assert dev.steps == total
+        dev.close()
+    with pytest.raises(ValueError):
+        batch_mod.BounceBatch(DEFAULT_BOUNCE, 8).set_launches_in_flight(0)
+
+
 def test_bounce_rollout_max_plies_and_resume(batch_mod):
     n = 4000
     dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)

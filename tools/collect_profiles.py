@@ -26,7 +26,7 @@ def main():
               "WRITE_SIZE), per-dispatch means; FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads), KiB -> B")
     for tag, want, name in (("bench", "k_connect_rollout_opened", "r03_bench_kernel.json"), ("k1", "step_random", "r03_k1.json"),
                             ("k2c", "_lds", "r03_k2c.json"), ("k2b", "k_connect_rollout_aligned_wide", "r03_k2b.json"),
-                            ("bounce", "k_bounce", "r03_bounce.json"), ("bounce_k3f", "k_bounce", "r03_bounce_k3f.json"),
+                            ("bounce", "k_bounce", "r03_bounce.json"), ("bounce_solo", "k_bounce", "r03_bounce_solo.json"), ("bounce_k3f", "k_bounce", "r03_bounce_k3f.json"),
                             ("bounce8", "k_bounce_rollout", "r03_bounce_lane_groups.json")):
         try:
             s = summary(tag, want)

@@ -13,9 +13,12 @@ bash tools/profile_kernel.sh k1 python3 tools/k1_steps.py
 bash tools/profile_kernel.sh k2c python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9
 # K3: Bounce 9x6, 2^18 boards, max_plies 4096: the piece-list kernel + tail pass (default at this size), the flat cell
 # search it replaces (K3f, one launch) and lane-group mode
-bash tools/profile_kernel.sh bounce python3 tools/rollout_rate.py bounce --depth 1 --reps 6
-BGS_BOUNCE_PIECES=0 BGS_BOUNCE_PLAN=single bash tools/profile_kernel.sh bounce_k3f python3 tools/rollout_rate.py bounce --depth 1 --reps 6
-BGS_BOUNCE_GROUP=8 bash tools/profile_kernel.sh bounce8 python3 tools/rollout_rate.py bounce --depth 1 --reps 6
+# (the launch shape follows the launches-in-flight hint: "bounce" = the shape of 16 in flight, which bench.py's
+# other_configs runs, counted one launch at a time; "bounce_solo" = the shape of a launch that is alone)
+bash tools/profile_kernel.sh bounce python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 16
+bash tools/profile_kernel.sh bounce_solo python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 1
+BGS_BOUNCE_PIECES=0 BGS_BOUNCE_PLAN=single bash tools/profile_kernel.sh bounce_k3f python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 16
+BGS_BOUNCE_GROUP=8 bash tools/profile_kernel.sh bounce8 python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 16
 # K2b: the register kernel K2c replaced on 12x13x5, for the instruction-count comparison
 BGS_ROLLOUT_NO_LDS=1 bash tools/profile_kernel.sh k2b python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9
 # K4 and the rest (reset, unpack, legal, ...): kernel stats only

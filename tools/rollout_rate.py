@@ -28,6 +28,7 @@ ap.add_argument("--depth", type=int, default=3)
 ap.add_argument("--reps", type=int, default=24)
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--max-plies", type=int, default=4096)
+ap.add_argument("--hint", type=int, default=0, help="launches-in-flight hint for every run (0: the run's own depth); counters of the pipelined launch shape can then be taken one launch at a time")
 ap.add_argument("--bounce-waves", type=int, default=0, help="BGS_BOUNCE_FLAT_WAVES for this run (0: library default)")
 args = ap.parse_args()
 
@@ -49,6 +50,7 @@ for s in streams:
 def run(depth, reps):
     for b in batches[:depth]:
         b.reset_steps()
+        b.set_launches_in_flight(args.hint or depth)  # (what the rollout executor tells its batches)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(reps):

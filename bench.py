@@ -359,7 +359,9 @@ def other_configs():
     """Run configs 3 and 4 as child processes (their own HIP queue settings; the GPU is idle meanwhile)."""
     results = {}
     for name in OTHER_CONFIGS:
-        steps = 48  # (Bounce: three launches per stream; with two the pipeline's two ends are a fifth of the region)
+        # ten launches per stream: with three the two ends of a 16-deep Bounce pipeline were a sixth of the region
+        # (8.7 vs 10.3 x 10^9 on tools/rollout_rate.py's 96 launches); both regions together stay under half a second
+        steps = 10 * OTHER_CONFIGS[name][2] * (8 if name == "connect_12x13x5" else 1)
         cmd = [sys.executable, os.path.abspath(__file__), "--only", name, "--steps", str(steps)]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BGS_FORCE_DIST", "BGS_ROLLOUT_WPS")}
         try:

@@ -3,8 +3,10 @@
 # must carry this build's id before bench.py is run for the record), then the bench lines and the secondary measurements.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
+if [ -z "${SKIP_PROFILES:-}" ]; then  # (SKIP_PROFILES=1: the kernels have not changed since the last counter pass)
 bash tools/profile_all.sh > gpurun_out/r3_profile_all.log 2>&1
 echo "profile_all done"; tail -2 gpurun_out/r3_profile_all.log
+fi
 python bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err
 python bench.py --steps 20 --warmup 5 > gpurun_out/r03_bench_steps20.json 2> gpurun_out/r03_bench_steps20.err
 D="RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 BGS_FORCE_DIST=1"

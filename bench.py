@@ -76,7 +76,7 @@ LAUNCH_OVERRIDES = ("BGS_ROLLOUT_OPENING", "BGS_ROLLOUT_CHUNK", "BGS_ROLLOUT_GEN
 BOUNCE_GRID = [[0] * 6, [1, 2, 3, 3, 2, 1]] + [[0] * 6] * 5 + [[1, 2, 3, 3, 2, 1], [0] * 6]  # textual/bounce.py:66-78
 OTHER_CONFIGS = {
     # name: (BASELINE.json config, boards, batches in flight, max plies, SURVEY 8d bytes per env-step, counters file, kernel)
-    "connect_12x13x5": ("Connect4(12,13,5) large-board batch=262,144 on 1 MI355X", 1 << 18, 3, 2**31 - 1, 96, "k2c", "k_connect_rollout_lds"),
+    "connect_12x13x5": ("Connect4(12,13,5) large-board batch=262,144 on 1 MI355X", 1 << 18, 8, 2**31 - 1, 96, "k2c", "k_connect_rollout_lds"),
     "bounce_default": ("Bounce default config batch=262,144 on 1 MI355X", 1 << 18, 16, 4096, 64, "bounce", "k_bounce_rollout"),
 }
 
@@ -361,7 +361,7 @@ def other_configs():
     for name in OTHER_CONFIGS:
         # ten launches per stream: with three the two ends of a 16-deep Bounce pipeline were a sixth of the region
         # (8.7 vs 10.3 x 10^9 on tools/rollout_rate.py's 96 launches); both regions together stay under half a second
-        steps = 10 * OTHER_CONFIGS[name][2] * (8 if name == "connect_12x13x5" else 1)
+        steps = 10 * OTHER_CONFIGS[name][2] * (4 if name == "connect_12x13x5" else 1)
         cmd = [sys.executable, os.path.abspath(__file__), "--only", name, "--steps", str(steps)]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BGS_FORCE_DIST", "BGS_ROLLOUT_WPS")}
         try:

@@ -110,11 +110,18 @@ class RolloutExecutor:
             pass
 
 
-def default_depth(batch_cls) -> int:
-    """Batches in flight that saturate the chip: a Connect rollout is a ~50 us launch bound by VALU issue (3 in flight
-    fill the drain of one launch with the next); a Bounce rollout is a 5-15 ms launch whose tail is a handful of long
-    games (16 in flight on 32 hardware queues: 5x one launch at a time)."""
-    return 16 if getattr(batch_cls, "game", 0) == _abi.GAME_BOUNCE else 3
+def default_depth(batch_cls, config_args: tuple = ()) -> int:
+    """Batches in flight that saturate the chip.  A one-word Connect rollout (6x7x4) is a ~50 us launch bound by VALU
+    issue at two waves per SIMD: 3 in flight fill the drain of one launch with the next, more only add to the tail.  A
+    multi-word Connect board (12x13x5: the LDS-staged kernel, ONE wave per SIMD per launch, each issuing one VALU per
+    ~9 cycles when alone) wants more waves per SIMD than three launches give: 8 in flight, 2.45 against 2.18 x 10^11
+    env-steps/s (tools/r3_k2c_depth.sh; 12-16 with larger chunks reach 2.5-2.56).  A Bounce rollout is a 5-15 ms launch
+    whose tail is a handful of long games: 16 in flight on 32 hardware queues, 5x one launch at a time."""
+    if getattr(batch_cls, "game", 0) == _abi.GAME_BOUNCE:
+        return 16
+    if len(config_args) >= 2 and int(config_args[1]) * (int(config_args[0]) + 1) > 64:
+        return 8
+    return 3
 
 
 def check_depth(depth: int) -> None:
@@ -131,14 +138,14 @@ class RolloutPipeline:
     def __init__(self, batch_cls, config_args: tuple, n: int, depth: Optional[int] = None, host_threads: int = 6, device: int = 0,
                  first_game: int = 0, max_plies: int = 2**31 - 1, host_arrays=None, arrays_per_stream: int = 3):
         """`batch_cls(*config_args, n, device=..., use_torch=True)` is built `depth` times, each bound to its own stream
-        (default: `default_depth(batch_cls)` -- 3 for Connect, 16 for Bounce).
+        (default: `default_depth(batch_cls, config_args)` -- 3 for one-word Connect boards, 8 for larger ones, 16 for Bounce).
         `host_arrays`: optional list of arrays_per_stream * depth C-contiguous int8[n, 2] destinations (e.g. rows of a shared array,
         `SharedRewardRing.mine(slot)`); by default the pipeline allocates (and pre-faults) its own."""
         _abi.lib()  # (asks for more hardware queues while that is still possible: before torch touches the GPU)
         import torch
 
         if depth is None:
-            depth = default_depth(batch_cls)
+            depth = default_depth(batch_cls, config_args)
             arrays_per_stream = min(arrays_per_stream, max(1, 48 // depth))
         if depth < 1:
             raise ValueError("depth must be >= 1")

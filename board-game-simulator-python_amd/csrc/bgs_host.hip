@@ -22,6 +22,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -275,6 +276,18 @@ bool device_node_cpus(int device, cpu_set_t* out) {
 // ------------------------------------------------------------------------------------------------
 // reward sink: slots of pinned code buffers + worker threads
 // ------------------------------------------------------------------------------------------------
+namespace {
+// BGS_SINK_TRACE=1: the sink's threads report when they saw a job's codes, expanded their share and completed it, in
+// microseconds of CLOCK_MONOTONIC (what time.perf_counter() reads too) -- for tools/short_run_timeline.py
+inline bool sink_trace_on() {
+    static const bool on = getenv("BGS_SINK_TRACE") != nullptr;
+    return on;
+}
+inline double mono_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
 struct bgs_reward_sink {
     int device = 0;
     int64_t max_games = 0;
@@ -361,6 +374,7 @@ struct bgs_reward_sink {
                 } else {
                     ok = hipEventSynchronize(landed[slot]) == hipSuccess;
                 }
+                if (sink_trace_on()) fprintf(stderr, "sink-trace ticket %lld landed %.1f\n", (long long)ticket, mono_us());
                 {
                     std::lock_guard<std::mutex> lock(mu);
                     if (!ok) failed = true;
@@ -369,7 +383,17 @@ struct bgs_reward_sink {
                 }
                 cv_landed.notify_all();
             } else {
-                spin_for(a_landed, ticket);
+                if (urgent.load(std::memory_order_relaxed) > 0) {
+                    // somebody waits for the LAST deliveries: a wake-up out of the condition variable would cost this
+                    // thread what its share of the expansion costs, so it watches the counter instead (bounded: a
+                    // waiter that never comes back must not leave the cores spinning)
+                    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+                    while (a_landed.load(std::memory_order_acquire) <= ticket && !a_stop.load(std::memory_order_relaxed) &&
+                           urgent.load(std::memory_order_relaxed) > 0 && std::chrono::steady_clock::now() < until)
+                        for (int i = 0; i < 16; ++i) _mm_pause();
+                } else {
+                    spin_for(a_landed, ticket);
+                }
                 std::unique_lock<std::mutex> lock(mu);
                 cv_landed.wait(lock, [&] { return stop || landed_upto > ticket; });
                 if (landed_upto <= ticket) return;  // stop, nothing left
@@ -382,6 +406,7 @@ struct bgs_reward_sink {
             const int expanders = threads > 1 ? threads - 1 : 1;
             const int share = threads > 1 ? t - 1 : 0;
             if (threads > 1 && t == 0) continue;
+            const double trace_t0 = sink_trace_on() ? mono_us() : 0.0;
             if (ok && grids) {
                 // (shares are whole 64-game blocks: a block is what the expansion streams out in full cache lines)
                 const int64_t blocks = (job.n_games + 63) / 64;
@@ -398,6 +423,7 @@ struct bgs_reward_sink {
                 if (first + count > job.n_games) count = job.n_games - first;
                 if (count > 0) expand_range(pinned[slot], first, count, job.host_reward);
             }
+            if (sink_trace_on()) fprintf(stderr, "sink-trace ticket %lld worker %d expand %.1f .. %.1f\n", (long long)ticket, t, trace_t0, mono_us());
             {
                 std::lock_guard<std::mutex> lock(mu);
                 if (++parts_done[slot] == expanders) {

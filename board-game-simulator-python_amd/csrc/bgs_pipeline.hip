@@ -40,6 +40,14 @@ struct bgs_pipeline {
     bool consumer = false;
     int lag = 0;
     int64_t timeout_ms = 60000;
+    // [depth] 1: the batch's stream holds work no hand-over accounts for (a step without hand-over):
+    // bgs_pipeline_drain synchronises that stream.  A stream whose last step was handed over is idle once the newest
+    // hand-over has been delivered (deliveries complete in order, a delivery follows its kernel), and a
+    // hipStreamSynchronize on an idle stream still costs ~15 us each: the 45 us between the last delivery and the return
+    // of a drain at the end of a short run (tools/short_run_timeline.py with BGS_SINK_TRACE=1).  (A caller that follows
+    // the drain with hipDeviceSynchronize pays the same ~40 us there instead: it is what the first synchronising call
+    // after a burst of launches on three streams costs, whatever the wait mode.)
+    std::vector<char> dirty;
     // timing brackets
     std::vector<hipEvent_t> ev0, ev1;
     size_t brackets = 0;
@@ -66,6 +74,7 @@ int bgs_pipeline_create(bgs_batch* const* batches, int depth, bgs_reward_sink* s
     NEED(p != nullptr, "out of host memory");
     p->device = batches[0]->device;
     p->batches.assign(batches, batches + depth);
+    p->dirty.assign(depth, 1);  // (whatever the caller enqueued on the streams before)
     for (bgs_batch* b : p->batches) b->launches_in_flight = depth;  // (the launch shape follows it: bgs_set_launches_in_flight)
     p->sink = sink;
     p->gather = gather;
@@ -148,8 +157,10 @@ int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_
                  (long long)t, (long long)j);
             p->ticket[h] = t;
             ++p->handed;
+            p->dirty[p->step % depth] = 0;
         } else {
             if ((rc = bgs_rollout(b, seed, p->max_plies, p->flags))) return rc;
+            p->dirty[p->step % depth] = 1;
         }
         if (bracket != (size_t)-1) {
             // (the rollout kernels that deliver the outcome codes themselves leave nothing but an event record between
@@ -174,7 +185,11 @@ int bgs_pipeline_drain(bgs_pipeline* p) {
     // the consumer sees every hand-over of every rank before it calls the region done
     if (p->rank_words && p->consumer && p->handed > 0 && (rc = consume(p, p->handed - 1))) return rc;
     // steps without hand-over (and everything else the batches have enqueued): their streams run dry
-    for (bgs_batch* b : p->batches) HIP_TRY(hipStreamSynchronize(b->stream));
+    for (size_t k = 0; k < p->batches.size(); ++k) {
+        if (!p->dirty[k] && newest >= 0) continue;   // (nothing behind the delivered hand-over on this stream)
+        HIP_TRY(hipStreamSynchronize(p->batches[k]->stream));
+        p->dirty[k] = 0;
+    }
     return BGS_OK;
 }
 
@@ -191,12 +206,26 @@ int bgs_pipeline_kernel_ms(bgs_pipeline* p, double* mean_ms, int* pairs) {
     double total = 0.0;
     for (size_t k = 0; k < p->brackets; ++k) {
         float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(p->ev1[k]));  // (recorded just behind a delivered hand-over: a formality)
         HIP_TRY(hipEventElapsedTime(&ms, p->ev0[k], p->ev1[k]));
         total += ms;
     }
     *mean_ms = p->brackets ? total / (double)p->brackets : 0.0;
     if (pairs) *pairs = (int)p->brackets;
     p->brackets = 0;  // the events are reused by the next timed region
+    return BGS_OK;
+}
+
+int bgs_pipeline_timeline(bgs_pipeline* p, float* start_ms, float* end_ms, int capacity, int* pairs) {
+    NEED(p != nullptr && start_ms != nullptr && end_ms != nullptr && capacity >= 0, "bad argument");
+    HIP_TRY(hipSetDevice(p->device));
+    const int count = (int)p->brackets < capacity ? (int)p->brackets : capacity;
+    for (int k = 0; k < count; ++k) {
+        HIP_TRY(hipEventSynchronize(p->ev1[k]));
+        HIP_TRY(hipEventElapsedTime(&start_ms[k], p->ev0[0], p->ev0[k]));
+        HIP_TRY(hipEventElapsedTime(&end_ms[k], p->ev0[0], p->ev1[k]));
+    }
+    if (pairs) *pairs = count;
     return BGS_OK;
 }
 

@@ -75,6 +75,14 @@ class RolloutExecutor:
         _abi.check(_abi.lib().bgs_pipeline_kernel_ms(self._handle, ctypes.byref(ms), ctypes.byref(pairs)))
         return (ms.value if pairs.value else None), pairs.value
 
+    def timeline(self, capacity: int = 1024):
+        """[(start_ms, end_ms)] of the bracketed launches, relative to the first one's start -- after `drain()` and before
+        `kernel_ms()` (which resets the brackets)."""
+        a, z = (ctypes.c_float * capacity)(), (ctypes.c_float * capacity)()
+        n = ctypes.c_int(0)
+        _abi.check(_abi.lib().bgs_pipeline_timeline(self._handle, a, z, capacity, ctypes.byref(n)))
+        return [(a[k], z[k]) for k in range(n.value)]
+
     @property
     def steps(self) -> int:
         """Steps enqueued so far; the next step's seed is seed0 + steps."""

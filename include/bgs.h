@@ -287,6 +287,9 @@ int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_
 int bgs_pipeline_drain(bgs_pipeline* p);
 int bgs_pipeline_progress(const bgs_pipeline* p, int64_t* steps, int64_t* handovers);
 int bgs_pipeline_kernel_ms(bgs_pipeline* p, double* mean_ms, int* pairs);
+/* The bracketed launches' start and end, in ms after the first bracket's start (after bgs_pipeline_drain, BEFORE
+ * bgs_pipeline_kernel_ms resets the brackets): where the time of a short timed region goes. */
+int bgs_pipeline_timeline(bgs_pipeline* p, float* start_ms, float* end_ms, int capacity, int* pairs);
 /* N ranks delivering into one shared host array (progress words, see above): rank r's sink announces its deliveries in
  * rank_words[r * word_stride] (bgs_sink_set_progress; the sink must serve this pipeline only), the consumer announces
  * the hand-overs it has released in *consumed.  Every rank: hand-over j waits for the release of hand-over j - n_host

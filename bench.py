@@ -597,7 +597,11 @@ def main() -> int:
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
+        if ring is not None:
+            # the ranks of a node meet on words of the shared segment within microseconds; a barrier collective is a
+            # launch + a kernel + a synchronise on every rank, tens of microseconds of a 0.7 ms region -- twice
+            ring.barrier()
+        elif dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 

@@ -812,6 +812,24 @@ int bgs_progress_wait(const int64_t* words, int64_t count, int64_t stride_words,
     return BGS_OK;
 }
 
+int bgs_progress_barrier(int64_t* words, int64_t count, int64_t stride_words, int64_t mine, int64_t epoch, int64_t spin_us,
+                         int64_t timeout_ms) {
+    NEED(words != nullptr && count >= 1 && stride_words >= 1 && mine >= 0 && mine < count, "bad argument");
+    NEED((reinterpret_cast<uintptr_t>(words) & 7u) == 0, "progress words must be 8-byte aligned");
+    progress_store_max(words + mine * stride_words, epoch);   // (wakes whoever already sleeps on this word)
+    // the others are a few microseconds away when the ranks run in step: watch their words for a while before sleeping
+    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us > 0 ? spin_us : 0);
+    for (int64_t i = 0; i < count; ++i) {
+        auto* a = reinterpret_cast<const std::atomic<int64_t>*>(words + i * stride_words);
+        while (a->load(std::memory_order_acquire) < epoch) {
+            if (std::chrono::steady_clock::now() >= until)
+                return bgs_progress_wait(words, count, stride_words, epoch, timeout_ms, nullptr);
+            for (int k = 0; k < 16; ++k) _mm_pause();
+        }
+    }
+    return BGS_OK;
+}
+
 int bgs_bind_host_thread(int device, int* cpus_out) {
     cpu_set_t cpus;
     int n = 0;

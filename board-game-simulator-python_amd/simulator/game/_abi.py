@@ -121,6 +121,7 @@ SIGNATURES = {
     "bgs_sink_completed": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_int64)]),
     "bgs_sink_set_progress": (ctypes.c_int, [c_handle, ctypes.c_void_p]),
     "bgs_progress_store": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    "bgs_progress_barrier": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
     "bgs_progress_wait": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)],

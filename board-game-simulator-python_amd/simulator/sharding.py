@@ -127,6 +127,7 @@ class SharedRewardRing:
         self._progress = np.frombuffer(self._map, dtype=np.int64, count=8 * (self.world + 1), offset=data).reshape(self.world + 1, 8)
         self._words = self._progress.ctypes.data  # rank r's word at + 64 r, the consumer's at + 64 world
         self._sink = None
+        self._barriers = 0
         # first touch by the rank that will write the rows: the pages land on that rank's NUMA node
         for k in range(self.slots):
             self.mine(k)[...] = 0x55
@@ -167,6 +168,16 @@ class SharedRewardRing:
     def release(self, step: int) -> None:
         """The consumer is done with every step <= `step`: their slots may be overwritten."""
         _abi.check(_abi.lib().bgs_progress_store(ctypes.c_void_p(self._words + 64 * self.world), int(step) + 1))
+
+    def barrier(self, spin_us: int = 2000, timeout: float = 60.0) -> None:
+        """Every rank of the ring has arrived (word 1 of each rank's progress line counts its barriers): ranks that run
+        in step meet within microseconds -- no collective, no GPU work (bgs_progress_barrier)."""
+        self._barriers += 1
+        rc = _abi.lib().bgs_progress_barrier(ctypes.c_void_p(self._words + 8), self.world, 8, self.rank, self._barriers,
+                                             int(spin_us), int(timeout * 1000))
+        if rc != 0:
+            behind = [int(r) for r in (self._progress[: self.world, 1] < self._barriers).nonzero()[0]]
+            raise TimeoutError(f"barrier {self._barriers}: ranks {behind} did not arrive within {timeout} s")
 
     def _wait(self, address: int, count: int, target: int, timeout: float, what: str) -> None:
         laggard = ctypes.c_int64(-1)

@@ -237,6 +237,13 @@ int bgs_sink_completed(bgs_reward_sink* s, int64_t* completed);
  * BGS_ERR_RUNTIME after timeout_ms (< 0: no timeout), *laggard = index of the word that was behind. */
 int bgs_sink_set_progress(bgs_reward_sink* s, int64_t* word);
 int bgs_progress_store(int64_t* word, int64_t value);
+/* A barrier of `count` processes on `count` such words (words[i * stride_words], word `mine` this process's): raises
+ * its own word to `epoch` (1, 2, 3, ... from barrier to barrier), then waits until every word is >= epoch -- watching
+ * them for up to spin_us microseconds before it sleeps as bgs_progress_wait does.  Ranks of one node that run in step
+ * meet within a few microseconds, which a collective on the GPU (a launch, a kernel, a synchronise: tens of microseconds)
+ * cannot match; bench.py brackets its timed region with it when the shared array exists. */
+int bgs_progress_barrier(int64_t* words, int64_t count, int64_t stride_words, int64_t mine, int64_t epoch, int64_t spin_us,
+                         int64_t timeout_ms);
 int bgs_progress_wait(const int64_t* words, int64_t count, int64_t stride_words, int64_t target, int64_t timeout_ms,
                       int64_t* laggard);
 /* Confine the calling thread (and the threads it creates later) to the CPUs of the NUMA node `device` hangs off,

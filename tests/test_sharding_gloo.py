@@ -134,6 +134,28 @@ RING_WORKER = textwrap.dedent(
     assert ring._progress[rank, 0] == steps
     dist.barrier()
     assert ring.done(steps - 1)
+    # the ring's own barrier (words of the shared segment, no collective): nobody passes before the last rank arrives,
+    # whether the others are still spinning (20 ms) or already asleep (spin_us = 0), barrier after barrier
+    for round_, spin in enumerate((2000, 0, 50)):
+        time.sleep(0.02 * ((rank + round_) % world))
+        arrived = time.monotonic()
+        ring.barrier(spin_us=spin)
+        passed = time.monotonic()
+        stamps = [None] * world
+        dist.all_gather_object(stamps, (arrived, passed))
+        assert min(p for _, p in stamps) >= max(a for a, _ in stamps) - 1e-4, stamps
+        assert max(p for _, p in stamps) - max(a for a, _ in stamps) < 0.5, stamps
+    if rank == world - 1:
+        time.sleep(0.5)   # a rank that does not come: the others time out and name it
+    else:
+        try:
+            ring.barrier(spin_us=100, timeout=0.2)
+            raise SystemExit("the barrier let a rank through before everybody had arrived")
+        except TimeoutError as exc:
+            assert str(world - 1) in str(exc), exc
+    if rank == world - 1:
+        ring.barrier()    # (arrives late: everybody else's word is already there)
+    dist.barrier()
     # a directory that cannot hold the ring: the constructor raises on EVERY rank (callers then fall back together)
     try:
         SharedRewardRing(dist, 1 << 40, slots)

@@ -457,7 +457,7 @@ def main() -> int:
                          "memory and every rank's own sink delivers its rows (no collective, every GPU uses its own PCIe "
                          "link); rccl: outcome codes gathered to rank 0's GPU over RCCL inside the library, rank 0's sink "
                          "expands them all")
-    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed steps (hand-over included) before the W warm-up steps until this many milliseconds have "
                     "passed: the GPU's power state climbs for tens of milliseconds under load, and RCCL connects on first "
                     "use; without it a short timed region measures that ramp (0 = off)")

@@ -495,8 +495,10 @@ int rollout_with_codes(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t 
 // Measured (tools/object_latency.py, tools/r3_transition.sh; Connect 6x7x4 / default Bounce, one thread, with the
 // engines leaving out the load of a board the device already holds): staged 53 / 63 us per transition, in place 28 / 46,
 // graph 35 / 52 -- hipGraphLaunch costs more than the five launches it replaces.  From 8 threads the order of in place
-// and graph changed between runs (30 vs 42 and 48 vs 38 thousand Connect transitions per second), so in place is the
-// default and BGS_TRANSITION=staged | graph select the other two; all three run the same kernels.
+// and graph changed between runs (30 vs 42 and 48 vs 38 thousand Connect transitions per second).  The default goes one
+// step further on the packed geometries: in place, with the move and the whole observation in ONE kernel
+// (k_connect_transition / k_bounce_transition) instead of five.  BGS_TRANSITION=staged | mapped | graph select the
+// multi-kernel forms (the only ones for generic geometries and for batches above kSmallTransition boards).
 namespace {
 constexpr int64_t kSmallTransition = 64;
 constexpr size_t kSmallBlock = 64u << 10;
@@ -516,8 +518,9 @@ int transition_mode() {
     static const int mode = [] {
         const char* e = getenv("BGS_TRANSITION");
         if (e && !strcmp(e, "staged")) return 0;
+        if (e && !strcmp(e, "mapped")) return 1;
         if (e && !strcmp(e, "graph")) return 2;
-        return 1;
+        return 3;  // in place, and one fused kernel for move + observation (packed geometries)
     }();
     return mode;
 }
@@ -1136,16 +1139,24 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
             else if (connect) bgs::connect_pack(b, dg, dp, dw, d_load);
             else bgs::bounce_pack(b, dg, dp, dw, dl, d_load);
         }
+        int8_t* og = reinterpret_cast<int8_t*>(d_out + out_grid);
+        int8_t* op = reinterpret_cast<int8_t*>(d_out + out_player);
+        int8_t* ow = reinterpret_cast<int8_t*>(d_out + out_winner);
+        int32_t* ol = reinterpret_cast<int32_t*>(d_out + out_plies);
+        if (mode == 3 && !b->generic) {
+            // the move and the whole observation in one launch (k_connect_transition / k_bounce_transition)
+            const int32_t* da = actions ? reinterpret_cast<const int32_t*>(d_in + in_actions) : nullptr;
+            int8_t* orw = reinterpret_cast<int8_t*>(d_out + out_reward);
+            if (connect) bgs::connect_transition(b, da, d_step, og, op, ow, ol, d_out + out_legal, orw);
+            else bgs::bounce_transition(b, da, d_step, og, op, ow, ol, reinterpret_cast<uint64_t*>(d_out + out_legal), orw);
+            return finish_launch();
+        }
         if (actions) {
             const int32_t* da = reinterpret_cast<const int32_t*>(d_in + in_actions);
             if (b->generic) bgs::generic_step_actions(b, da, d_step);
             else if (connect) bgs::connect_step_actions(b, da, d_step);
             else bgs::bounce_step_actions(b, da, d_step);
         }
-        int8_t* og = reinterpret_cast<int8_t*>(d_out + out_grid);
-        int8_t* op = reinterpret_cast<int8_t*>(d_out + out_player);
-        int8_t* ow = reinterpret_cast<int8_t*>(d_out + out_winner);
-        int32_t* ol = reinterpret_cast<int32_t*>(d_out + out_plies);
         if (b->generic) {
             bgs::generic_unpack_grid(b, og);
             bgs::generic_meta(b, op, nullptr, ow, ol);

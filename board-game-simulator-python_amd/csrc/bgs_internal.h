@@ -132,6 +132,8 @@ namespace bgs {
 void connect_reset(const bgs_batch* b);
 void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count);  // count plies per board
 void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out);
+void connect_transition(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
+                        int8_t* d_winner, int32_t* d_plies, uint8_t* d_legal, int8_t* d_reward_out);
 bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, uint32_t* codes_out);
 void connect_unpack_grid(const bgs_batch* b, int8_t* d_grid);
 void connect_cell_planes(const bgs_batch* b, uint64_t* d_dst);  // wire format of the grid hand-over (see the kernel)
@@ -144,6 +146,8 @@ void connect_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_play
 void bounce_reset(const bgs_batch* b);
 void bounce_step_random(const bgs_batch* b, uint64_t seed, uint32_t count);
 void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out);
+void bounce_transition(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
+                       int8_t* d_winner, int32_t* d_plies, uint64_t* d_targets, int8_t* d_reward_out);
 void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags);
 void bounce_unpack_grid(const bgs_batch* b, int8_t* d_grid);
 void bounce_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies);

@@ -1281,6 +1281,70 @@ k_bounce_step_actions(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
     add_steps(steps, stepped);
 }
 
+// The object API's round trip on a small batch (see k_connect_transition): the chosen move, if any, then grid, player,
+// winner, plies, the targets record and the reward pair of every board in one launch.
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_transition(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+                    uint16_t* __restrict__ reward, int64_t n, const int32_t* __restrict__ moves, int32_t* __restrict__ result,
+                    unsigned long long* __restrict__ steps, int8_t* __restrict__ grid, int8_t* __restrict__ player,
+                    int8_t* __restrict__ winner, int32_t* __restrict__ plies_out, uint64_t* __restrict__ targets,
+                    uint16_t* __restrict__ reward_out) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    uint32_t stepped = 0;
+    if (i < n) {
+        Board b = load_board(planes, n, i);
+        uint32_t st = status[i];
+        uint32_t plies = plies_buf[i];
+        uint16_t pair = reward[i];
+        if (moves) {
+            const int sx = moves[4 * i], sy = moves[4 * i + 1], tx = moves[4 * i + 2], ty = moves[4 * i + 3];
+            int32_t rc = 0;
+            if (sx >= 0) {
+                rc = -2;  // BGS_ERR_ILLEGAL
+                const bool inside = sx < g.w && sy >= 0 && sy < g.h && tx >= 0 && tx < g.w && ty >= 0 && ty < g.h;
+                if (inside && st == BGS_ST_RUNNING && plies < kMaxPlies) {
+                    const uint32_t mover = plies & 1u;
+                    const uint64_t occ = occupancy(b);
+                    const int s = sy * g.w + sx, t = ty * g.w + tx;
+                    if (((movable(g, occ, mover) >> s) & 1ull) && ((reach(g, b, occ, mover, s) >> t) & 1ull)) {
+                        move_piece(b, s, t);
+                        ++plies;
+                        uint32_t n_next;
+                        const uint32_t after = settle(g, b, mover, t, n_next);
+                        store_board(planes, n, i, b);
+                        plies_buf[i] = (uint16_t)plies;
+                        if (after != BGS_ST_RUNNING) {
+                            st = after;
+                            pair = reward_pair(st);
+                            status[i] = (uint8_t)st;
+                            reward[i] = pair;
+                        }
+                        stepped = 1;
+                        rc = 0;
+                    }
+                }
+            }
+            result[i] = rc;
+        }
+        const int hw = g.h * g.w;
+        for (int c = 0; c < hw; ++c) grid[i * hw + c] = (int8_t)value_at(b, c);
+        player[i] = (int8_t)(plies & 1u);
+        winner[i] = st == 0 ? -1 : (st == BGS_ST_DRAW ? 2 : (int8_t)(st - 1));
+        plies_out[i] = (int32_t)plies;
+        const uint64_t occ = occupancy(b);
+        const uint32_t mover = plies & 1u;
+        const uint64_t src = st == BGS_ST_RUNNING ? movable(g, occ, mover) : 0ull;
+        const int row = src ? (int)(((uint32_t)(__ffsll((unsigned long long)src) - 1) * g.inv_w) >> 16) : 0;
+        for (int x = 0; x < g.w; ++x) {
+            const int c = row * g.w + x;
+            targets[i * (g.w + 1) + x] = ((src >> c) & 1ull) ? reach(g, b, occ, mover, c) : 0ull;
+        }
+        targets[i * (g.w + 1) + g.w] = src ? (uint64_t)row : ~0ull;
+        reward_out[i] = pair;
+    }
+    add_steps(steps, stepped);
+}
+
 // packed planes -> reference layout int8[n][H][W]: one lane expands one board into the workgroup's LDS tile, the
 // workgroup streams the tile out with 16-byte stores
 __global__ void __launch_bounds__(BGS_BLOCK)
@@ -1569,6 +1633,13 @@ void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_
     hipLaunchKernelGGL(k_bounce_step_actions, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
                        b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_moves, d_status_out,
                        b->d_steps);
+}
+
+void bounce_transition(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
+                       int8_t* d_winner, int32_t* d_plies, uint64_t* d_targets, int8_t* d_reward_out) {
+    hipLaunchKernelGGL(k_bounce_transition, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->d_status,
+                       b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_moves, d_status_out, b->d_steps, d_grid,
+                       d_player, d_winner, d_plies, d_targets, reinterpret_cast<uint16_t*>(d_reward_out));
 }
 
 void bounce_unpack_grid(const bgs_batch* b, int8_t* d_grid) {

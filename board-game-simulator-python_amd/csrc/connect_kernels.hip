@@ -1622,6 +1622,69 @@ k_connect_legal(G g, const uint64_t* __restrict__ planes, const uint8_t* __restr
     if (count) count[i] = __popc(open);
 }
 
+// The object API's round trip on a small batch (bgs_transition, n <= 64): the chosen move, if any, and then everything a
+// State shows -- grid, player, winner, plies, open columns, reward pair -- in ONE launch instead of five (step, unpack,
+// meta, legal, reward copy).  A thread owns a board; the outputs are plain per-board records (the caller passes host
+// memory the device addresses: a few hundred bytes over PCIe).  Same device functions as the kernels it stands in for.
+template <class G>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_transition(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward, int64_t n,
+                     const int32_t* __restrict__ actions, int32_t* __restrict__ result, unsigned long long* __restrict__ steps,
+                     int8_t* __restrict__ grid, int8_t* __restrict__ player, int8_t* __restrict__ winner,
+                     int32_t* __restrict__ plies, uint8_t* __restrict__ legal, uint16_t* __restrict__ reward_out) {
+    constexpr int NW = G::NW;
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    uint32_t stepped = 0;
+    if (i < n) {
+        Bits<NW> p0, p1;
+        load_planes<NW>(planes, n, i, p0, p1);
+        uint32_t st = status[i];
+        uint16_t pair = reward[i];
+        if (actions) {
+            const int col = actions[i];
+            int32_t rc = 0;
+            if (col >= 0) {
+                rc = -2;  // BGS_ERR_ILLEGAL
+                if (st == BGS_ST_RUNNING) {
+                    Lane<NW> l = make_lane(g, p0, p1);
+                    uint32_t after = 0;
+                    if (play_column(g, l, col, after)) {
+                        lane_planes(l, p0, p1);
+                        store_planes<NW>(planes, n, i, p0, p1);
+                        if (after != BGS_ST_RUNNING) {
+                            st = after;
+                            pair = reward_pair(st);
+                            status[i] = (uint8_t)st;
+                            reward[i] = pair;
+                        }
+                        stepped = 1;
+                        rc = 0;
+                    }
+                }
+            }
+            result[i] = rc;
+        }
+        const int h = g.h(), w = g.w();
+        int8_t* cells = grid + i * h * w;
+        uint32_t count = 0;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const int bit = x * (h + 1) + y;
+                const uint32_t b0 = test_bit(p0, bit), b1 = test_bit(p1, bit);
+                cells[y * w + x] = (int8_t)(b0 + 2u * b1 - 1u);  // -1 empty, 0 player 0, 1 player 1
+                count += b0 + b1;
+            }
+        player[i] = (int8_t)(count & 1u);
+        winner[i] = st == 0 ? -1 : (st == BGS_ST_DRAW ? 2 : (int8_t)(st - 1));
+        plies[i] = (int32_t)count;
+        const Lane<NW> l = make_lane(g, p0, p1);
+        const uint32_t open = st == BGS_ST_RUNNING ? (~l.full & g.all_columns()) : 0u;
+        for (int x = 0; x < w; ++x) legal[i * w + x] = (open >> x) & 1u;
+        reward_out[i] = pair;
+    }
+    add_steps(steps, stepped);
+}
+
 // reference layout -> packed planes, with validation (gravity, stone counts, cell codes)
 template <class G>
 __global__ void __launch_bounds__(BGS_BLOCK)
@@ -1930,6 +1993,16 @@ void connect_legal(const bgs_batch* b, uint8_t* d_legal, int32_t* d_count) {
         using G = decltype(g);
         hipLaunchKernelGGL((k_connect_legal<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g, b->d_planes,
                            b->d_status, b->n, d_legal, d_count);
+    });
+}
+
+void connect_transition(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
+                        int8_t* d_winner, int32_t* d_plies, uint8_t* d_legal, int8_t* d_reward_out) {
+    dispatch(b->cg, [&](auto g) {
+        using G = decltype(g);
+        hipLaunchKernelGGL((k_connect_transition<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g, b->d_planes,
+                           b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_actions, d_status_out, b->d_steps,
+                           d_grid, d_player, d_winner, d_plies, d_legal, reinterpret_cast<uint16_t*>(d_reward_out));
     });
 }
 

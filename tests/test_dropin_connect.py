@@ -246,15 +246,16 @@ print(h.hexdigest())
 
 
 def test_the_three_forms_of_the_round_trip_agree():
-    """bgs_transition on a one-board batch: staged copies, blocks the device addresses in host memory (the default),
-    and the same launches replayed from a HIP graph (BGS_TRANSITION) -- one digest over three playthroughs."""
+    """bgs_transition on a one-board batch: staged copies, blocks the device addresses in host memory, the same launches
+    replayed from a HIP graph, and the default -- in place with move + observation fused into one kernel
+    (BGS_TRANSITION) -- one digest over three playthroughs (12x13x5 and Bounce included)."""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = _PLAYTHROUGH.format(root=root, pkg=os.path.join(root, "board-game-simulator-python_amd"))
     digests = {}
-    for form in ("staged", "mapped", "graph"):
+    for form in ("staged", "mapped", "graph", "fused"):
         env = dict(os.environ, BGS_TRANSITION=form)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]

@@ -2,7 +2,7 @@
 # object API round trip: staged copies vs host-mapped blocks vs one replayed HIP graph (BGS_TRANSITION)
 set -e
 mkdir -p gpurun_out
-for mode in staged mapped graph auto; do
+for mode in staged mapped graph fused; do
   echo "== $mode"
   BGS_TRANSITION=$mode timeout -k 10 200 python tools/object_latency.py > gpurun_out/object_latency_$mode.json
   cat gpurun_out/object_latency_$mode.json

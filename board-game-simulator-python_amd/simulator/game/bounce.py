@@ -11,7 +11,6 @@ an empty cell, otherwise the piece's step count.
 
 from __future__ import annotations
 
-import ctypes
 import os
 import threading
 from typing import Any, ClassVar, Dict, List, Tuple
@@ -19,6 +18,7 @@ from typing import Any, ClassVar, Dict, List, Tuple
 import numpy as np
 
 from . import _abi
+from ._engine import EngineBase, EngineCache
 from ._value import ValueObject
 from ..batch import BounceBatch
 
@@ -34,28 +34,21 @@ def _as_cell(value, what: str) -> Cell:
     return int(a[0]), int(a[1])
 
 
-class _Engine:
+class _Engine(EngineBase):
     """One-board device batch per start grid AND per calling thread, each on a HIP stream of its own (see connect.py)."""
 
-    _local = threading.local()
+    _cache = EngineCache()
 
     def __init__(self, grid: np.ndarray):
         self.batch = BounceBatch(grid, 1, device=_DEVICE, use_torch=False)
         self.lock = threading.Lock()  # (uncontended: the engine belongs to one thread)
-        stream = ctypes.c_void_p()
-        _abi.check(_abi.lib().bgs_stream_create(_DEVICE, ctypes.byref(stream)))
-        self.batch.set_stream(stream.value)
+        self._own_stream(_DEVICE)
         self.call = self.batch.one_board_call()
         self.held = None  # (grid bytes, player, winner, plies) of the board the device batch holds, when known
 
     @classmethod
     def get(cls, grid: np.ndarray) -> "_Engine":
-        cache = cls._local.__dict__.setdefault("engines", {})
-        key = (grid.shape, grid.tobytes())
-        eng = cache.get(key)
-        if eng is None:
-            eng = cache[key] = _Engine(grid)
-        return eng
+        return cls._cache.get((grid.shape, grid.tobytes()), lambda: _Engine(grid))
 
     def _round_trip(self, grid=None, player=0, winner=-1, plies=0, move=None):
         """One fused call (bgs_transition): optional load, optional move, then the observations a State needs.  The

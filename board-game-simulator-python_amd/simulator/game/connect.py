@@ -18,36 +18,30 @@ from typing import Any, ClassVar, Dict, List, Tuple
 import numpy as np
 
 from . import _abi
+from ._engine import EngineBase, EngineCache
 from ._value import ValueObject
 from ..batch import ConnectBatch
 
 _DEVICE = int(os.environ.get("BGS_DEVICE", "0"))
 
 
-class _Engine:
+class _Engine(EngineBase):
     """One-board device batch that evaluates transitions for the object API: one per geometry AND per calling thread,
     each on a HIP stream of its own, so the thread pools the reference's callers use (8 boards at once in
     textual/examples/arena.py:53, agent.py:61,71) run their round trips side by side instead of queueing on one lock."""
 
-    _local = threading.local()
+    _cache = EngineCache()
 
     def __init__(self, height: int, width: int, count: int):
         self.batch = ConnectBatch(height, width, count, 1, device=_DEVICE, use_torch=False)
         self.lock = threading.Lock()  # (uncontended: the engine belongs to one thread; States may cross threads, engines do not)
-        stream = ctypes.c_void_p()
-        _abi.check(_abi.lib().bgs_stream_create(_DEVICE, ctypes.byref(stream)))
-        self.batch.set_stream(stream.value)
+        self._own_stream(_DEVICE)
         self.call = self.batch.one_board_call()
         self.held = None  # (grid bytes, player, winner) of the board the device batch holds, when known
 
     @classmethod
     def get(cls, height: int, width: int, count: int) -> "_Engine":
-        cache = cls._local.__dict__.setdefault("engines", {})
-        key = (height, width, count)
-        eng = cache.get(key)
-        if eng is None:
-            eng = cache[key] = _Engine(height, width, count)
-        return eng
+        return cls._cache.get((height, width, count), lambda: _Engine(height, width, count))
 
     def _round_trip(self, grid=None, player=0, winner=-1, column=None):
         """One fused call (bgs_transition): optional load, optional move, then the observations a State needs.  The

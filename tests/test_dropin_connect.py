@@ -261,3 +261,24 @@ def test_the_three_forms_of_the_round_trip_agree():
         assert out.returncode == 0, out.stderr[-2000:]
         digests[form] = out.stdout.strip().splitlines()[-1]
     assert len(set(digests.values())) == 1, digests
+
+
+def test_engine_cache_is_bounded_and_evicted_configs_still_play():
+    """A thread keeps at most 32 one-board engines per game (device batch + stream + two page-locked blocks each); a
+    Config whose engine was evicted gets a new one on its next use, and its old States still step correctly."""
+    from oracle import oracle
+    from simulator.game import _engine
+    from simulator.game.connect import Config, _Engine
+
+    first = Config(4, 5, 3)
+    s0 = first.sample_initial_state()
+    child = s0.action_at(2).sample_next_state()
+    for width in range(2, 2 + _engine.MAX_ENGINES_PER_THREAD + 6):
+        Config(3, width, 3).sample_initial_state()
+    engines = _Engine._cache._local.engines
+    assert len(engines) <= _engine.MAX_ENGINES_PER_THREAD and (4, 5, 3) not in engines
+    again = child.action_at(2).sample_next_state()  # an old State of the evicted Config: new engine, board reloaded
+    orc = oracle.ConnectOracle(4, 5, 3, 1)
+    orc.step_actions([2]); orc.step_actions([2])
+    np.testing.assert_array_equal(again.grid, orc.grid[0])
+    assert (4, 5, 3) in engines

@@ -25,6 +25,10 @@ ref = make(BGS_BOUNCE_PIECES=0, BGS_BOUNCE_PLAN="single", BGS_BOUNCE_PARK=0)
 variants = {"K3p default (bulk + tail)": make(), "K3p single launch": make(BGS_BOUNCE_PLAN="single"),
             "K3p 64 waves": make(BGS_BOUNCE_FLAT_WAVES=64), "K3p park 5 / 300 waves": make(BGS_BOUNCE_PARK=5, BGS_BOUNCE_FLAT_WAVES=300),
             "K3p tail at 96": make(BGS_BOUNCE_PLAN="96:1,0:8")}
+# the launch shapes of bounce_shape(): one launch at a time (the default above), 8 and 16 in flight
+for hint in (8, 16):
+    variants[f"K3p shape of {hint} in flight"] = make()
+    variants[f"K3p shape of {hint} in flight"].set_launches_in_flight(hint)
 t0 = time.perf_counter()
 for s in range(seeds):
     seed = 0xABCDEF0123 + 7919 * s

@@ -167,3 +167,34 @@ def test_progress_words_wake_sleepers_and_never_move_backwards():
     assert rc == _abi.BGS_ERR_RUNTIME and laggard.value == 1 and 0.1 < time.monotonic() - t0 < 2.0
     assert "timed out" in _abi.last_error()
     assert lib.bgs_progress_wait(ctypes.c_void_p(base + 4), 1, 1, 0, 0, None) == _abi.BGS_ERR_ARG  # misaligned
+
+
+def test_engine_cache_evicts_least_recently_used_per_thread():
+    """simulator.game._engine.EngineCache (host logic, no GPU): bounded per thread, least recently used out first and
+    closed, threads do not see each other's engines."""
+    import threading
+
+    from simulator.game import _engine
+
+    class Fake:
+        closed = 0
+
+        def __init__(self, key):
+            self.key = key
+
+        def close(self):
+            Fake.closed += 1
+
+    cache = _engine.EngineCache()
+    cap = _engine.MAX_ENGINES_PER_THREAD
+    first = cache.get(0, lambda: Fake(0))
+    for k in range(1, cap):
+        cache.get(k, lambda k=k: Fake(k))
+    assert cache.get(0, lambda: Fake("again")) is first and Fake.closed == 0   # 0 is now the most recently used
+    cache.get(cap, lambda: Fake(cap))                                          # one too many: key 1 goes, not key 0
+    assert Fake.closed == 1 and cache.get(0, lambda: Fake("again")) is first
+    assert cache.get(1, lambda: Fake("new 1")).key == "new 1"
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(cache.get(0, lambda: Fake("other thread")).key))
+    t.start(); t.join()
+    assert seen == ["other thread"]

@@ -12,6 +12,12 @@
 // ranks delivering into a shared host array) or a reward gather (RCCL to rank 0).
 #include <cstdlib>
 #include <new>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <immintrin.h>
 #include <vector>
 
 #include "bgs_capi_util.h"
@@ -19,6 +25,47 @@
 #include "bgs_internal.h"
 
 using bgs::fail;
+
+// A thread that synchronises ONE stream when a drain says so.  hipStreamSynchronize is a marker's round trip through the
+// GPU even on a stream that has run dry (~15 us), and whichever synchronising call ends the caller's region pays it
+// once per stream, one after the other (3 streams: 40-45 us at the end of a 0.7 ms region).  With one of these per
+// stream the round trips run side by side and BEHIND the last kernels, while the sink still expands the last delivery:
+// the draining thread only waits for the delivery and for their flags, and the caller's own hipDeviceSynchronize finds
+// idle streams (5 us).  tools/r3_drain.sh: 20-step regions 6.48 -> 6.83 x 10^11, last delivery expanded -> device
+// synchronised 55 -> 22 us.  The threads sleep between drains.
+struct StreamSyncer {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    int cmd = 0;                // (under mu) 0 asleep, 1 go, 2 exit
+    std::atomic<int> done{1};   // 0 while a synchronise is in flight
+    std::atomic<int> err{0};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void run() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return cmd != 0; });
+                if (cmd == 2) return;
+                cmd = 0;
+            }
+            if (hipStreamSynchronize(stream) != hipSuccess) err.store(1, std::memory_order_relaxed);
+            done.store(1, std::memory_order_release);
+        }
+    }
+    void go(hipStream_t s) {
+        stream = s;
+        done.store(0, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> lock(mu); cmd = 1; }
+        cv.notify_one();
+    }
+    bool wait() {   // true: the stream is idle; false: the synchronise failed
+        while (!done.load(std::memory_order_acquire)) _mm_pause();
+        return err.exchange(0) == 0;
+    }
+};
 
 struct bgs_pipeline {
     int device = 0;
@@ -40,14 +87,7 @@ struct bgs_pipeline {
     bool consumer = false;
     int lag = 0;
     int64_t timeout_ms = 60000;
-    // [depth] 1: the batch's stream holds work no hand-over accounts for (a step without hand-over):
-    // bgs_pipeline_drain synchronises that stream.  A stream whose last step was handed over is idle once the newest
-    // hand-over has been delivered (deliveries complete in order, a delivery follows its kernel), and a
-    // hipStreamSynchronize on an idle stream still costs ~15 us each: the 45 us between the last delivery and the return
-    // of a drain at the end of a short run (tools/short_run_timeline.py with BGS_SINK_TRACE=1).  (A caller that follows
-    // the drain with hipDeviceSynchronize pays the same ~40 us there instead: it is what the first synchronising call
-    // after a burst of launches on three streams costs, whatever the wait mode.)
-    std::vector<char> dirty;
+    std::vector<std::unique_ptr<StreamSyncer>> syncers;   // [depth], started by the first drain of a pipeline deeper than 1
     // timing brackets
     std::vector<hipEvent_t> ev0, ev1;
     size_t brackets = 0;
@@ -74,7 +114,6 @@ int bgs_pipeline_create(bgs_batch* const* batches, int depth, bgs_reward_sink* s
     NEED(p != nullptr, "out of host memory");
     p->device = batches[0]->device;
     p->batches.assign(batches, batches + depth);
-    p->dirty.assign(depth, 1);  // (whatever the caller enqueued on the streams before)
     for (bgs_batch* b : p->batches) b->launches_in_flight = depth;  // (the launch shape follows it: bgs_set_launches_in_flight)
     p->sink = sink;
     p->gather = gather;
@@ -157,10 +196,8 @@ int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_
                  (long long)t, (long long)j);
             p->ticket[h] = t;
             ++p->handed;
-            p->dirty[p->step % depth] = 0;
         } else {
             if ((rc = bgs_rollout(b, seed, p->max_plies, p->flags))) return rc;
-            p->dirty[p->step % depth] = 1;
         }
         if (bracket != (size_t)-1) {
             // (the rollout kernels that deliver the outcome codes themselves leave nothing but an event record between
@@ -180,17 +217,40 @@ int bgs_pipeline_drain(bgs_pipeline* p) {
     // the newest hand-over first: every waiter it turns urgent stays so until the last delivery is in
     int64_t newest = -1;
     for (int64_t t : p->ticket) newest = t > newest ? t : newest;
-    if (newest >= 0 && (rc = wait_ticket(p, newest, true))) return rc;   // (deliveries complete in ticket order)
+    // every stream is synchronised by its helper, starting NOW (see StreamSyncer); BGS_DRAIN_SERIAL_SYNC=1: by this
+    // thread, one after the other, once the deliveries are in (the A/B of tools/r3_drain.sh)
+    const size_t depth = p->batches.size();
+    static const bool serial = getenv("BGS_DRAIN_SERIAL_SYNC") != nullptr;
+    const bool helpers = depth > 1 && !serial;
+    if (helpers) {
+        while (p->syncers.size() < depth) {
+            p->syncers.emplace_back(new StreamSyncer());
+            StreamSyncer* h = p->syncers.back().get();
+            h->device = p->device;
+            h->th = std::thread([h] { h->run(); });
+        }
+        for (size_t k = 0; k < depth; ++k) p->syncers[k]->go(p->batches[k]->stream);
+    }
+    auto streams_idle = [&]() -> int {   // (on every path out: a helper must not be left inside a synchronise)
+        bool ok = true;
+        for (size_t k = 0; k < depth; ++k) {
+            if (helpers) ok = p->syncers[k]->wait() && ok;
+            else ok = hipStreamSynchronize(p->batches[k]->stream) == hipSuccess && ok;
+        }
+        return ok ? BGS_OK : fail(BGS_ERR_RUNTIME, "hipStreamSynchronize failed in bgs_pipeline_drain");
+    };
+    if (newest >= 0 && (rc = wait_ticket(p, newest, true))) {   // (deliveries complete in ticket order)
+        (void)streams_idle();
+        return rc;
+    }
     for (size_t h = 0; h < p->ticket.size(); ++h) p->ticket[h] = -1;
     // the consumer sees every hand-over of every rank before it calls the region done
-    if (p->rank_words && p->consumer && p->handed > 0 && (rc = consume(p, p->handed - 1))) return rc;
-    // steps without hand-over (and everything else the batches have enqueued): their streams run dry
-    for (size_t k = 0; k < p->batches.size(); ++k) {
-        if (!p->dirty[k] && newest >= 0) continue;   // (nothing behind the delivered hand-over on this stream)
-        HIP_TRY(hipStreamSynchronize(p->batches[k]->stream));
-        p->dirty[k] = 0;
+    if (p->rank_words && p->consumer && p->handed > 0 && (rc = consume(p, p->handed - 1))) {
+        (void)streams_idle();
+        return rc;
     }
-    return BGS_OK;
+    // steps without hand-over (and everything else the batches have enqueued): their streams run dry
+    return streams_idle();
 }
 
 int bgs_pipeline_progress(const bgs_pipeline* p, int64_t* steps, int64_t* handovers) {
@@ -233,6 +293,11 @@ int bgs_pipeline_destroy(bgs_pipeline* p) {
     if (!p) return BGS_OK;
     (void)hipSetDevice(p->device);
     (void)bgs_pipeline_drain(p);
+    for (auto& h : p->syncers) {
+        { std::lock_guard<std::mutex> lock(h->mu); h->cmd = 2; }
+        h->cv.notify_one();
+        if (h->th.joinable()) h->th.join();
+    }
     for (auto e : p->ev0) (void)hipEventDestroy(e);
     for (auto e : p->ev1) (void)hipEventDestroy(e);
     delete p;

@@ -1,9 +1,9 @@
 #!/bin/bash
-# the closing synchronize of a short run: runtime wait modes
+# the end of a short run: every stream synchronised by a helper thread from the start of the drain, or by the draining thread at its end
 mkdir -p gpurun_out
-for knob in "X=1" "ROC_ACTIVE_WAIT_TIMEOUT=2000" "ROC_CPU_WAIT_FOR_SIGNAL=1" "BGS_SCHEDULE_SPIN=1" "X=1"; do
+for knob in "X=1" "BGS_DRAIN_SERIAL_SYNC=1" "X=1" "BGS_DRAIN_SERIAL_SYNC=1"; do
   echo "== $knob"
-  env $knob BGS_SINK_TRACE=1 python tools/short_run_timeline.py 20 4 > gpurun_out/_t.json 2> gpurun_out/sink_trace.txt
+  env $knob BGS_SINK_TRACE=1 python tools/short_run_timeline.py 20 5 > gpurun_out/_t.json 2> gpurun_out/sink_trace.txt
   python - <<'PY'
 import re
 lines=open('gpurun_out/sink_trace.txt').read().splitlines()
@@ -19,7 +19,7 @@ for h in [l for l in lines if l.startswith('host-trace')][1:]:
     last=max(t for t in land if land[t]<=td+1)
     print('  landed %.1f expanded %.1f drain returns %.1f synchronized %.1f' % (land[last]-t0, max(exp[last])-t0, td-t0, ts-t0))
 PY
-  for i in 1 2; do env $knob python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
+  for i in 1 2 3; do env $knob python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-device-resident 2>/dev/null | python -c "
 import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('  bench 20: %.1f G/s of3 %s' % (d['value']/1e9, [round(v/1e9,1) for v in d.get('values_of_3',[])]))"; done
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('  bench 20: of3 %s' % ([round(v/1e9,1) for v in d.get('values_of_3',[])]))"; done
 done

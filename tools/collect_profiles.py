@@ -49,8 +49,32 @@ def main():
         insts = sum(k.get("SQ_ACTIVE_INST_VALU", 0.0) * k.get("dispatches", 1) for k in s.values())
         if insts:
             total["active_lanes_per_valu_instruction"] = lanes / insts
+        extra = {}
+        if tag == "bench":
+            # the same kernel under `rocprofv3 --kernel-trace --stats -- python3 bench.py` (the bench's own command: pre-warm,
+            # warm-up and 200 timed steps, three launches in flight throughout)
+            try:
+                full = summary("benchfull", want)
+                if full:
+                    k = next(iter(full.values()))
+                    extra["same_command_as_bench"] = {
+                        "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-other-configs --no-device-resident --no-repeats",
+                        "dispatches": k.get("dispatches"), "mean_us": k.get("mean_us"), "min_us": k.get("min_us"), "max_us": k.get("max_us")}
+                    # what the bench itself read INSIDE that traced run: the tracer's per-dispatch work thins the overlap
+                    # of the three launches in flight, so the run is slower and its kernels, sharing the chip less, shorter
+                    log = os.path.join(ROOT, "gpurun_out", "prof_benchfull_stats.log")
+                    if os.path.exists(log):
+                        lines = [ln for ln in open(log) if ln.startswith("{")]
+                        if lines:
+                            line = json.loads(lines[-1])
+                            extra["same_command_as_bench"]["bench_line_inside_the_traced_run"] = {
+                                "value": line["value"], "ms_per_step": line["ms_per_step"],
+                                "kernel_ms_per_launch_live": line["roofline"].get("kernel_ms_per_launch"),
+                                "event_pairs": line["roofline"].get("event_pairs")}
+            except Exception as exc:
+                print(f"no benchfull pass: {exc}", file=sys.stderr)
         with open(os.path.join(OUT, name), "w") as fh:
-            json.dump(dict({"build_id": build, "method": method}, **total, kernels=s), fh, indent=1)
+            json.dump(dict({"build_id": build, "method": method}, **total, **extra, kernels=s), fh, indent=1)
     misc = summary("misc")
     with open(os.path.join(OUT, "r03_misc_kernel_stats.json"), "w") as fh:
         json.dump({"build_id": build, "command": "rocprofv3 --kernel-trace --stats -- python3 tools/measure_all.py", "kernels": misc}, fh, indent=1)

@@ -7,6 +7,10 @@ set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 # K2a: the bench itself (hand-over included), 12 timed launches in the counter passes
 bash tools/profile_kernel.sh bench python3 bench.py --steps 10 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-device-resident --no-other-configs --no-repeats
+# ... and rocprofv3 --kernel-trace --stats of the bench's OWN command (200 timed steps behind the pre-warm): the mean
+# duration of the bench kernel there is what the line's live kernel_ms_per_launch has to agree with (the 12-launch
+# counter passes above are half ramp and tail)
+( cd /tmp && export TMPDIR=/tmp && rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_benchfull_stats && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_benchfull_stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-other-configs --no-device-resident --no-repeats > $GRAFT_REPO_ROOT/gpurun_out/prof_benchfull_stats.log 2>&1 ) || echo "pass failed: benchfull stats"
 # K1s: the HBM-bound per-ply kernel at 2^24 boards
 bash tools/profile_kernel.sh k1 python3 tools/k1_steps.py
 # K2c: Connect(12,13,5), 2^18 boards

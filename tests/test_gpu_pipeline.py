@@ -54,9 +54,13 @@ def test_executor_delivers_every_step_in_order(depth, slots):
         exe.enqueue(slots + 2, True)
         exe.drain()
         assert exe.steps == 12 + slots and exe.handovers == 9 + slots
+        line = exe.timeline()                 # (start, end) of the bracketed launches, ms after the first one's start
+        assert len(line) == 4 and line[0][0] == 0.0 and all(0.0 <= a < z for a, z in line)
+        assert [a for a, _ in line] == sorted(a for a, _ in line)   # launches on one device start in enqueue order
         ms, pairs = exe.kernel_ms()
-        assert pairs == 4 and ms > 0
-        assert exe.kernel_ms() == (None, 0)   # the brackets are consumed
+        assert pairs == 4 and ms > 0 and abs(ms - sum(z - a for a, z in line) / 4) < 1e-3
+        assert exe.kernel_ms() == (None, 0) and exe.timeline() == []   # the brackets are consumed
+        exe.drain(); exe.drain()              # (a drain with nothing to wait for, twice: the helpers are idle)
         # hand-over j came from step j (j < 7) or step j + 3 (j >= 7)
         for j in range(exe.handovers - slots, exe.handovers):
             step = j if j < 7 else j + 3

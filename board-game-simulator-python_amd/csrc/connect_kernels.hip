@@ -663,9 +663,28 @@ k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __rest
     int64_t t = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
     ulonglong2 a{0, 0}, b{0, 0};
     uint32_t s2 = 0;
+    // one ply per launch touches every board exactly once: non-temporal accesses (nothing is worth keeping in L2)
+    constexpr bool NT = SINGLE;
+    auto load2 = [](const ulonglong2* p) -> ulonglong2 {
+        if constexpr (NT) {
+            const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+            return ulonglong2{__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1)};
+        } else {
+            return *p;
+        }
+    };
+    auto store2 = [](ulonglong2* p, ulonglong2 v) {
+        if constexpr (NT) {
+            unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+            __builtin_nontemporal_store(v.x, q);
+            __builtin_nontemporal_store(v.y, q + 1);
+        } else {
+            *p = v;
+        }
+    };
     if (t < pairs) {
-        a = plane0[t];
-        b = plane1[t];
+        a = load2(plane0 + t);
+        b = load2(plane1 + t);
         s2 = status2[t];
     }
     while (t < pairs) {
@@ -674,8 +693,8 @@ k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __rest
         ulonglong2 an{0, 0}, bn{0, 0};
         uint32_t s2n = 0;
         if (tn < pairs) {
-            an = plane0[tn];
-            bn = plane1[tn];
+            an = load2(plane0 + tn);
+            bn = load2(plane1 + tn);
             s2n = status2[tn];
         }
         uint32_t st0 = s2 & 255u, st1 = s2 >> 8;
@@ -689,8 +708,8 @@ k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __rest
             // that 16-byte store is skipped -- in lock-step play both boards have the same side to move
             const bool touch0 = !SINGLE || p00 != a.x || p10 != a.y;
             const bool touch1 = !SINGLE || p01 != b.x || p11 != b.y;
-            if (touch0) reinterpret_cast<ulonglong2*>(planes)[t] = ulonglong2{p00, p10};
-            if (touch1) reinterpret_cast<ulonglong2*>(planes + n)[t] = ulonglong2{p01, p11};
+            if (touch0) store2(reinterpret_cast<ulonglong2*>(planes) + t, ulonglong2{p00, p10});
+            if (touch1) store2(reinterpret_cast<ulonglong2*>(planes + n) + t, ulonglong2{p01, p11});
             if (st0 != was0 || st1 != was1) {
                 reinterpret_cast<uint16_t*>(status)[t] = (uint16_t)(st0 | (st1 << 8));
                 reinterpret_cast<uint32_t*>(reward)[t] = (uint32_t)reward_pair(st0) | ((uint32_t)reward_pair(st1) << 16);
@@ -1782,7 +1801,10 @@ void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
     if (b->cg.nw == 1 && (b->n & 1) == 0 && !b->rollout_generic) {
         const int64_t pairs = b->n >> 1;
         int64_t blocks = (pairs + BGS_BLOCK - 1) / BGS_BLOCK;
-        const int64_t resident = (int64_t)b->num_cus * 8;  // 8 workgroups of 4 waves per CU
+        // 16 workgroups of 4 waves per CU: twice what is resident, so a CU that finishes its share early takes more
+        // (tools/r3_k1.sh at 2^24 boards, one ply: 4 / 6 / 8 / 12 / 16 / 32 per CU = 4.35 / 4.68 / 4.75 / 4.96 / 4.94 / 4.83
+        // TB/s; with the non-temporal accesses 16 per CU reads 5.04)
+        const int64_t resident = (int64_t)b->num_cus * 16;
         if (blocks > resident) blocks = resident;
         dispatch(b->cg, [&](auto g) {
             using G = decltype(g);

@@ -687,6 +687,7 @@ k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __rest
         b = load2(plane1 + t);
         s2 = status2[t];
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // (the first pair has arrived: the loop never has to wait at its top, see below)
     while (t < pairs) {
         // the next pair's loads go out before this pair is played
         const int64_t tn = t + stride;
@@ -703,6 +704,14 @@ k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __rest
         uint64_t p00 = a.x, p01 = b.x, p10 = a.y, p11 = b.y;  // board 2t: planes p00 / p01, board 2t + 1: p10 / p11
         const uint32_t n0 = play_plies<SINGLE>(g, bottoms, cells, p00, p01, st0, seed, game, count);
         const uint32_t n1 = play_plies<SINGLE>(g, bottoms, cells, p10, p11, st1, seed, game + 1ull, count);
+        // The next pair's loads have had this pair's play to arrive: wait for them HERE, before this pair's stores go
+        // out.  Left to itself the compiler waits at the top of the next iteration -- after that iteration's own loads
+        // were issued, and with vmcnt(0) because a run-time number of stores sits between the two: it waited for the
+        // loads it had just issued, every iteration paid a full memory latency and the "prefetch" was none (4.97 TB/s;
+        // with this wait and the one in front of the loop 5.28).  Two pairs ahead (three register sets taking turns, a
+        // loop unrolled by three, vmcnt(3)) was tried: 102 VGPRs, half the occupancy, and the compiler's own vmcnt(0)
+        // back at two of the three joins.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
         if (n0 | n1) {
             // one ply changes only the mover's plane: when neither board of the pair changed plane 0 (or plane 1),
             // that 16-byte store is skipped -- in lock-step play both boards have the same side to move

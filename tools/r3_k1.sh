@@ -1,7 +1,8 @@
 #!/bin/bash
-# K1s (per-ply kernel, HBM-bound, 2^24 boards): does the power-of-two distance between the two planes matter?
-for extra in 0 64 1024 4096 65536 1000000; do
-  N_EXTRA=$extra python tools/k1_steps.py | python -c "
+# K1s (per-ply kernel, HBM-bound): time per ply at 2^24 and 2^20 boards
+for lg in 24 24 22 20; do
+  LOG2N=$lg python tools/k1_steps.py | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('2^24 + $extra boards: 1 ply %.1f us %.0f GB/s   4 plies %.1f us' % (d['1_ply_launch']['s_per_launch']*1e6, d['1_ply_launch']['GBps'], d['4_ply_launch']['s_per_launch']*1e6))"
+d=json.loads(sys.stdin.read()); print('2^$lg boards: 1 ply %.1f us %.0f GB/s   4 plies %.1f us' % (d['1_ply_launch']['s_per_launch']*1e6, d['1_ply_launch']['GBps'], d['4_ply_launch']['s_per_launch']*1e6))"
 done
+timeout -k 10 300 python -m pytest tests -x -q -m gpu -k "step_random or lockstep or lock_step or connect_parity or test_connect" 2>&1 | tail -2

@@ -1,6 +1,6 @@
 /* A plain C99 host of libbgs.so: what a non-Python embedder of the C ABI (include/bgs.h) writes.  Plays one batch of
  * Connect4(6,7,4) games to the end, receives the rewards in page-locked host memory through the asynchronous hand-over,
- * and prints counts the Python test compares with the CPU oracle.  Built and run by tests/test_gpu_c_abi.py. */
+ * runs the native rollout loop over two batches, and prints counts the Python test compares with the CPU oracle.  Built and run by tests/test_gpu_c_abi.py. */
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -45,6 +45,42 @@ int main(int argc, char** argv) {
         else if (r[2 * i] == 0 && r[2 * i + 1] == 0) ++draws;
         else ++mismatches;
         if (r[2 * i] != by_sink[2 * i] || r[2 * i + 1] != by_sink[2 * i + 1]) ++mismatches;
+    }
+    /* 3: the native rollout loop (bgs_pipeline_*): two batches on streams of their own, five steps with seeds seed - 4 ..
+     * seed, every step's rewards handed over; the last host array must hold the rewards of `seed` again */
+    {
+        bgs_batch* two[2] = {NULL, NULL};
+        void* streams[2] = {NULL, NULL};
+        bgs_reward_sink* loop_sink = NULL;
+        bgs_pipeline* loop = NULL;
+        int8_t* hosts[3];
+        int64_t enqueued = 0, handed = 0;
+        float start_ms[8], end_ms[8];
+        int pairs = 0;
+        for (int k = 0; k < 3; ++k) hosts[k] = (int8_t*)malloc((size_t)n * 2);
+        for (int k = 0; k < 2; ++k) {
+            CHECK(bgs_stream_create(0, &streams[k]));
+            CHECK(bgs_connect_create(6, 7, 4, n, 0, NULL, 0, &two[k]));
+            CHECK(bgs_set_stream(two[k], streams[k]));
+            CHECK(bgs_set_first_game(two[k], 1000));
+            CHECK(bgs_set_launches_in_flight(two[k], 2));
+        }
+        CHECK(bgs_sink_create(0, n, 3, 2, &loop_sink));
+        CHECK(bgs_pipeline_create(two, 2, loop_sink, NULL, hosts, 3, seed - 4, 0x7FFFFFFF, BGS_ROLLOUT_FROM_INITIAL, &loop));
+        CHECK(bgs_pipeline_enqueue(loop, 5, 1, 1));
+        CHECK(bgs_pipeline_drain(loop));
+        CHECK(bgs_pipeline_progress(loop, &enqueued, &handed));
+        CHECK(bgs_pipeline_timeline(loop, start_ms, end_ms, 8, &pairs));
+        if (enqueued != 5 || handed != 5 || pairs != 5 || !(end_ms[4] > start_ms[4])) ++mismatches;
+        for (int64_t i = 0; i < 2 * n; ++i)
+            if (hosts[4 % 3][i] != by_sink[i]) { ++mismatches; break; }
+        CHECK(bgs_pipeline_destroy(loop));
+        CHECK(bgs_sink_destroy(loop_sink));
+        for (int k = 0; k < 2; ++k) {
+            CHECK(bgs_destroy(two[k]));
+            CHECK(bgs_stream_destroy(0, streams[k]));
+        }
+        for (int k = 0; k < 3; ++k) free(hosts[k]);
     }
     printf("C_ABI n=%lld steps=%llu wins0=%lld wins1=%lld draws=%lld mismatches=%lld build=%s version=%d\n", (long long)n,
            (unsigned long long)steps, (long long)wins0, (long long)wins1, (long long)draws, (long long)mismatches,

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <new>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -62,7 +63,12 @@ struct StreamSyncer {
         cv.notify_one();
     }
     bool wait() {   // true: the stream is idle; false: the synchronise failed
-        while (!done.load(std::memory_order_acquire)) _mm_pause();
+        // (a few hundred microseconds of watching the flag -- the end of a run -- then the core is given back: a stream
+        // that still holds milliseconds of kernels is waited for by its helper, inside the runtime)
+        for (int spins = 0; !done.load(std::memory_order_acquire); ++spins) {
+            if (spins < 20000) _mm_pause();
+            else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
         return err.exchange(0) == 0;
     }
 };

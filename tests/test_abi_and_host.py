@@ -198,3 +198,46 @@ def test_engine_cache_evicts_least_recently_used_per_thread():
     t = threading.Thread(target=lambda: seen.append(cache.get(0, lambda: Fake("other thread")).key))
     t.start(); t.join()
     assert seen == ["other thread"]
+
+
+def test_progress_barrier_between_threads():
+    """bgs_progress_barrier on words in this process's memory: four threads, ten barriers, some arriving late (spinning
+    and sleeping waiters), nobody through before the last arrival; bad arguments and a missing participant are reported."""
+    import ctypes
+    import threading
+    import time
+
+    import numpy as np
+
+    from simulator.game import _abi
+
+    lib = _abi.lib()
+    parties, rounds = 4, 10
+    words = np.zeros((parties, 8), dtype=np.int64)
+    base = words.ctypes.data
+    arrived = np.zeros((rounds, parties))
+    passed = np.zeros((rounds, parties))
+    errors = []
+
+    def party(me):
+        for epoch in range(1, rounds + 1):
+            time.sleep(0.002 * ((me + epoch) % parties))
+            arrived[epoch - 1, me] = time.monotonic()
+            rc = lib.bgs_progress_barrier(ctypes.c_void_p(base), parties, 8, me, epoch, 100 if epoch % 2 else 0, 5000)
+            passed[epoch - 1, me] = time.monotonic()
+            if rc != 0:
+                errors.append((me, epoch, rc))
+
+    threads = [threading.Thread(target=party, args=(k,)) for k in range(parties)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    assert (passed.min(axis=1) >= arrived.max(axis=1) - 1e-4).all()
+    assert (words[:, 0] == rounds).all()
+    # a participant that never comes: timeout; nonsense arguments: BGS_ERR_ARG
+    assert lib.bgs_progress_barrier(ctypes.c_void_p(base), parties, 8, 0, rounds + 1, 50, 100) != 0
+    assert "timed out" in _abi.last_error()
+    assert lib.bgs_progress_barrier(ctypes.c_void_p(base), parties, 8, parties, 1, 0, 100) == _abi.BGS_ERR_ARG
+    assert lib.bgs_progress_barrier(None, 1, 8, 0, 1, 0, 100) == _abi.BGS_ERR_ARG

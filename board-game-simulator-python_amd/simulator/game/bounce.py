@@ -176,20 +176,21 @@ class State(ValueObject):
 
     @property
     def actions(self) -> List["Action"]:
-        return [Action(self, s, t) for s, t in self._moves]
+        of = Action._of
+        return [of(self, s, t) for s, t in self._moves]
 
     def actions_at(self, source) -> List["Action"]:
         src = _as_cell(source, "source")
         h, w = self._grid.shape
         if not (0 <= src[0] < w and 0 <= src[1] < h):
             raise RuntimeError(f"source {src} is outside the board")
-        return [Action(self, s, t) for s, t in self._moves if s == src]
+        return [Action._of(self, s, t) for s, t in self._moves if s == src]
 
     def action_at(self, source, target) -> "Action":
         src, dst = _as_cell(source, "source"), _as_cell(target, "target")
         if (src, dst) not in self._moves:
             raise RuntimeError(f"illegal action: {src} -> {dst}")
-        return Action(self, src, dst)
+        return Action._of(self, src, dst)
 
     def to_json(self) -> Dict[str, Any]:
         return {"grid": self._grid.tolist(), "player": self._player, "winner": self._winner}
@@ -213,6 +214,17 @@ class Action(ValueObject):
         object.__setattr__(self, "state", state)
         object.__setattr__(self, "_source", (int(source[0]), int(source[1])))
         object.__setattr__(self, "_target", (int(target[0]), int(target[1])))
+
+    @classmethod
+    def _of(cls, state: State, source: Cell, target: Cell) -> "Action":
+        """An Action of one of the state's own decoded moves (tuples of ints already): `state.actions` builds a dozen
+        of these per ply, a third of the Python side of a transition."""
+        a = object.__new__(cls)
+        put = object.__setattr__
+        put(a, "state", state)
+        put(a, "_source", source)
+        put(a, "_target", target)
+        return a
 
     def __setattr__(self, name, value):
         raise AttributeError("Action is immutable")

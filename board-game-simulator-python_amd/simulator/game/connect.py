@@ -163,7 +163,8 @@ class State(ValueObject):
 
     @property
     def actions(self) -> List["Action"]:
-        return [Action(self, c) for c in self._legal]
+        of = Action._of
+        return [of(self, c) for c in self._legal]
 
     def action_at(self, column: int) -> "Action":
         if isinstance(column, bool) or not isinstance(column, (int, np.integer)):
@@ -193,6 +194,14 @@ class Action(ValueObject):
     def __init__(self, state: State, column: int):
         object.__setattr__(self, "state", state)
         object.__setattr__(self, "column", int(column))
+
+    @classmethod
+    def _of(cls, state: State, column: int) -> "Action":
+        """An Action of one of the state's own legal columns (ints already)."""
+        a = object.__new__(cls)
+        object.__setattr__(a, "state", state)
+        object.__setattr__(a, "column", column)
+        return a
 
     def __setattr__(self, name, value):
         raise AttributeError("Action is immutable")

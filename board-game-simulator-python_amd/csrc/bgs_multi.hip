@@ -321,8 +321,9 @@ struct bgs_gather {
                                        reinterpret_cast<uint4*>(bgs::sink_slot_device(sink, st[i])), units);
                     if ((he = hipGetLastError()) != hipSuccess) ok = false;
                 }
-                // `sent`: this step's code buffer (rank 0: its gathered codes) may be written again
-                if (ok && (he = hipEventRecord(sent[slot], stream)) != hipSuccess) ok = false;
+                // `sent`: this step's code buffer (rank 0: its gathered codes) may be written again -- nobody waits for
+                // it on rank 0 when the codes go straight into the sink's slot
+                if (ok && !(rank == 0 && direct) && (he = hipEventRecord(sent[slot], stream)) != hipSuccess) ok = false;
                 if (rank != 0) continue;
                 if (ok && (he = hipEventRecord(bgs::sink_slot_event(sink, st[i]), stream)) != hipSuccess) ok = false;
                 bgs::sink_publish(sink, st[i], n * world, host[slot], ok);
@@ -431,7 +432,10 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
         if (g->failed) return fail(BGS_ERR_RUNTIME, "the reward gather failed earlier: %s", g->error.c_str());
     }
     const int slot = (int)(t % g->slots);
-    if (t >= g->slots) HIP_TRY(hipStreamWaitEvent(b->stream, g->sent[slot], 0));
+    // (rank 0 receiving straight into the sink's slot needs no such wait: the slot is the sink's, and claiming it below
+    // blocks until its previous job has been expanded; a barrier packet per step on the batch's stream is not free)
+    const bool own_buffer = !(g->rank == 0 && g->direct);
+    if (own_buffer && t >= g->slots) HIP_TRY(hipStreamWaitEvent(b->stream, g->sent[slot], 0));
     // Rank 0 needs no transport for its own codes: its rollout kernel writes them straight to where the gathered codes of
     // games [0, n) belong -- the sink's device-mapped slot (or the device buffer the copy kernel reads).  The sink ticket
     // is claimed here, by the launching thread (claim blocks while the slot's previous job is still being expanded: the
@@ -453,12 +457,16 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
         return rc;
     }
     HIP_TRY(hipEventRecord(g->rolled[slot], b->stream));
+    bool wake;
     {
         std::lock_guard<std::mutex> lock(g->mu);
         g->host[slot] = host_reward;
         g->submitted = t + 1;
+        // the communication thread sleeps until a whole group is there (or somebody asks for a flush): waking it for
+        // every step only to have it go back to sleep costs both threads a futex round trip per step
+        wake = g->submitted >= g->enqueued + g->batch || g->flush_upto > g->enqueued;
     }
-    g->cv.notify_all();
+    if (wake) g->cv.notify_all();
     if (ticket) *ticket = t;
     return BGS_OK;
 }

@@ -77,7 +77,7 @@ BOUNCE_GRID = [[0] * 6, [1, 2, 3, 3, 2, 1]] + [[0] * 6] * 5 + [[1, 2, 3, 3, 2, 1
 OTHER_CONFIGS = {
     # name: (BASELINE.json config, boards, batches in flight, max plies, SURVEY 8d bytes per env-step, counters file, kernel)
     "connect_12x13x5": ("Connect4(12,13,5) large-board batch=262,144 on 1 MI355X", 1 << 18, 8, 2**31 - 1, 96, "k2c", "k_connect_rollout_lds"),
-    "bounce_default": ("Bounce default config batch=262,144 on 1 MI355X", 1 << 18, 16, 4096, 64, "bounce", "k_bounce_rollout"),
+    "bounce_default": ("Bounce default config batch=262,144 on 1 MI355X", 1 << 18, 20, 4096, 64, "bounce", "k_bounce_rollout"),
 }
 
 
@@ -269,7 +269,7 @@ def valu_issue_block(counters, why_not, seconds_per_launch, build):
 # ------------------------------------------------------------------------------------------------------------------
 def run_other_config(name: str, steps: int) -> int:
     label, n, depth, max_plies, bytes_per_step, stem, kernel = OTHER_CONFIGS[name]
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, 2 * depth)))  # HIP maps a process's streams onto 4 hardware queues by default
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(32, max(4, 2 * depth))))  # HIP maps a process's streams onto 4 hardware queues by default
     import numpy as np
     import torch
 

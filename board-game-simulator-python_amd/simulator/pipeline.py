@@ -124,9 +124,11 @@ def default_depth(batch_cls, config_args: tuple = ()) -> int:
     multi-word Connect board (12x13x5: the LDS-staged kernel, ONE wave per SIMD per launch, each issuing one VALU per
     ~9 cycles when alone) wants more waves per SIMD than three launches give: 8 in flight, 2.45 against 2.18 x 10^11
     env-steps/s (tools/r3_k2c_depth.sh; 12-16 with larger chunks reach 2.5-2.56).  A Bounce rollout is a 5-15 ms launch
-    whose tail is a handful of long games: 16 in flight on 32 hardware queues, 5x one launch at a time."""
+    whose tail is a handful of long games: 20 in flight on 32 hardware queues (16 / 20 / 24 / 28 / 32 in flight read
+    10.1 / 11.0 / 10.1 / 7.9 / 5.9 x 10^9 env-steps/s at 2^18 boards: beyond 24 the hardware queues thrash), 7x one launch
+    at a time."""
     if getattr(batch_cls, "game", 0) == _abi.GAME_BOUNCE:
-        return 16
+        return 20
     if len(config_args) >= 2 and int(config_args[1]) * (int(config_args[0]) + 1) > 64:
         return 8
     return 3
@@ -146,7 +148,7 @@ class RolloutPipeline:
     def __init__(self, batch_cls, config_args: tuple, n: int, depth: Optional[int] = None, host_threads: int = 6, device: int = 0,
                  first_game: int = 0, max_plies: int = 2**31 - 1, host_arrays=None, arrays_per_stream: int = 3):
         """`batch_cls(*config_args, n, device=..., use_torch=True)` is built `depth` times, each bound to its own stream
-        (default: `default_depth(batch_cls, config_args)` -- 3 for one-word Connect boards, 8 for larger ones, 16 for Bounce).
+        (default: `default_depth(batch_cls, config_args)` -- 3 for one-word Connect boards, 8 for larger ones, 20 for Bounce).
         `host_arrays`: optional list of arrays_per_stream * depth C-contiguous int8[n, 2] destinations (e.g. rows of a shared array,
         `SharedRewardRing.mine(slot)`); by default the pipeline allocates (and pre-faults) its own."""
         _abi.lib()  # (asks for more hardware queues while that is still possible: before torch touches the GPU)

@@ -333,7 +333,7 @@ def test_rollout_pipeline_refuses_a_depth_it_cannot_deliver():
         "assert os.environ['GPU_MAX_HW_QUEUES'] == '32' and not _abi.hw_queues_too_late\n"
         "g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]\n"
         "with RolloutPipeline(BounceBatch, (g,), 512, max_plies=200) as pipe:\n"
-        "    assert pipe.depth == 16 and len(list(pipe.run(range(20)))) == 20\n"
+        "    assert pipe.depth == 20 and len(list(pipe.run(range(24)))) == 24\n"
         "print('EARLY_OK')\n" % (ROOT, PKG))
     for code, word in ((code_late, "LATE_OK"), (code_early, "EARLY_OK")):
         proc = subprocess.run(["timeout", "-k", "10", "300", sys.executable, "-c", code], capture_output=True, text=True)

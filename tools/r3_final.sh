@@ -17,7 +17,7 @@ env $D MASTER_PORT=$((29500 + RANDOM % 400)) BGS_GATHER_BATCH=6 BGS_BENCH_SLOT_F
 BGS_DIST_BACKEND=gloo python bench.py --gpus 3 --steps 40 --batch 262144 > gpurun_out/r03_selfstart_gloo3.json 2> gpurun_out/r03_selfstart_gloo3.err
 BGS_DIST_BACKEND=gloo python bench.py --gpus 6 --steps 40 --batch 131072 --host-threads 2 > gpurun_out/r03_selfstart_gloo6.json 2> gpurun_out/r03_selfstart_gloo6.err
 python tools/object_latency.py > gpurun_out/r03_object_latency.json 2>/dev/null
-( echo "["; python tools/rollout_rate.py connect6x7 --depth 3 --reps 90 2>/dev/null; echo ","; python tools/rollout_rate.py connect12x13 --depth 8 --reps 160 2>/dev/null; echo ","; python tools/rollout_rate.py bounce --depth 16 --reps 64 2>/dev/null; echo ","; BGS_BOUNCE_PIECES=0 BGS_BOUNCE_PLAN=single python tools/rollout_rate.py bounce --depth 16 --reps 64 2>/dev/null; echo "]" ) > gpurun_out/r03_rollout_rates.json
+( echo "["; python tools/rollout_rate.py connect6x7 --depth 3 --reps 90 2>/dev/null; echo ","; python tools/rollout_rate.py connect12x13 --depth 8 --reps 160 2>/dev/null; echo ","; python tools/rollout_rate.py bounce --depth 20 --reps 160 2>/dev/null; echo ","; BGS_BOUNCE_PIECES=0 BGS_BOUNCE_PLAN=single python tools/rollout_rate.py bounce --depth 20 --reps 160 2>/dev/null; echo "]" ) > gpurun_out/r03_rollout_rates.json
 python - <<'PY'
 import json
 for f in ("r03_bench","r03_bench_steps20","r03_dist_shm","r03_dist_rccl","r03_dist_rccl_batch6","r03_selfstart_gloo3","r03_selfstart_gloo6"):

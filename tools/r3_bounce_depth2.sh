@@ -1,16 +1,10 @@
 #!/bin/bash
+# Bounce at 20 launches in flight: bulk cap x waves per launch around the shape bounce_shape() picks
 mkdir -p gpurun_out
-out=gpurun_out/bounce_depth2.txt; : > $out
-for depth in 16 24; do
- for cfg in "auto 0" "96:1,4096:8 512" "128:1,4096:8 512" "160:1,4096:8 512" "192:1,4096:8 512" "256:1,4096:8 512" "192:1,4096:8 768" "192:1,4096:8 384" "128:1,4096:8 384" "auto 0"; do
+for cfg in "160:1,4096:8 512" "160:1,4096:8 448" "160:1,4096:8 384" "160:1,4096:8 320" "160:1,4096:8 256" "128:1,4096:8 384" "192:1,4096:8 384" "160:1,4096:8 384" "160:1,4096:8 512"; do
   set -- $cfg
-  BGS_BOUNCE_PLAN=$1 timeout -k 10 120 python tools/rollout_rate.py bounce --depth $depth --reps 96 --bounce-waves $2 > gpurun_out/_solo.json 2>/dev/null || { echo "$cfg failed" >> $out; continue; }
-  python - "$1" "$2" "$depth" >> $out <<'PY'
-import json, sys
-d = json.load(open("gpurun_out/_solo.json"))
-k = [k for k in d if k.endswith("_in_flight")][0]
-print(f"depth {sys.argv[3]:3s} plan {sys.argv[1]:18s} waves {sys.argv[2]:5s} solo {d['one_launch_at_a_time']['env_steps_per_s']/1e9:5.2f}  {k} {d[k]['env_steps_per_s']/1e9:5.2f} G/s")
-PY
-  tail -1 $out
- done
+  BGS_BOUNCE_PLAN=$1 timeout -k 10 120 python tools/rollout_rate.py bounce --depth 20 --reps 160 --bounce-waves $2 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); k=[k for k in d if k.endswith('_in_flight')][0]
+print('plan $1 waves $2: %s %.2f G/s' % (k, d[k]['env_steps_per_s']/1e9))"
 done

@@ -10,15 +10,17 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <unordered_map>
 
 #include "bgs_capi_util.h"
 #include "bgs_common.h"
 #include "bgs_internal.h"
 
-#ifndef BGS_BUILD_ID
-#define BGS_BUILD_ID "unknown"
-#endif
+// every kernel translation unit carries the hash of its own source, headers and compile flags (csrc/Makefile: -DBGS_TU_ID)
+extern "C" const char bgs_tu_id_connect[];
+extern "C" const char bgs_tu_id_bounce[];
+extern "C" const char bgs_tu_id_generic[];
 
 namespace {
 thread_local char g_error[512] = "";
@@ -561,7 +563,35 @@ extern "C" {
 
 int bgs_version(void) { return 200; }
 
-const char* bgs_build_id(void) { return BGS_BUILD_ID; }
+// The identity of the kernels this library was LINKED with: the three units' own ids folded into 16 hex digits (the same
+// fold as `make print-id`: h = id_0; h = h * 0x100000001b3 ^ id_k, 64-bit wrap-around).  "unknown..." when a unit was
+// compiled outside the Makefile.
+const char* bgs_build_id(void) {
+    static const std::string id = [] {
+        uint64_t h = 0;
+        bool first = true;
+        for (const char* tu : {bgs_tu_id_connect, bgs_tu_id_bounce, bgs_tu_id_generic}) {
+            char* end = nullptr;
+            const uint64_t v = strtoull(tu, &end, 16);
+            if (end == tu || *end != 0) return std::string("unknown");
+            h = first ? v : (h * 0x100000001b3ull) ^ v;
+            first = false;
+        }
+        char text[17];
+        snprintf(text, sizeof text, "%016llx", (unsigned long long)h);
+        return std::string(text);
+    }();
+    return id.c_str();
+}
+
+const char* bgs_kernel_unit_id(int unit) {
+    switch (unit) {
+        case 0: return bgs_tu_id_connect;
+        case 1: return bgs_tu_id_bounce;
+        case 2: return bgs_tu_id_generic;
+        default: return nullptr;
+    }
+}
 
 const char* bgs_last_error(void) { return g_error; }
 

@@ -14,6 +14,12 @@
 #include "bgs_common.h"
 #include "bgs_internal.h"
 
+// identity of this translation unit as compiled: hash of this file, the kernel headers and the compile flags (csrc/Makefile)
+#ifndef BGS_TU_ID
+#define BGS_TU_ID "unknown"
+#endif
+extern "C" const char bgs_tu_id_generic[] = BGS_TU_ID;
+
 namespace bgs {
 namespace {
 

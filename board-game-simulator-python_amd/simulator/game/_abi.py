@@ -39,6 +39,7 @@ SIGNATURES = {
     "bgs_last_error": (ctypes.c_char_p, []),
     "bgs_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "bgs_build_id": (ctypes.c_char_p, []),
+    "bgs_kernel_unit_id": (ctypes.c_char_p, [ctypes.c_int]),
     "bgs_connect_arena_bytes": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_size_t)]),
     "bgs_connect_create": (
         ctypes.c_int,

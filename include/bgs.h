@@ -62,9 +62,13 @@ typedef enum bgs_buffer_id {
 int bgs_version(void);
 const char* bgs_last_error(void);
 int bgs_device_count(int* count);
-/* hash of the kernel sources this library was built from (16 hex digits): measurement files under profiles/ carry the
- * id of the build they were taken on, and bench.py refuses to quote instruction counts of another build */
+/* identity of the kernels this library was LINKED with (16 hex digits): every kernel translation unit embeds the hash of
+ * its own source, the kernel headers and the compile flags when it is compiled, and this folds the three.  Measurement
+ * files under profiles/ carry the id of the build they were taken on, and bench.py refuses to quote instruction counts
+ * of another build.  `make -C csrc print-id` gives the id the sources in the tree would produce. */
 const char* bgs_build_id(void);
+/* the id one kernel unit was compiled with: 0 connect_kernels, 1 bounce_kernels, 2 generic_kernels; NULL otherwise */
+const char* bgs_kernel_unit_id(int unit);
 
 /* ---- configuration + batch lifetime ------------------------------------------------------------- */
 /* replaces connect::Config(height, width, count) + Config::sample_initial_state (connect.cpp:26,32), N at a time.

@@ -303,6 +303,9 @@ struct bgs_reward_sink {
     struct Job {
         int64_t n_games = 0;
         int8_t* host_reward = nullptr;  // (a grid sink: int8[n][H][W])
+        int event_slot = 0;             // the slot whose `landed` event says this job's bytes have arrived: its own, or
+                                        // the LAST slot of a group of jobs that were delivered behind one event (the
+                                        // in-library gather: one record per group of steps, bgs_multi.hip)
     };
     std::vector<Job> jobs;            // [slots]
     std::mutex mu;
@@ -315,8 +318,12 @@ struct bgs_reward_sink {
     int64_t landed_upto = 0;             // the codes of jobs [0, landed_upto) are in their slots
     int64_t completed = 0;               // jobs [0, completed) are in their host arrays
     std::vector<int> parts_done;         // [slots] workers that finished their share of the slot's job
+    std::vector<char> slot_ok;           // [slots] the slot's current job arrived intact (worker 0 -> the expanders)
     bool stop = false;
-    bool failed = false;
+    // Failures belong to TICKETS, not to the sink: a hand-over that could not be enqueued (or whose event failed) is
+    // reported once, to the first bgs_sink_wait for that ticket or a later one, and the deliveries after it are as good
+    // as any (round-3 advisor: a sticky flag made one argument error poison every later wait).  Under mu.
+    std::vector<int64_t> failed_tickets;
     bool poll = false;                   // worker 0 polls the slot's event instead of sleeping on it (BGS_SINK_POLL=1)
     std::vector<std::thread> workers;
     // Lock-free mirrors of the three counters: a waiter may spin on them for up to spin_us microseconds before it
@@ -369,15 +376,16 @@ struct bgs_reward_sink {
                     // busy-poll: the wake-up out of hipEventSynchronize costs tens of microseconds, which matters at
                     // the end of a short run (the last delivery is not overlapped with anything)
                     hipError_t e;
-                    while ((e = hipEventQuery(landed[slot])) == hipErrorNotReady) _mm_pause();
+                    while ((e = hipEventQuery(landed[job.event_slot])) == hipErrorNotReady) _mm_pause();
                     ok = e == hipSuccess;
                 } else {
-                    ok = hipEventSynchronize(landed[slot]) == hipSuccess;
+                    ok = hipEventSynchronize(landed[job.event_slot]) == hipSuccess;
                 }
                 if (sink_trace_on()) fprintf(stderr, "sink-trace ticket %lld landed %.1f\n", (long long)ticket, mono_us());
                 {
                     std::lock_guard<std::mutex> lock(mu);
-                    if (!ok) failed = true;
+                    if (!ok && job.n_games != 0) failed_tickets.push_back(ticket);  // (n_games == 0: recorded by publish)
+                    slot_ok[slot] = ok;
                     landed_upto = ticket + 1;
                     a_landed.store(ticket + 1, std::memory_order_release);
                 }
@@ -398,7 +406,7 @@ struct bgs_reward_sink {
                 cv_landed.wait(lock, [&] { return stop || landed_upto > ticket; });
                 if (landed_upto <= ticket) return;  // stop, nothing left
                 job = jobs[slot];  // published before its event could complete, and not reused before this job is done
-                ok = !failed;
+                ok = slot_ok[slot];
             }
             // With more than one thread, worker 0 only waits and releases: while the others expand job k it is already
             // in the runtime waiting for job k + 1, so the event latency of a job overlaps the expansion of the one
@@ -452,13 +460,14 @@ int64_t claim(bgs_reward_sink* s) {
 
 // `ok` false: the enqueue for this ticket failed; the job is published all the same (the ring must not stall) with
 // nothing to expand, and the sink remembers the failure
-void publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok = true) {
+void publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok = true, int64_t event_ticket = -1) {
     {
         std::unique_lock<std::mutex> lock(s->mu);
         s->cv_done.wait(lock, [&] { return s->submitted == ticket; });  // (tickets of other threads publish first)
         s->jobs[ticket % s->slots].n_games = ok ? n_games : 0;
         s->jobs[ticket % s->slots].host_reward = host_reward;
-        if (!ok) s->failed = true;
+        s->jobs[ticket % s->slots].event_slot = (int)((event_ticket >= 0 ? event_ticket : ticket) % s->slots);
+        if (!ok) s->failed_tickets.push_back(ticket);
         s->submitted = ticket + 1;
         s->a_submitted.store(ticket + 1, std::memory_order_release);
     }
@@ -474,8 +483,8 @@ int64_t sink_claim(bgs_reward_sink* s) { return claim(s); }
 uint8_t* sink_slot_device(bgs_reward_sink* s, int64_t ticket) { return s->mapped[ticket % s->slots]; }
 uint8_t* sink_slot_host(bgs_reward_sink* s, int64_t ticket) { return s->pinned[ticket % s->slots]; }
 hipEvent_t sink_slot_event(bgs_reward_sink* s, int64_t ticket) { return s->landed[ticket % s->slots]; }
-void sink_publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok) {
-    publish(s, ticket, n_games, host_reward, ok);
+void sink_publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok, int64_t event_ticket) {
+    publish(s, ticket, n_games, host_reward, ok, event_ticket);
 }
 // urgent: the caller is at the END of a run (bgs_pipeline_drain): worker 0 polls the arrival events from here on and
 // the caller spins a little before it sleeps -- the last deliveries are a few tens of microseconds away and overlap
@@ -499,7 +508,23 @@ int sink_wait(bgs_reward_sink* s, int64_t ticket, bool urgent) {
         }
         if (urgent) s->urgent.fetch_sub(1, std::memory_order_relaxed);
     }
-    if (s->failed) return fail(BGS_ERR_RUNTIME, "a reward hand-over failed (enqueue or hipEventSynchronize)");
+    // a failure is reported once, to the first waiter for that ticket or a later one
+    int64_t bad = -1;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        auto& f = s->failed_tickets;
+        for (size_t i = 0; i < f.size();) {
+            if (f[i] <= ticket) {
+                if (bad < 0 || f[i] < bad) bad = f[i];
+                f.erase(f.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
+    }
+    if (bad >= 0)
+        return fail(BGS_ERR_RUNTIME, "reward hand-over %lld failed (its enqueue or its arrival event); later deliveries are unaffected",
+                    (long long)bad);
     return BGS_OK;
 }
 }  // namespace bgs
@@ -647,6 +672,7 @@ static int make_sink(int device, int64_t max_games, int slots, int threads, size
         if (v >= 0 && v <= 1000000) s->spin_us = v;
     }
     s->parts_done.assign(slots, 0);
+    s->slot_ok.assign(slots, 1);
     const size_t bytes = slot_bytes;
     hipError_t err = hipSuccess;
     // The page-locked slots are written by the GPU and read by the workers, which sit on the GPU's NUMA node: allocate
@@ -889,6 +915,13 @@ int bgs_sink_rollout(bgs_reward_sink* s, bgs_batch* b, uint64_t seed, int32_t ma
     NEED(b->n <= s->max_games, "batch of %lld games exceeds the sink's %lld", (long long)b->n, (long long)s->max_games);
     if (s->grids) {
         int rc0 = grid_sink_matches(s, b);
+        if (rc0) return rc0;
+    }
+    // what bgs_rollout would refuse is refused HERE, before a ticket exists: an argument error is the caller's, not a
+    // failed delivery
+    NEED(max_plies >= 0, "max_plies must be >= 0");
+    {
+        int rc0 = enter_device(s->device);
         if (rc0) return rc0;
     }
     const int64_t t = claim(s);

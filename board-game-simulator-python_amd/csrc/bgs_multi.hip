@@ -49,16 +49,30 @@ struct Rccl {
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
-    std::string why;  // when !ok
+    std::string why;   // when !ok
+    std::string name;  // what was loaded
 };
 
 const Rccl& rccl() {
     static const Rccl api = [] {
         Rccl r;
         void* h = nullptr;
+        // BGS_RCCL_LIB=<path>: another library with the same nine entry points -- tests/c/fake_rccl.hip, a test-only
+        // transport over shared memory that lets several processes SHARING ONE GPU run the world > 1 code below (RCCL
+        // itself refuses two ranks on one device)
+        if (const char* path = getenv("BGS_RCCL_LIB")) {
+            h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+            if (!h) {
+                const char* e = dlerror();
+                r.why = std::string("BGS_RCCL_LIB: ") + (e ? e : path);
+                return r;
+            }
+            r.name = path;
+        }
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (h) break;
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) r.name = name;
         }
         if (!h) {
             const char* e = dlerror();  // (one call: a second one returns NULL)
@@ -80,13 +94,6 @@ const Rccl& rccl() {
         return r;
     }();
     return api;
-}
-
-// gathered codes (device) -> the sink's page-locked slot as the GPU sees it: 16-byte stores over PCIe, no copy engine
-// and no copy call (a hipMemcpyAsync device -> host per step costs the communication stream ~10x this kernel)
-__global__ void __launch_bounds__(256) k_codes_to_slot(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t units) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < units) dst[i] = src[i];
 }
 
 #define NCCL_TRY(expr)                                                                                   \
@@ -232,34 +239,77 @@ extern "C" int bgs_multi_connect_rollout(const int* devices, int n_devices, int 
 
 // ------------------------------------------------------------------------------------------------
 // bgs_gather: one process per GPU, persistent communicator, communication thread
+//
 // Rank 0's own codes are not transported: its rollout kernel writes them where they belong among the gathered codes.
 // (Round 3 first sent them to itself like everybody else's: RCCL turns a self send / receive into ~25 small fill / copy
-// dispatches per group on the communication stream, and a one-rank world read 0.6-0.93 of the shared-memory loop
-// depending on the box.)
+// dispatches per group on the communication stream.)
+//
+// What a step costs (round 4: the machinery is per GROUP of steps, not per step):
+//   launching thread  the rollout, ONE event record behind it (as the plain sink's hand-over), a mutex;
+//   comm thread       per group of `batch` steps: one hipStreamWaitEvent per distinct launch stream of the group (the last
+//                     rollout on each), one group of point-to-point calls, rank 0 without direct receives: ONE copy kernel
+//                     for the whole group, ONE event record -- rank 0's sink is told that the group's jobs have arrived when
+//                     the LAST job's slot event fires (sink_publish with an event ticket);
+//   a one-rank world  has nothing to gather: no communication thread, no communication stream, the communicator is
+//                     created (the library loads, the id is good) and destroyed again; a step is exactly the sink's
+//                     bgs_sink_rollout.
+// Groups are the same on every rank as long as every rank enqueues the same number of steps between two waits for the
+// newest ticket (what bgs_pipeline_* and bench.py do): a group closes when `batch` steps are there, and a partial group
+// only when somebody waits for one of its steps -- at the end of a region, with all of its steps submitted.
 // ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kMaxGroup = 32;   // steps per group of point-to-point calls (slots <= 64, default batch = slots / 2)
+
+struct CopyList {
+    const uint4* src[kMaxGroup];
+    uint4* dst[kMaxGroup];
+};
+
+// rank 0 without direct receives: the gathered codes of a whole group of steps (device) -> their sink slots as the GPU
+// sees them (device-mapped page-locked memory): 16-byte stores over PCIe, one launch per group
+__global__ void __launch_bounds__(256) k_codes_to_slots(CopyList list, size_t units) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < units) list.dst[blockIdx.y][i] = list.src[blockIdx.y][i];
+}
+
+inline uint8_t check_byte(int rank, size_t i) { return (uint8_t)(rank * 37 + (int)(i * 11 % 251) + 5); }
+
+}  // namespace
+
 struct bgs_gather {
     int device = 0, rank = 0, world = 1, slots = 0;
     int64_t n = 0;            // games per rank
     size_t code_bytes = 0;    // n / 4: what a rank contributes per step
-    bool direct = true;       // rank 0 receives straight into the sink's device-mapped slot; BGS_GATHER_DIRECT=0: into
-                              // device memory, and a copy kernel takes the gathered codes to the slot
+    // rank 0 receives straight into the sink's device-mapped slot (BGS_GATHER_DIRECT=1) or into device memory, from where a
+    // copy kernel takes the gathered codes of a group to their slots (the default with peers: until a run on real xGMI has
+    // been seen to deliver into device-mapped host memory, the conservative form is the default -- round-3 advisor)
+    bool direct = false;
+    int transport_check = 0;  // 0: none (one rank); 1: the create-time message arrived intact in the mode asked for;
+                              // 2: it did not arrive intact in direct mode, the gather fell back to the copy kernel
     int batch = 0;            // steps per group of point-to-point calls: slots / 2 (BGS_GATHER_BATCH overrides; the launching
                               // thread runs `slots` steps ahead, so half of them can wait for their group to fill)
     int64_t flush_upto = 0;   // somebody waits for a step below this: send partial groups
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;        // everything RCCL does for this rank is enqueued here
-    std::vector<uint8_t*> codes;         // [slots] device: the rollout kernel writes a step's codes here
-    std::vector<uint8_t*> gathered;      // [slots] device, rank 0: the codes of all ranks, in global game order
+    std::vector<uint8_t*> codes;         // [slots] device: the rollout kernel writes a step's codes here (ranks != 0)
+    std::vector<uint8_t*> gathered;      // [slots] device, rank 0 without direct receives: the codes of all ranks
     std::vector<hipEvent_t> rolled;      // [slots] on the batch's stream, behind the rollout
-    std::vector<hipEvent_t> sent;        // [slots] on the communication stream, behind the step's group
+    std::vector<hipEvent_t> sent;        // [slots] on the communication stream, behind a GROUP (recorded for its last step)
     std::vector<int8_t*> host;           // [slots] rank 0: destination of the step's rewards
+    std::vector<hipStream_t> step_stream;  // [slots] the stream the step's rollout was enqueued on
+    std::vector<char> step_ok;           // [slots] the rollout and its event were enqueued
+    std::vector<int64_t> cover_seq;      // [slots] sequence number of the group the slot's last step left in ...
+    std::vector<int> cover_ev;           // [slots] ... and the slot whose `sent` event was recorded behind that group
+    int64_t group_seq = 0;
+    std::vector<std::pair<hipStream_t, int64_t>> waited;  // launch stream -> newest group it has been told to wait for
     bgs_reward_sink* sink = nullptr;     // rank 0
     std::mutex mu;
     std::condition_variable cv;
     int64_t submitted = 0;               // steps handed to the communication thread
     int64_t enqueued = 0;                // steps whose send / receives are on the communication stream
     bool stop = false;
-    bool failed = false;
+    bool failed = false;                 // (under mu) the communicator is beyond repair: every later call reports `error`
     std::string error;
     std::thread worker;
 
@@ -268,15 +318,93 @@ struct bgs_gather {
         if (!failed) error = std::string(what) + ": " + detail;
         failed = true;
     }
+    bool has_failed() {
+        std::lock_guard<std::mutex> lock(mu);
+        return failed;
+    }
+    bool own_buffer() const { return !(rank == 0 && direct); }   // the step's codes live in a buffer of the gather's
 
-    // The communication thread.  Steps are gathered `batch` at a time (BGS_GATHER_BATCH, default 1): ONE group of
-    // point-to-point calls -- one RCCL kernel -- carries the codes of `batch` consecutive steps, at the price of
-    // delivering a step only when the last rollout of its group has finished.  A partial group goes out as soon as
-    // somebody waits for one of its steps (flush_upto).
+    // One group: steps [t, t + k) -- stream waits, point-to-point calls, rank 0's copy, one record, rank 0's publishes.
+    void run_group(int64_t t, int k, std::vector<int64_t>& st) {
+        const Rccl& api = rccl();
+        bool ok = !has_failed();
+        hipError_t he = hipSuccess;
+        int ne = 0;
+        for (int i = 0; i < k; ++i) {
+            st[i] = t + i;  // rank 0: the launching thread claimed the sink ticket of this step (same numbers)
+            if (!step_ok[(t + i) % slots]) ok = false;   // (its rollout could not be enqueued: nothing to wait for)
+        }
+        // the communication stream waits for the LAST rollout of the group on every launch stream it used
+        hipStream_t seen[kMaxGroup];
+        int n_seen = 0;
+        for (int i = k - 1; i >= 0 && ok; --i) {
+            const int slot = (int)((t + i) % slots);
+            bool dup = false;
+            for (int j = 0; j < n_seen; ++j) dup = dup || seen[j] == step_stream[slot];
+            if (dup) continue;
+            seen[n_seen++] = step_stream[slot];
+            if ((he = hipStreamWaitEvent(stream, rolled[slot], 0)) != hipSuccess) ok = false;
+        }
+        // The gather: one group of point-to-point calls, every OTHER rank -> rank 0.
+        if (ok) {
+            if ((ne = api.GroupStart()) == 0) {
+                for (int i = 0; i < k && ne == 0; ++i) {
+                    const int slot = (int)((t + i) % slots);
+                    if (rank != 0) {
+                        ne = api.Send(codes[slot], code_bytes, kNcclUint8, 0, comm, stream);
+                    } else {
+                        uint8_t* dst = direct ? bgs::sink_slot_device(sink, st[i]) : gathered[slot];
+                        for (int r = 1; r < world && ne == 0; ++r)
+                            ne = api.Recv(dst + (size_t)r * code_bytes, code_bytes, kNcclUint8, r, comm, stream);
+                    }
+                }
+                const int ge = api.GroupEnd();
+                if (ne == 0) ne = ge;
+            }
+            if (ne != 0) ok = false;
+        }
+        if (rank == 0 && ok && !direct) {
+            CopyList list;
+            for (int i = 0; i < k; ++i) {
+                list.src[i] = reinterpret_cast<const uint4*>(gathered[(t + i) % slots]);
+                list.dst[i] = reinterpret_cast<uint4*>(bgs::sink_slot_device(sink, st[i]));
+            }
+            const size_t units = (code_bytes * (size_t)world + 15) / 16;  // (both buffers are whole 16-byte units)
+            hipLaunchKernelGGL(k_codes_to_slots, dim3((unsigned)((units + 255) / 256), (unsigned)k), dim3(256), 0, stream, list, units);
+            if ((he = hipGetLastError()) != hipSuccess) ok = false;
+        }
+        const int last = (int)((t + k - 1) % slots);
+        // `sent`: the code buffers of the group (rank 0: its gathered codes) may be written again -- nobody waits for it
+        // on rank 0 when the codes go straight into the sink's slots
+        if (ok && own_buffer() && (he = hipEventRecord(sent[last], stream)) != hipSuccess) ok = false;
+        if (rank == 0) {
+            // ONE arrival event for the group -- the last job's -- and every job of the group points at it
+            if (ok && (he = hipEventRecord(bgs::sink_slot_event(sink, st[k - 1]), stream)) != hipSuccess) ok = false;
+            for (int i = 0; i < k; ++i)
+                bgs::sink_publish(sink, st[i], n * world, host[(t + i) % slots], ok && step_ok[(t + i) % slots], st[k - 1]);
+        }
+        if (!ok && !has_failed()) {
+            if (ne != 0) fail_with("RCCL", api.GetErrorString(ne));
+            else if (he != hipSuccess) fail_with("HIP", hipGetErrorString(he));
+            else fail_with("rollout", "a step of the group could not be enqueued");
+        }
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            ++group_seq;
+            for (int i = 0; i < k; ++i) {
+                cover_seq[(t + i) % slots] = group_seq;
+                cover_ev[(t + i) % slots] = last;
+            }
+            enqueued = t + k;
+        }
+        cv.notify_all();
+    }
+
+    // The communication thread (worlds of two ranks and more).  A group closes when `batch` steps are there; a partial
+    // group goes out as soon as somebody waits for one of its steps (flush_upto).
     void run() {
         (void)hipSetDevice(device);
-        const Rccl& api = rccl();
-        std::vector<int64_t> st((size_t)batch, -1);
+        std::vector<int64_t> st((size_t)kMaxGroup, -1);
         for (int64_t t = 0;;) {
             int k;
             {
@@ -285,60 +413,95 @@ struct bgs_gather {
                 if (submitted <= t) return;  // stop, nothing left
                 k = (int)std::min<int64_t>(batch, submitted - t);
             }
-            bool ok = !failed;
-            hipError_t he = hipSuccess;
-            int ne = 0;
-            for (int i = 0; i < k; ++i) {
-                const int slot = (int)((t + i) % slots);
-                st[i] = t + i;  // rank 0: the launching thread claimed the sink ticket of this step (same numbers)
-                if (ok && (he = hipStreamWaitEvent(stream, rolled[slot], 0)) != hipSuccess) ok = false;
-            }
-            // The gather: one group of point-to-point calls, every OTHER rank -> rank 0.  Rank 0's own codes need no
-            // transport: its rollout kernel wrote them where the gathered codes of its games belong (bgs_gather_rollout).
-            if (ok && world > 1) {
-                if ((ne = api.GroupStart()) == 0) {
-                    for (int i = 0; i < k && ne == 0; ++i) {
-                        const int slot = (int)((t + i) % slots);
-                        if (rank != 0) {
-                            ne = api.Send(codes[slot], code_bytes, kNcclUint8, 0, comm, stream);
-                        } else {
-                            uint8_t* dst = direct ? bgs::sink_slot_device(sink, st[i]) : gathered[slot];
-                            for (int r = 1; r < world && ne == 0; ++r)
-                                ne = api.Recv(dst + (size_t)r * code_bytes, code_bytes, kNcclUint8, r, comm, stream);
-                        }
-                    }
-                    const int ge = api.GroupEnd();
-                    if (ne == 0) ne = ge;
-                }
-                if (ne != 0) ok = false;
-            }
-            for (int i = 0; i < k; ++i) {
-                const int slot = (int)((t + i) % slots);
-                if (rank == 0 && ok && !direct) {
-                    const size_t units = (code_bytes * (size_t)world + 15) / 16;  // (both buffers are whole 16-byte units)
-                    hipLaunchKernelGGL(k_codes_to_slot, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream,
-                                       reinterpret_cast<const uint4*>(gathered[slot]),
-                                       reinterpret_cast<uint4*>(bgs::sink_slot_device(sink, st[i])), units);
-                    if ((he = hipGetLastError()) != hipSuccess) ok = false;
-                }
-                // `sent`: this step's code buffer (rank 0: its gathered codes) may be written again -- nobody waits for
-                // it on rank 0 when the codes go straight into the sink's slot
-                if (ok && !(rank == 0 && direct) && (he = hipEventRecord(sent[slot], stream)) != hipSuccess) ok = false;
-                if (rank != 0) continue;
-                if (ok && (he = hipEventRecord(bgs::sink_slot_event(sink, st[i]), stream)) != hipSuccess) ok = false;
-                bgs::sink_publish(sink, st[i], n * world, host[slot], ok);
-            }
-            if (!ok && !failed) {
-                if (ne != 0) fail_with("RCCL", api.GetErrorString(ne));
-                else fail_with("HIP", hipGetErrorString(he));
-            }
+            run_group(t, k, st);
             t += k;
-            {
-                std::lock_guard<std::mutex> lock(mu);
-                enqueued = t;
-            }
-            cv.notify_all();
         }
+    }
+
+    // Create-time check of the transport in the mode the gather will use (worlds of two ranks and more; collective):
+    // every other rank sends one step's worth of a known pattern, rank 0 receives it where a step's codes would go and
+    // compares what arrives in the sink's page-locked slot; rank 0 then tells everybody the verdict (one 16-byte message
+    // each).  A direct receive that does not deliver falls back to the copy kernel, once, and says so on stderr.
+    int check_transport() {
+        const Rccl& api = rccl();
+        int rc = BGS_OK;
+        uint8_t* verdict_dev = nullptr;
+        std::vector<uint8_t> pattern(code_bytes);
+        HIP_GO(hipMalloc(reinterpret_cast<void**>(&verdict_dev), 16));
+        for (int round = 0; round < 2; ++round) {
+            int verdict = 0;  // 0 fine, 1 again without direct receives, 2 give up
+            if (rank != 0) {
+                for (size_t i = 0; i < code_bytes; ++i) pattern[i] = check_byte(rank, i);
+                HIP_GO(hipMemcpyAsync(codes[0], pattern.data(), code_bytes, hipMemcpyHostToDevice, stream));
+                NCCL_TRY(api.GroupStart());
+                NCCL_TRY(api.Send(codes[0], code_bytes, kNcclUint8, 0, comm, stream));
+                NCCL_TRY(api.GroupEnd());
+                NCCL_TRY(api.GroupStart());
+                NCCL_TRY(api.Recv(verdict_dev, 16, kNcclUint8, 0, comm, stream));
+                NCCL_TRY(api.GroupEnd());
+                uint8_t got[16] = {0};
+                HIP_GO(hipMemcpyAsync(got, verdict_dev, 16, hipMemcpyDeviceToHost, stream));
+                HIP_GO(hipStreamSynchronize(stream));
+                verdict = got[0];
+            } else {
+                uint8_t* slot_host = bgs::sink_slot_host(sink, 0);
+                uint8_t* slot_dev = bgs::sink_slot_device(sink, 0);
+                const size_t all = code_bytes * (size_t)world;
+                memset(slot_host, 0, all);
+                if (!direct) HIP_GO(hipMemsetAsync(gathered[0], 0, (all + 15) / 16 * 16, stream));
+                uint8_t* dst = direct ? slot_dev : gathered[0];
+                NCCL_TRY(api.GroupStart());
+                for (int r = 1; r < world; ++r) NCCL_TRY(api.Recv(dst + (size_t)r * code_bytes, code_bytes, kNcclUint8, r, comm, stream));
+                NCCL_TRY(api.GroupEnd());
+                if (!direct) {
+                    CopyList list;
+                    list.src[0] = reinterpret_cast<const uint4*>(gathered[0]);
+                    list.dst[0] = reinterpret_cast<uint4*>(slot_dev);
+                    const size_t units = (all + 15) / 16;
+                    hipLaunchKernelGGL(k_codes_to_slots, dim3((unsigned)((units + 255) / 256), 1u), dim3(256), 0, stream, list, units);
+                    HIP_GO(hipGetLastError());
+                }
+                HIP_GO(hipStreamSynchronize(stream));
+                size_t wrong = 0;
+                for (int r = 1; r < world; ++r)
+                    for (size_t i = 0; i < code_bytes; ++i) wrong += slot_host[(size_t)r * code_bytes + i] != check_byte(r, i);
+                memset(slot_host, 0, all);
+                if (wrong == 0) {
+                    transport_check = round == 0 ? 1 : 2;
+                } else if (direct && round == 0) {
+                    verdict = 1;
+                    fprintf(stderr, "libbgs: RCCL gather: %zu of %zu bytes received straight into the device-mapped host slot differ "
+                                    "from what was sent; falling back to receives into device memory + a copy kernel\n",
+                            wrong, code_bytes * (size_t)(world - 1));
+                } else {
+                    verdict = 2;
+                }
+                uint8_t msg[16] = {(uint8_t)verdict};
+                HIP_GO(hipMemcpyAsync(verdict_dev, msg, 16, hipMemcpyHostToDevice, stream));
+                NCCL_TRY(api.GroupStart());
+                for (int r = 1; r < world; ++r) NCCL_TRY(api.Send(verdict_dev, 16, kNcclUint8, r, comm, stream));
+                NCCL_TRY(api.GroupEnd());
+                HIP_GO(hipStreamSynchronize(stream));
+                if (verdict == 2) rc = fail(BGS_ERR_RUNTIME, "RCCL gather: %zu bytes of the create-time message did not arrive intact", wrong);
+            }
+            if (verdict == 0) break;
+            if (verdict == 2) {
+                if (rc == BGS_OK) rc = fail(BGS_ERR_RUNTIME, "RCCL gather: rank 0 reports that the create-time message did not arrive intact");
+                break;
+            }
+            // again, without direct receives (rank 0 needs the device buffers it did not allocate)
+            direct = false;
+            if (rank == 0) {
+                while ((int)gathered.size() < slots) {
+                    void* p = nullptr;
+                    HIP_GO(hipMalloc(&p, (code_bytes * (size_t)world + 15) / 16 * 16));
+                    gathered.push_back(static_cast<uint8_t*>(p));
+                }
+            }
+        }
+    done:
+        if (verdict_dev) (void)hipFree(verdict_dev);
+        return rc;
     }
 };
 
@@ -371,27 +534,36 @@ int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_
     g->slots = slots;
     g->n = n_per_rank;
     g->code_bytes = (size_t)n_per_rank / 4;
-    if (const char* e = getenv("BGS_GATHER_DIRECT")) g->direct = atoi(e) != 0;
+    g->direct = world == 1;   // (a one-rank world: rank 0's own kernel writes the slot, nothing is received)
+    if (const char* e = getenv("BGS_GATHER_DIRECT")) g->direct = atoi(e) != 0 || world == 1;
     if (const char* e = getenv("BGS_GATHER_BATCH")) {
         const int v = atoi(e);
         if (v >= 1) g->batch = v;
     }
     if (g->batch <= 0) g->batch = slots / 2;
     if (g->batch > slots) g->batch = slots;
+    if (g->batch > kMaxGroup) g->batch = kMaxGroup;
     if (g->batch < 1) g->batch = 1;
     g->host.assign(slots, nullptr);
+    g->step_stream.assign(slots, nullptr);
+    g->step_ok.assign(slots, 0);
+    g->cover_seq.assign(slots, 0);
+    g->cover_ev.assign(slots, 0);
     int rc = BGS_OK;
-    hipError_t he = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    hipError_t he = hipSuccess;
     const size_t padded = (size_t)(n_per_rank + 63) / 64 * 16;  // the rollout kernels store whole 16-byte units
-    for (int k = 0; k < slots && he == hipSuccess; ++k) {
-        void* p = nullptr;
-        hipEvent_t e = nullptr;
-        if ((he = hipMalloc(&p, padded)) == hipSuccess) g->codes.push_back(static_cast<uint8_t*>(p));
-        if (he == hipSuccess && rank == 0 && !g->direct &&
-            (he = hipMalloc(&p, (g->code_bytes * (size_t)world + 15) / 16 * 16)) == hipSuccess)
-            g->gathered.push_back(static_cast<uint8_t*>(p));
-        if (he == hipSuccess && (he = hipEventCreateWithFlags(&e, hipEventDisableTiming)) == hipSuccess) g->rolled.push_back(e);
-        if (he == hipSuccess && (he = hipEventCreateWithFlags(&e, hipEventDisableTiming)) == hipSuccess) g->sent.push_back(e);
+    if (world > 1) {
+        he = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+        for (int k = 0; k < slots && he == hipSuccess; ++k) {
+            void* p = nullptr;
+            hipEvent_t e = nullptr;
+            if (rank != 0 && (he = hipMalloc(&p, padded)) == hipSuccess) g->codes.push_back(static_cast<uint8_t*>(p));
+            if (he == hipSuccess && rank == 0 && !g->direct &&
+                (he = hipMalloc(&p, (g->code_bytes * (size_t)world + 15) / 16 * 16)) == hipSuccess)
+                g->gathered.push_back(static_cast<uint8_t*>(p));
+            if (he == hipSuccess && (he = hipEventCreateWithFlags(&e, hipEventDisableTiming)) == hipSuccess) g->rolled.push_back(e);
+            if (he == hipSuccess && (he = hipEventCreateWithFlags(&e, hipEventDisableTiming)) == hipSuccess) g->sent.push_back(e);
+        }
     }
     if (he != hipSuccess) rc = fail(BGS_ERR_RUNTIME, "gather allocation failed: %s", hipGetErrorString(he));
     if (rc == BGS_OK && rank == 0) rc = bgs_sink_create(device, n_per_rank * world, slots, host_threads, &g->sink);
@@ -402,25 +574,52 @@ int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_
         const int r = rccl().CommInitRank(&g->comm, world, u, rank);
         if (r != 0) rc = fail(BGS_ERR_RUNTIME, "ncclCommInitRank failed: %s", rccl().GetErrorString(r));
     }
-    if (rc != BGS_OK) {
-        (void)bgs_gather_destroy(g);
-        return rc;
+    if (rc == BGS_OK && world == 1) {
+        // nothing will ever be sent: the library loaded and the id was good, which is all a one-rank world can show
+        (void)rccl().CommDestroy(g->comm);
+        g->comm = nullptr;
     }
-    g->worker = std::thread([g] { g->run(); });
+    if (rc == BGS_OK && world > 1) rc = g->check_transport();
+    if (rc != BGS_OK) {
+        // (bgs_gather_destroy must not overwrite the message of the failure)
+        const std::string why = bgs_last_error();
+        (void)bgs_gather_destroy(g);
+        return fail(rc, "%s", why.c_str());
+    }
+    if (world > 1) g->worker = std::thread([g] { g->run(); });
     *out = g;
+    return BGS_OK;
+}
+
+const char* bgs_gather_transport(void) { return rccl().ok ? rccl().name.c_str() : ""; }
+
+int bgs_gather_info(const bgs_gather* g, int* direct, int* batch, int* transport_check) {
+    NEED(g != nullptr, "gather is NULL");
+    if (direct) *direct = g->direct ? 1 : 0;
+    if (batch) *batch = g->world > 1 ? g->batch : 1;
+    if (transport_check) *transport_check = g->transport_check;
     return BGS_OK;
 }
 
 int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, int8_t* host_reward,
                        int64_t* ticket) {
+    // everything that can be refused is refused BEFORE a ticket exists (round-3 advisor: a claimed sink ticket that is
+    // never published stalls the sink, and with it bgs_gather_destroy)
     NEED(g != nullptr && b != nullptr, "NULL argument");
     NEED(b->device == g->device, "batch lives on device %d, the gather on device %d", b->device, g->device);
     NEED(b->n == g->n, "batch of %lld games, the gather was made for %lld per rank", (long long)b->n, (long long)g->n);
     NEED(g->rank != 0 || host_reward != nullptr, "rank 0 needs the host array int8[world * n][2]");
+    NEED(max_plies >= 0, "max_plies must be >= 0");
+    // fault injection for the tests (BGS_GATHER_INJECT_FAILURE=<step>): that step "cannot be enqueued" after its ticket
+    // was claimed -- the path a device error would take
+    static const long long inject = getenv("BGS_GATHER_INJECT_FAILURE") ? atoll(getenv("BGS_GATHER_INJECT_FAILURE")) : -1;
+    if (g->world == 1) return bgs_sink_rollout(g->sink, b, seed, max_plies, flags, host_reward, ticket);
     HIP_TRY(hipSetDevice(g->device));
     int64_t t;
+    int64_t wait_seq = 0;
+    int wait_ev = -1;
     {
-        // the codes buffer of this step was last used `slots` steps ago: its send must be on the communication stream
+        // the code buffer of this step was last used `slots` steps ago: its group must be on the communication stream
         // before the batch's stream can be told to wait for it
         std::unique_lock<std::mutex> lock(g->mu);
         t = g->submitted;
@@ -430,45 +629,68 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
         }
         g->cv.wait(lock, [&] { return g->enqueued > t - g->slots; });
         if (g->failed) return fail(BGS_ERR_RUNTIME, "the reward gather failed earlier: %s", g->error.c_str());
+        const int slot = (int)(t % g->slots);
+        if (g->own_buffer() && t >= g->slots) {
+            // one wait per launch stream and GROUP, not per step: a stream that has been told to wait for a group has
+            // waited for every earlier one (the communication stream runs them in order)
+            wait_seq = g->cover_seq[slot];
+            auto it = std::find_if(g->waited.begin(), g->waited.end(), [&](const std::pair<hipStream_t, int64_t>& w) { return w.first == b->stream; });
+            if (it == g->waited.end()) {
+                if (g->waited.size() >= 256) g->waited.clear();   // (streams come and go: forgetting one costs a redundant wait)
+                g->waited.emplace_back(b->stream, wait_seq);
+                wait_ev = g->cover_ev[slot];
+            } else if (it->second < wait_seq) {
+                it->second = wait_seq;
+                wait_ev = g->cover_ev[slot];
+            }
+        }
     }
     const int slot = (int)(t % g->slots);
     // (rank 0 receiving straight into the sink's slot needs no such wait: the slot is the sink's, and claiming it below
-    // blocks until its previous job has been expanded; a barrier packet per step on the batch's stream is not free)
-    const bool own_buffer = !(g->rank == 0 && g->direct);
-    if (own_buffer && t >= g->slots) HIP_TRY(hipStreamWaitEvent(b->stream, g->sent[slot], 0));
+    // blocks until its previous job has been expanded)
+    bool ok = true;
+    int rc = BGS_OK;
+    hipError_t he = hipSuccess;
+    if (wait_ev >= 0 && (he = hipStreamWaitEvent(b->stream, g->sent[wait_ev], 0)) != hipSuccess) ok = false;
     // Rank 0 needs no transport for its own codes: its rollout kernel writes them straight to where the gathered codes of
-    // games [0, n) belong -- the sink's device-mapped slot (or the device buffer the copy kernel reads).  The sink ticket
+    // games [0, n) belong -- the device buffer the copy kernel reads, or the sink's device-mapped slot.  The sink ticket
     // is claimed here, by the launching thread (claim blocks while the slot's previous job is still being expanded: the
-    // same back-pressure as before), and carries the gather's own ticket number.
-    uint8_t* codes_out = g->codes[slot];
+    // same back-pressure as the plain sink's), and carries the gather's own ticket number.
+    uint8_t* codes_out = g->rank != 0 ? g->codes[slot] : nullptr;
     if (g->rank == 0) {
         const int64_t st = bgs::sink_claim(g->sink);
-        NEED(st == t, "the gather's sink handed out ticket %lld for step %lld", (long long)st, (long long)t);
-        codes_out = g->direct ? bgs::sink_slot_device(g->sink, st) : g->gathered[slot];
-    }
-    int rc = bgs::rollout_with_codes(b, seed, max_plies, flags, codes_out);
-    if (rc) {
-        if (g->rank == 0) {  // the claimed ticket must not stall the sink; the gather itself is beyond repair
-            bgs::sink_publish(g->sink, t, 0, host_reward, false);
-            std::lock_guard<std::mutex> lock(g->mu);
-            g->failed = true;
-            g->error = "a rollout could not be enqueued";
+        if (st != t) {
+            // cannot happen while the gather owns its sink; if it does, the ticket is still published (by the
+            // communication thread, in order) and the gather reports it
+            ok = false;
+            rc = fail(BGS_ERR_RUNTIME, "the gather's sink handed out ticket %lld for step %lld", (long long)st, (long long)t);
         }
-        return rc;
+        codes_out = g->direct ? bgs::sink_slot_device(g->sink, t) : g->gathered[slot];
     }
-    HIP_TRY(hipEventRecord(g->rolled[slot], b->stream));
+    // From here on the step is submitted whatever happens -- a step that could not be enqueued travels through the
+    // communication thread with its flag down, so that rank 0's sink ticket is published in order and nothing stalls.
+    if (ok && t == inject) {
+        ok = false;
+        rc = fail(BGS_ERR_RUNTIME, "injected failure at step %lld (BGS_GATHER_INJECT_FAILURE)", (long long)t);
+    }
+    if (ok && (rc = bgs::rollout_with_codes(b, seed, max_plies, flags, codes_out)) != BGS_OK) ok = false;
+    if (ok && (he = hipEventRecord(g->rolled[slot], b->stream)) != hipSuccess) ok = false;
+    if (!ok && rc == BGS_OK) rc = fail(BGS_ERR_RUNTIME, "the step could not be enqueued: %s", hipGetErrorString(he));
     bool wake;
     {
         std::lock_guard<std::mutex> lock(g->mu);
         g->host[slot] = host_reward;
+        g->step_stream[slot] = b->stream;
+        g->step_ok[slot] = ok ? 1 : 0;
         g->submitted = t + 1;
+        if (!ok) g->flush_upto = std::max(g->flush_upto, t + 1);   // (let the failed step's group leave at once)
         // the communication thread sleeps until a whole group is there (or somebody asks for a flush): waking it for
         // every step only to have it go back to sleep costs both threads a futex round trip per step
         wake = g->submitted >= g->enqueued + g->batch || g->flush_upto > g->enqueued;
     }
     if (wake) g->cv.notify_all();
     if (ticket) *ticket = t;
-    return BGS_OK;
+    return rc;
 }
 
 int bgs_gather_wait(bgs_gather* g, int64_t ticket) { return bgs::gather_wait(g, ticket, false); }
@@ -477,6 +699,7 @@ int bgs_gather_wait(bgs_gather* g, int64_t ticket) { return bgs::gather_wait(g, 
 
 int bgs::gather_wait(bgs_gather* g, int64_t ticket, bool urgent) {
     NEED(g != nullptr, "gather is NULL");
+    if (g->world == 1) return bgs::sink_wait(g->sink, ticket, urgent);
     int64_t enq;
     {
         std::unique_lock<std::mutex> lock(g->mu);
@@ -492,7 +715,14 @@ int bgs::gather_wait(bgs_gather* g, int64_t ticket, bool urgent) {
     if (g->rank == 0) return bgs::sink_wait(g->sink, ticket, urgent);  // the sink belongs to the gather: same ticket numbers
     // other ranks: "my codes have left".  A slot's event is reused `slots` steps later, and a step that old has been
     // sent long ago (its successor could not have been enqueued otherwise)
-    if (ticket + g->slots >= enq) HIP_TRY(hipEventSynchronize(g->sent[ticket % g->slots]));
+    if (ticket + g->slots >= enq) {
+        int ev;
+        {
+            std::lock_guard<std::mutex> lock(g->mu);
+            ev = g->cover_ev[ticket % g->slots];
+        }
+        HIP_TRY(hipEventSynchronize(g->sent[ev]));
+    }
     return BGS_OK;
 }
 

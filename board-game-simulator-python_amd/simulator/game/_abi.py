@@ -138,6 +138,8 @@ SIGNATURES = {
         [c_handle, c_handle, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
     ),
     "bgs_gather_wait": (ctypes.c_int, [c_handle, ctypes.c_int64]),
+    "bgs_gather_info": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "bgs_gather_transport": (ctypes.c_char_p, []),
     "bgs_gather_destroy": (ctypes.c_int, [c_handle]),
     "bgs_pipeline_create": (
         ctypes.c_int,

@@ -237,6 +237,17 @@ class RewardGather:
         self._alive[ticket.value] = (host_reward, batch)
         return ticket.value
 
+    def info(self) -> dict:
+        """How the gather runs: {"direct": receives straight into the sink's device-mapped slots (else device memory + a
+        copy kernel), "batch": steps per group of point-to-point calls, "transport_check": "none" (one rank) / "passed" /
+        "passed after falling back from direct receives", "transport": the library in use}."""
+        direct, batch, check = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _abi.check(_abi.lib().bgs_gather_info(self._handle, ctypes.byref(direct), ctypes.byref(batch), ctypes.byref(check)))
+        name = _abi.lib().bgs_gather_transport()
+        return {"direct": bool(direct.value), "batch": batch.value,
+                "transport_check": ("none", "passed", "passed after falling back from direct receives")[check.value],
+                "transport": name.decode() if name else ""}
+
     def wait(self, ticket: int) -> None:
         """Rank 0: the step's rewards of ALL ranks are in its host array; other ranks: this rank's codes have left."""
         _abi.check(_abi.lib().bgs_gather_wait(self._handle, int(ticket)))
@@ -320,10 +331,16 @@ class MultiDeviceRollout:
 
         import numpy as np
 
+        from .batch import _reward_destination
+
+        if not self._handle:
+            raise RuntimeError("this MultiDeviceRollout has been closed")
         if out is None:
             out = np.empty((len(self.devices) * self.n_per_device, 2), dtype=np.int8)
+        # (dtype, size, contiguity and writeability checked: the library writes devices * n * 2 bytes through this pointer)
+        ptr = _reward_destination(out, len(self.devices) * self.n_per_device)
         steps = ctypes.c_uint64(0)
-        _abi.check(_abi.lib().bgs_multi_rollout(self._handle, ctypes.c_uint64(seed), ctypes.c_void_p(out.ctypes.data), ctypes.byref(steps)))
+        _abi.check(_abi.lib().bgs_multi_rollout(self._handle, ctypes.c_uint64(seed), ctypes.c_void_p(ptr), ctypes.byref(steps)))
         return out, steps.value
 
     def close(self) -> None:

@@ -263,7 +263,14 @@ int bgs_bind_host_thread(int device, int* cpus);
  * reward sink.  Per step the launching thread makes ONE call, bgs_gather_rollout, which enqueues the rollout on the
  * batch's stream and returns; send, receives, copy to the host and expansion follow behind it on other threads and
  * streams while the next rollouts play.  The launcher (torch.distributed, MPI, a file) only has to carry the 128-byte
- * id from rank 0 to the others.  RCCL is loaded on first use (dlopen "librccl.so.1"). */
+ * id from rank 0 to the others.  RCCL is loaded on first use (dlopen "librccl.so.1"; BGS_RCCL_LIB=<path> names another
+ * library with the same nine nccl* entry points: the tests' shared-memory stand-in, tests/c/fake_rccl.hip).
+ * The machinery is per GROUP of steps (BGS_GATHER_BATCH, default slots / 2): one stream wait per launch stream, one
+ * group of point-to-point calls, one copy kernel, one event.  Rank 0 receives into device memory and a copy kernel takes
+ * the gathered codes to the sink's page-locked slots; BGS_GATHER_DIRECT=1 receives straight into the device-mapped slots.
+ * With two ranks or more bgs_gather_create sends one message per peer through the transport in that mode and compares
+ * what arrives in host memory (a direct receive that does not deliver falls back to the copy kernel, on stderr and in
+ * bgs_gather_info).  A one-rank world has nothing to gather: no thread, no stream, a step is bgs_sink_rollout. */
 #define BGS_UNIQUE_ID_BYTES 128
 typedef struct bgs_gather bgs_gather;
 int bgs_gather_unique_id(uint8_t* id /* [BGS_UNIQUE_ID_BYTES] */);   /* rank 0; ncclGetUniqueId */
@@ -277,6 +284,12 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
                        int64_t* ticket);
 /* rank 0: that step's rewards of all ranks are in its host array; other ranks: this rank's codes have been sent */
 int bgs_gather_wait(bgs_gather* g, int64_t ticket);
+/* how the gather runs: *direct 1 = receives straight into the sink's device-mapped slots, 0 = device memory + copy kernel;
+ * *batch = steps per group of point-to-point calls; *transport_check 0 = none (one rank), 1 = the create-time message
+ * arrived intact in the mode asked for, 2 = only after falling back from direct receives.  NULL pointers are skipped. */
+int bgs_gather_info(const bgs_gather* g, int* direct, int* batch, int* transport_check);
+/* name of the transport library in use ("librccl.so.1", or BGS_RCCL_LIB's path), "" when none could be loaded */
+const char* bgs_gather_transport(void);
 int bgs_gather_destroy(bgs_gather* g);
 
 /* ---- the rollout loop as ONE call (README.md:45-72 `while not state.has_ended`, for batch after batch) ------------------

@@ -21,18 +21,23 @@ expand them into the step's host array -- with three times as many host arrays a
 
 N > 1: one process per GPU, rank r owns global game ids [r * 2^20, (r+1) * 2^20) (RNG streams are keyed by global
 game id, so the shards reproduce the unsharded run).  The only exchange is the hand-over into THE one host array
-int8[N * 2^20, 2] (`--gather`):
-  shm   (default) the array lives in shared memory mapped by every rank of the node and each rank's own sink delivers
-        its rows -- the one-GPU loop on every rank, every GPU on its own PCIe link, no collective in the data path;
-        rank 0 is the consumer: it waits (futex) for every rank's delivery of a step and releases the slot, and the
-        timed region ends when it has seen the last step of every rank (simulator/sharding.py: SharedRewardRing);
+int8[N * 2^20, 2] (`--gather`, default `both`: the two hand-overs one after the other in the same run, each with its
+own timed regions and its own verification of rank 0's array against a replay of every rank's first games):
+  shm   the array lives in shared memory mapped by every rank of the node and each rank's own sink delivers its rows --
+        the one-GPU loop on every rank, every GPU on its own PCIe link, no collective in the data path; rank 0 is the
+        consumer: it waits (futex) for every rank's delivery of a step and releases the slot, and the timed region ends
+        when it has seen the last step of every rank (simulator/sharding.py: SharedRewardRing).  Carries `value`;
   rccl  the north-star's collective: every rank's codes to rank 0's GPU over RCCL / xGMI, inside the library
-        (bgs_gather_*: persistent communicator, communication stream and thread; the launching thread never enters
-        RCCL), rank 0's sink copies them to the host and expands them all.
-Plus one all-reduce of the step counters after the timed region.  Weak scaling.
+        (bgs_gather_*: persistent communicator, communication stream and thread, one group of point-to-point calls per
+        `slots / 2` steps; the launching thread never enters RCCL), rank 0's sink takes them to the host and expands them
+        all (`gather_rccl` block).  A gather that does not finish within BGS_BENCH_GATHER_TIMEOUT (180 s) is given up:
+        the line is printed with what the shared array measured and the gather's error.
+Plus one all-reduce of the step counters after each timed region.  Weak scaling.
 
 Environment (experiments): BGS_BENCH_SLOT_FACTOR (host arrays per stream, default 3), BGS_BENCH_TRACE=1 (where the
-timed region's time goes), BGS_FORCE_DIST=1 / BGS_DIST_BACKEND=gloo (the N > 1 loops on a one-GPU box).
+timed region's time goes), BGS_FORCE_DIST=1 (the N > 1 loops with one rank), BGS_DIST_BACKEND=gloo (several ranks on a
+one-GPU box: the ranks share the GPU; `--gather rccl` then needs BGS_RCCL_LIB=tests/c/libfake_rccl.so, the tests'
+shared-memory stand-in for RCCL, which runs the library's real world > 1 code).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline      : the binding resource of the rollout kernel -- VALU instruction issue: wave-instructions per launch
@@ -89,15 +94,35 @@ def free_port() -> int:
 
 def launch_ranks(n_ranks: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this process never touches
-    the GPU or imports torch), relay rank 0's JSON line and the children's exit codes."""
+    the GPU or imports torch), relay rank 0's JSON line and the children's exit codes.  Every child's stdout and stderr are
+    read WHILE it runs (a child that prints more than a pipe buffer -- a traceback, RCCL's debug output -- must not block
+    on a pipe nobody reads); stderr is passed through as it comes, each line under its rank's name."""
+    import threading
+
     env = dict(os.environ, WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(free_port()))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = []
+    procs, readers = [], []
+    lines = [[] for _ in range(n_ranks)]   # stdout lines per rank (only rank 0's JSON line is relayed)
+
+    def pump(stream, rank, is_err):
+        for text in iter(stream.readline, ""):
+            if is_err:
+                sys.stderr.write(text if n_ranks == 1 else f"[rank {rank}] {text}")
+                sys.stderr.flush()
+            else:
+                lines[rank].append(text)
+        stream.close()
+
     for rank in range(n_ranks):
         renv = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
-        out = subprocess.PIPE if rank == 0 else subprocess.DEVNULL  # only rank 0 prints the line
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv, stdout=out, text=True))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, bufsize=1)
+        procs.append(p)
+        for stream, is_err in ((p.stdout, False), (p.stderr, True)):
+            t = threading.Thread(target=pump, args=(stream, rank, is_err), daemon=True)
+            t.start()
+            readers.append(t)
     # a rank that dies leaves the others in a collective: give them a moment, then stop exactly the processes started here
     codes = [None] * n_ranks
     first_failure = None
@@ -113,16 +138,18 @@ def launch_ranks(n_ranks: int) -> int:
                     p.terminate()
             break
         time.sleep(0.05)
-    line = procs[0].communicate(timeout=60)[0] if procs[0].stdout else ""
     for r, p in enumerate(procs):
         try:
             codes[r] = p.wait(timeout=30)
         except subprocess.TimeoutExpired:
             p.kill()
             codes[r] = p.wait()
-    if line:
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for t in readers:
+        t.join(timeout=10)
+    for text in lines[0]:
+        if text.startswith("{"):   # (library banners on stdout are not part of the contract)
+            sys.stdout.write(text)
+    sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         print(f"bench.py: rank(s) failed (rank, exit code): {bad}", file=sys.stderr)
@@ -186,6 +213,25 @@ def cpu_baseline(last_seed, host_reward_head):
         gomp.omp_set_num_threads(cores)
     except OSError:
         pass
+    # ... and on EVERY core the process may use (the north-star asks for the box's host cores; the 16-thread figure above is
+    # what a one-GPU share of the host gets): a shorter sample, the thread team is new
+    all_cores = None
+    if avail > cores and os.environ.get("BGS_CPU_ALL_CORES", "1") != "0":
+        try:
+            gomp = ctypes.CDLL("libgomp.so.1")
+            gomp.omp_set_num_threads(avail)
+            orc.reset()
+            orc.rollout(SEED + 2000, max_plies=4)
+            t_all, s_all = 0.0, 0
+            for r in range(4):
+                orc.reset()
+                t0 = time.perf_counter()
+                s_all += orc.rollout(SEED + 2001 + r)
+                t_all += time.perf_counter() - t0
+            all_cores = {"value": s_all / t_all, "unit": "env-steps/s", "cores": avail, "sample": f"4 x 2^20 games ({s_all} env-steps)"}
+            gomp.omp_set_num_threads(cores)
+        except OSError:
+            pass
     capped = f"; {avail} cores visible, capped at BGS_CPU_THREADS={cap}" if avail > cap else ""
     return {
         "value": total / elapsed,
@@ -195,7 +241,10 @@ def cpu_baseline(last_seed, host_reward_head):
         "single_game_latency_us": latency,
         "single_game_mean_plies": plies,
         "single_game_us_inside_a_batch": (plies / single * 1e6) if single and plies else None,
-        "kind": "port",
+        "kind": "port",   # (the bench contract's word for "the oracle, not oracle/_ref"; what it is: see kind_note)
+        "kind_note": "restatement: oracle/bgs_oracle.c restates the algorithm in plain C from the reference's binding sites and "
+                     "tests; it is neither the reference's code nor a port of it (the reference's core is an un-vendored dependency)",
+        "all_cores": all_cores,
         "sample": f"CPU restatement (oracle/bgs_oracle.c, OpenMP, {cores} threads{capped}) -- the reference's own core is not "
         f"buildable offline: {reps} x 2^20 Connect4(6,7,4) games from the initial state ({total} env-steps); "
         "single_game_latency_us = one game (BASELINE config 1, N = 1) per reset + rollout call of the oracle through ctypes, mean "
@@ -457,11 +506,13 @@ def main() -> int:
     ap.add_argument("--host-threads", type=int, default=0,
                     help="worker threads of the reward sink; 0 = 6 on one GPU, 4 per rank with --gather shm, "
                     "min(24, 4 + 2 N) on rank 0 with --gather rccl (it expands N x 2 MiB of rewards per step)")
-    ap.add_argument("--gather", default="shm",
-                    help="N > 1: how the ranks' rewards reach the one host array. shm (default): the array is in shared "
+    ap.add_argument("--gather", default="both",
+                    help="N > 1: how the ranks' rewards reach the one host array. shm: the array is in shared "
                          "memory and every rank's own sink delivers its rows (no collective, every GPU uses its own PCIe "
                          "link); rccl: outcome codes gathered to rank 0's GPU over RCCL inside the library, rank 0's sink "
-                         "expands them all")
+                         "expands them all; both (default): one after the other in the same run -- `value` is the shared "
+                         "array's, and the line carries a `gather_shm` and a `gather_rccl` block, each with its own "
+                         "verification of rank 0's host array")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed steps (hand-over included) before the W warm-up steps until this many milliseconds have "
                     "passed: the GPU's power state climbs for tens of milliseconds under load, and RCCL connects on first "
@@ -473,8 +524,8 @@ def main() -> int:
     ap.add_argument("--no-repeats", action="store_true", help="skip the two extra timed regions behind `value_median_of_3`")
     ap.add_argument("--only", choices=sorted(OTHER_CONFIGS), help="measure one of the other BASELINE configs and print its JSON object")
     args = ap.parse_args()
-    if args.gather not in ("shm", "rccl"):
-        print("bench.py: --gather must be shm or rccl", file=sys.stderr)
+    if args.gather not in ("shm", "rccl", "both"):
+        print("bench.py: --gather must be shm, rccl or both", file=sys.stderr)
         return 2
     if args.only:
         return run_other_config(args.only, max(2, args.steps))
@@ -538,38 +589,22 @@ def main() -> int:
         print("bench.py: --batch must be a multiple of 4 when sharded (4 outcome codes per byte)", file=sys.stderr)
         return 2
     handover = args.handover
-    ring_mode = sharded and args.gather == "shm" and handover == "codes"
-    lib_gather = sharded and args.gather == "rccl" and handover == "codes" and backend == "nccl"
-    torch_gather = sharded and args.gather == "rccl" and handover == "codes" and backend != "nccl"  # gloo rehearsal
-    if args.host_threads <= 0:
-        args.host_threads = 6 if not sharded else 4 if ring_mode else min(24, 4 + 2 * world)
+    # which hand-overs this run measures: one GPU -> the plain sink; N > 1 -> `--gather` (default both: the shared host
+    # array first -- it carries `value` -- then the in-library RCCL gather, each with its own verification)
+    if not sharded or handover == "none":
+        kinds = ["sink"]
+    else:
+        kinds = ["shm", "rccl"] if args.gather == "both" else [args.gather]
+    if "rccl" in kinds and backend != "nccl" and not os.environ.get("BGS_RCCL_LIB"):
+        print("bench.py: --gather rccl runs the in-library gather: it needs RCCL (backend nccl) or, for a rehearsal on one GPU, "
+              "BGS_RCCL_LIB=<tests/c/libfake_rccl.so>", file=sys.stderr)
+        return 2
     depth = max(1, args.inflight)
     os.environ.setdefault("BGS_ROLLOUT_WPS", "2")  # waves per SIMD per launch; `depth` launches share the chip
     streams = [torch.cuda.Stream(device=local_rank) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
     gpu = torch.device("cuda", local_rank)
     code_bytes = (n + 3) // 4
     owner = rank == 0  # rank 0 owns "the one host array"
-    # The hand-over pipeline is deeper than the GPU's (three times as many host arrays / sink slots as streams), so the
-    # launching thread waits for the delivery of step i - 3 * depth, not i - depth, before it enqueues step i (measured,
-    # tools/slots_sweep.sh: 3 per stream is 3 % faster than 2 on a 20-step run, 4 is slower: more arrays than the caches
-    # hold).
-    # Shared array: the consumer rank's launch loop also waits for EVERY rank's delivery of hand-over j - lag before it
-    # enqueues hand-over j, so it runs `lag`, not `host_slots`, steps ahead of the deliveries: one more array per stream
-    # keeps lag at 3 per stream (a delivery -> futex wake-up -> enqueue chain takes ~100 us, 3 steps' worth).
-    # (the in-library gather sends the codes of slots / 2 steps in one group of point-to-point calls: 12 arrays, groups of 6)
-    factor = int(os.environ.get("BGS_BENCH_SLOT_FACTOR", "4" if ring_mode or lib_gather else "3"))
-    host_slots = max(2, factor * depth)
-    ring = None
-    if ring_mode:
-        try:
-            ring = SharedRewardRing(dist, n, host_slots)
-        except RuntimeError as exc:  # raised on every rank or on none: all ranks fall back together
-            if rank == 0:
-                print(f"bench.py: {exc}; falling back to --gather rccl", file=sys.stderr)
-            ring_mode = False
-            lib_gather, torch_gather = backend == "nccl", backend != "nccl"
-            if args.host_threads == 4:
-                args.host_threads = min(24, 4 + 2 * world)
     batches = []
     for s in streams:
         with torch.cuda.stream(s):
@@ -577,156 +612,209 @@ def main() -> int:
             b.set_first_game(shard_range(n * world, rank, world)[0])
             batches.append(b)
     device = gpu if backend == "nccl" else torch.device("cpu")
-    rows = world * n if (lib_gather or torch_gather) else n
-    sink = gather = None
-    host_rewards = []
-    if handover == "codes":
+    # HIP-event pairs bracket a sample of the launches on the launch stream: about 32 pairs (at least every other launch
+    # stays unbracketed: a pair is two marker packets on the stream)
+    stride = max(2, args.steps // int(os.environ.get("BGS_BENCH_PAIRS", "32")))
+
+    def measure(kind, with_device_resident):
+        """Everything for ONE hand-over: its sink / ring / gather and the native loop on them, pre-warm, warm-up, the timed
+        region, two repeats, the verification of rank 0's host array; returns a dict and leaves nothing behind."""
+        ring_mode, lib_gather = kind == "shm", kind == "rccl"
+        host_threads = args.host_threads
+        if host_threads <= 0:
+            host_threads = 6 if kind == "sink" else 4 if ring_mode else min(24, 4 + 2 * world)
+        # The hand-over pipeline is deeper than the GPU's (three times as many host arrays / sink slots as streams), so the
+        # launching thread waits for the delivery of step i - 3 * depth, not i - depth, before it enqueues step i (measured,
+        # tools/slots_sweep.sh: 3 per stream is 3 % faster than 2 on a 20-step run, 4 is slower: more arrays than the caches
+        # hold).
+        # Shared array: the consumer rank's launch loop also waits for EVERY rank's delivery of hand-over j - lag before it
+        # enqueues hand-over j, so it runs `lag`, not `host_slots`, steps ahead of the deliveries: one more array per stream
+        # keeps lag at 3 per stream (a delivery -> futex wake-up -> enqueue chain takes ~100 us, 3 steps' worth).
+        # (the in-library gather sends the codes of slots / 2 steps in one group of point-to-point calls: 12 arrays, groups of 6)
+        factor = int(os.environ.get("BGS_BENCH_SLOT_FACTOR", "4" if ring_mode or lib_gather else "3"))
+        host_slots = max(2, factor * depth)
+        ring = sink = gather = None
+        note = None
         if ring_mode:
-            host_rewards = [ring.mine(k) for k in range(host_slots)]  # this rank's rows of the shared arrays
-            sink = RewardSink(n, slots=host_slots, threads=args.host_threads, device=local_rank)
-            ring.attach(sink)  # the sink's workers announce every delivery in this rank's progress word
-        elif lib_gather:
-            # written by rank 0's sink workers; filled here so that every page is mapped before the clock starts
-            host_rewards = [np.full((rows, 2), 0x55, dtype=np.int8) if owner else None for _ in range(host_slots)]
-            gather = RewardGather(dist, n, slots=host_slots, host_threads=args.host_threads, device=local_rank)
-        elif torch_gather:
-            host_rewards = [np.full((rows, 2), 0x55, dtype=np.int8) if owner else None for _ in range(host_slots)]
-        else:
-            host_rewards = [np.full((n, 2), 0x55, dtype=np.int8) for _ in range(host_slots)]
-            sink = RewardSink(n, slots=host_slots, threads=args.host_threads, device=local_rank)
-    exe = None
-    if not torch_gather:
+            try:
+                ring = SharedRewardRing(dist, n, host_slots)
+            except RuntimeError as exc:  # raised on every rank or on none
+                return {"error": str(exc)}
+        rows = world * n if lib_gather else n
+        host_rewards = []
+        if handover == "codes":
+            if ring_mode:
+                host_rewards = [ring.mine(k) for k in range(host_slots)]  # this rank's rows of the shared arrays
+                sink = RewardSink(n, slots=host_slots, threads=host_threads, device=local_rank)
+                ring.attach(sink)  # the sink's workers announce every delivery in this rank's progress word
+            elif lib_gather:
+                # written by rank 0's sink workers; filled here so that every page is mapped before the clock starts
+                host_rewards = [np.full((rows, 2), 0x55, dtype=np.int8) if owner else None for _ in range(host_slots)]
+                gather = RewardGather(dist, n, slots=host_slots, host_threads=host_threads, device=local_rank)
+                note = gather.info()
+            else:
+                host_rewards = [np.full((n, 2), 0x55, dtype=np.int8) for _ in range(host_slots)]
+                sink = RewardSink(n, slots=host_slots, threads=host_threads, device=local_rank)
         exe = RolloutExecutor(batches, sink=sink, gather=gather, host_arrays=host_rewards if (sink or gather) else (), seed0=SEED)
         if ring_mode:
             exe.set_ring(ring, consumer=owner, lag=host_slots - depth)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if ring is not None:
-            # the ranks of a node meet on words of the shared segment within microseconds; a barrier collective is a
-            # launch + a kernel + a synchronise on every rank, tens of microseconds of a 0.7 ms region -- twice
-            ring.barrier()
-        elif dist is not None:
-            dist.barrier()
+        def barrier():
             torch.cuda.synchronize()
+            if ring is not None:
+                # the ranks of a node meet on words of the shared segment within microseconds; a barrier collective is a
+                # launch + a kernel + a synchronise on every rank, tens of microseconds of a 0.7 ms region -- twice
+                ring.barrier()
+            elif dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    # ---- the gloo rehearsal of --gather rccl: torch collectives on host copies, a Python loop (never the timed path
-    # of a real run: RCCL cannot put several ranks on one GPU, so a one-GPU box exercises the gather's ordering here)
-    state = {"step": 0}
-
-    def torch_gather_steps(count, with_handover):
-        for _ in range(count):
-            i = state["step"]
-            b = batches[i % depth]
-            with torch.cuda.stream(streams[i % depth]):
-                if not with_handover:
-                    b.rollout(SEED + i, from_initial=True)
-                else:
-                    buf = torch.zeros((n + 63) // 64 * 16, dtype=torch.uint8, device=gpu)
-                    b.rollout_outcomes_tensor(buf, SEED + i, from_initial=True)
-                    got = gather_outcomes_to(dist, buf[:code_bytes].cpu(), torch.empty(world * code_bytes, dtype=torch.uint8) if owner else None, dst=0)
-                    if owner:
-                        expand_outcomes_host(got.numpy(), world * n, host_rewards[i % host_slots])
-                        state["last_host"] = host_rewards[i % host_slots]
-            state["step"] = i + 1
-
-    def run_steps(count, with_handover, stride=0):
-        if exe is not None:
+        def timed_region(count, with_handover, stride):
+            for b in batches:
+                b.reset_steps()
+            barrier()
+            t0 = time.perf_counter()
             exe.enqueue(count, with_handover and handover != "none", stride)
-        else:
-            torch_gather_steps(count, with_handover)
+            t_enqueued = time.perf_counter()
+            exe.drain()  # every step's rewards are in their host array (all ranks' rows, for the consumer) before the clock stops
+            t_drained = time.perf_counter()
+            barrier()
+            dt = time.perf_counter() - t0
+            if os.environ.get("BGS_BENCH_TRACE"):
+                print(f"[trace] rank {rank} ({kind}): {count} steps, handover={with_handover}: enqueued at {(t_enqueued - t0) * 1e3:.3f} ms, "
+                      f"rewards on the host at {(t_drained - t0) * 1e3:.3f} ms, device idle at {dt * 1e3:.3f} ms", file=sys.stderr)
+            steps_local = sum(b.steps for b in batches)
+            kernel_ms = exe.kernel_ms()[0] if stride else None
+            if dist is not None:
+                t = torch.tensor([dt], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+                steps_total = sum_steps(dist, steps_local, device)
+            else:
+                steps_total = steps_local
+            return dt, steps_total, steps_local, kernel_ms
 
-    def drain():
-        if exe is not None:
-            exe.drain()
+        # untimed: bring the device to its loaded power state (and RCCL to connected peers), then the W warm-up steps
+        prewarm_steps = 0
+        if args.prewarm_ms > 0:
+            t_end = time.perf_counter() + args.prewarm_ms * 1e-3
+            while True:
+                exe.enqueue(4 * depth, handover != "none")
+                exe.drain()
+                prewarm_steps += 4 * depth
+                go_on = time.perf_counter() < t_end
+                if dist is not None:  # every rank makes the same number of (collective) steps
+                    flag = torch.tensor([1 if go_on else 0], dtype=torch.int32, device=device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    go_on = bool(flag.item())
+                if not go_on:
+                    break
+        exe.enqueue(args.warmup, handover != "none")
+        exe.drain()
+        elapsed, steps_total, steps_local, kernel_ms = timed_region(args.steps, True, stride)
+        last = exe.steps - 1  # index (= seed offset) of the last timed step
 
-    def steps_done():
-        return exe.steps if exe is not None else state["step"]
+        # the host array of the LAST timed step (a copy: the extra passes below reuse the slots)
+        final_host = None
+        if owner and handover != "none":
+            final_host = np.array(ring.array((exe.handovers - 1) % host_slots)) if ring is not None else np.array(exe.last_host_array())
 
-    def timed_region(count, with_handover, stride):
-        for b in batches:
-            b.reset_steps()
-        barrier()
-        t0 = time.perf_counter()
-        run_steps(count, with_handover, stride)
-        t_enqueued = time.perf_counter()
-        drain()  # every step's rewards are in their host array (all ranks' rows, for the consumer) before the clock stops
-        t_drained = time.perf_counter()
-        barrier()
-        dt = time.perf_counter() - t0
-        if os.environ.get("BGS_BENCH_TRACE"):
-            print(f"[trace] rank {rank}: {count} steps, handover={with_handover}: enqueued at {(t_enqueued - t0) * 1e3:.3f} ms, "
-                  f"rewards on the host at {(t_drained - t0) * 1e3:.3f} ms, device idle at {dt * 1e3:.3f} ms", file=sys.stderr)
-        steps_local = sum(b.steps for b in batches)
-        kernel_ms = exe.kernel_ms()[0] if exe is not None and stride else None
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-            steps_total = sum_steps(dist, steps_local, device)
-        else:
-            steps_total = steps_local
-        return dt, steps_total, steps_local, kernel_ms
+        gather_ok = None
+        if dist is not None and owner and final_host is not None:
+            # the host array must hold every rank's rewards in global game order: rank 0 re-plays the first games of EVERY
+            # rank's shard on its own GPU (RNG streams are keyed by global game id) and compares
+            gather_ok = True
+            for r in range(world):
+                probe = ConnectBatch(HEIGHT, WIDTH, COUNT, 4096, device=local_rank, use_torch=True)
+                probe.set_first_game(r * n)
+                probe.rollout(SEED + last, from_initial=True)
+                gather_ok = gather_ok and bool((probe.reward == final_host[r * n : r * n + 4096]).all())
+                probe.close()
 
-    # untimed: bring the device to its loaded power state (and RCCL to connected peers), then the W warm-up steps
-    prewarm_steps = 0
-    if args.prewarm_ms > 0:
-        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
-        while True:
-            run_steps(4 * depth, True)
-            drain()
-            prewarm_steps += 4 * depth
-            go_on = time.perf_counter() < t_end
-            if dist is not None:  # every rank makes the same number of (collective) steps
-                flag = torch.tensor([1 if go_on else 0], dtype=torch.int32, device=device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                go_on = bool(flag.item())
-            if not go_on:
-                break
-    run_steps(args.warmup, True)
-    drain()
-    # HIP-event pairs bracket a sample of the launches on the launch stream: about 32 pairs (at least every other launch
-    # stays unbracketed: a pair is two marker packets on the stream)
-    stride = max(2, args.steps // int(os.environ.get("BGS_BENCH_PAIRS", "32")))
-    elapsed, steps_total, steps_local, kernel_ms = timed_region(args.steps, True, stride)
-    last = steps_done() - 1  # index (= seed offset) of the last timed step
+        # two more timed regions of the same length, back to back in the same process: how much one region's value moves
+        repeats = [steps_total / elapsed]
+        if not args.no_repeats:
+            for _ in range(2):
+                dt, st, _, _ = timed_region(args.steps, True, 0)
+                repeats.append(st / dt)
 
-    # the host array of the LAST timed step (a copy: the extra passes below reuse the slots)
-    final_host = None
-    if owner and handover != "none":
+        # the same launches without the hand-over (rewards stay on the device), timed separately: what the hand-over costs
+        device_resident = None
+        if with_device_resident and handover != "none":
+            reps = min(args.steps, 100)
+            dt, st, _, k_ms = timed_region(reps, False, max(1, reps // 32))
+            device_resident = {"value": st / dt, "unit": "env-steps/s", "ms_per_step": dt / reps * 1e3, "steps": reps,
+                               "kernel_ms_per_launch": k_ms}
+        # one launch at a time (no hand-over, one stream): what the pipelining of `depth` launches buys
+        solo = None
+        if with_device_resident and os.environ.get("BGS_BENCH_SOLO", "1") != "0":
+            solo_exe = RolloutExecutor(batches[:1], seed0=SEED + 7000)
+            solo_exe.enqueue(2, False)
+            solo_exe.drain()
+            reps = min(args.steps, 50)
+            batches[0].reset_steps()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            solo_exe.enqueue(reps, False, 1)
+            solo_exe.drain()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            k_ms, pairs = solo_exe.kernel_ms()
+            solo = {"value": batches[0].steps / dt, "unit": "env-steps/s", "ms_per_launch": dt / reps * 1e3,
+                    "kernel_ms_per_launch": k_ms, "event_pairs": pairs, "steps": reps, "rewards_to_host": False,
+                    "note": "ONE launch in flight on one stream (the rate a caller of a plain rollout() loop sees); `value` "
+                            f"is {depth} launches sharing the chip"}
+            solo_exe.close()
+            for b in batches:   # (the launch shape follows the launches in flight: back to the pipeline's)
+                b.set_launches_in_flight(depth)
+        result = {"kind": kind, "elapsed": elapsed, "steps_total": steps_total, "steps_local": steps_local, "kernel_ms": kernel_ms,
+                  "last": last, "final_host": final_host, "gather_ok": gather_ok, "repeats": repeats, "solo": solo,
+                  "device_resident": device_resident, "prewarm_steps": prewarm_steps, "host_slots": host_slots,
+                  "host_threads": host_threads, "rows": rows, "note": note}
+        exe.close()
+        if gather is not None:
+            gather.close()
+        if sink is not None:
+            sink.close()
         if ring is not None:
-            final_host = np.array(ring.array((exe.handovers - 1) % host_slots))
-        elif exe is not None:
-            final_host = np.array(exe.last_host_array())
-        else:
-            final_host = np.array(state["last_host"])
+            ring.close()
+        return result
 
-    gather_ok = None
-    if dist is not None and owner and final_host is not None:
-        # the host array must hold every rank's rewards in global game order: rank 0 re-plays the first games of the
-        # LAST rank's shard on its own GPU (RNG streams are keyed by global game id) and compares
-        probe = ConnectBatch(HEIGHT, WIDTH, COUNT, 4096, device=local_rank, use_torch=True)
-        probe.set_first_game((world - 1) * n)
-        probe.rollout(SEED + last, from_initial=True)
-        gather_ok = bool((probe.reward == final_host[(world - 1) * n : (world - 1) * n + 4096]).all())
-        probe.close()
+    def sharding_text(res):
+        kind, threads = res["kind"], res["host_threads"]
+        if kind == "shm":
+            return (f"game ids split over {world} rank(s); no data-path collective: the host array int8[{world * n}, 2] is "
+                    f"in shared memory and every rank's own sink delivers its rows ({code_bytes} B of codes per step "
+                    f"over the rank's own PCIe link, {threads} host threads per rank); rank 0 consumes: it waits "
+                    f"for every rank's delivery of each step (futex) and releases the slot")
+        if kind == "rccl":
+            info = res["note"] or {}
+            how = ("straight into the sink's device-mapped page-locked slot" if info.get("direct") else
+                   "into device memory, one copy kernel per group takes them to the sink's page-locked slots")
+            return (f"game ids split over {world} rank(s); RCCL gather inside the library (persistent communicator, communication "
+                    f"thread and stream): groups of {info.get('batch')} steps of 2-bit outcome codes ({code_bytes} B per rank "
+                    f"and step) to rank 0, received {how}; rank 0's sink expands them ({threads} host threads); transport "
+                    f"{info.get('transport')}, create-time check: {info.get('transport_check')}")
+        return "single GPU"
 
-    # two more timed regions of the same length, back to back in the same process: how much one region's value moves
-    repeats = [steps_total / elapsed]
-    if not args.no_repeats:
-        for _ in range(2):
-            dt, st, _, _ = timed_region(args.steps, True, 0)
-            repeats.append(st / dt)
+    def block(res):
+        """What one hand-over measured, for the `gather_<kind>` entries of the line."""
+        if "error" in res:
+            return res
+        v = res["steps_total"] / res["elapsed"]
+        to_host = code_bytes * (world if res["kind"] == "rccl" else 1)
+        ms = res["elapsed"] / args.steps * 1e3
+        return {"value": v, "unit": "env-steps/s", "ms_per_step": ms, "values_of_3": res["repeats"] if len(res["repeats"]) == 3 else None,
+                "gathered_rewards_verified": res["gather_ok"], "sharding": sharding_text(res), "host_arrays": res["host_slots"],
+                "host_threads": res["host_threads"], "gather_info": res["note"],
+                "pcie_bytes_per_step_on_rank0": to_host, "pcie_GBps_on_rank0": to_host / (ms * 1e-3) / 1e9}
 
-    # the same launches without the hand-over (rewards stay on the device), timed separately: what the hand-over costs
-    device_resident = None
-    if not args.no_device_resident and handover != "none":
-        reps = min(args.steps, 100)
-        dt, st, _, k_ms = timed_region(reps, False, max(1, reps // 32))
-        device_resident = {"value": st / dt, "unit": "env-steps/s", "ms_per_step": dt / reps * 1e3, "steps": reps,
-                           "kernel_ms_per_launch": k_ms}
-
-    if rank == 0:
+    def build_line(results, extra=None):
+        """The one JSON line: `value` and the roofline from the FIRST hand-over measured, every hand-over of an N > 1 run in
+        its own `gather_<kind>` block."""
+        primary = results[0]
+        elapsed, steps_total, steps_local, kernel_ms = primary["elapsed"], primary["steps_total"], primary["steps_local"], primary["kernel_ms"]
+        repeats = primary["repeats"]
         value = steps_total / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         steps_per_launch = steps_local / args.steps
@@ -750,10 +838,10 @@ def main() -> int:
                                    "GBps_over_ms_per_step": steps_per_launch * BYTES_PER_STEP / (ms_per_step * 1e-3) / 1e9,
                                    "note": "SURVEY 8d's per-ply byte model (32 B per env-step): what a ply-per-launch design would "
                                    "move. A fused rollout avoids it, so the figure may exceed the HBM peak; it is not a roofline"}
-        to_host = 0 if handover == "none" else code_bytes * (world if (lib_gather or torch_gather) else 1)
+        to_host = 0 if handover == "none" else code_bytes * (world if primary["kind"] == "rccl" else 1)
         roof["pcie"] = {"bytes_per_step": to_host, "achieved_GBps": to_host / (ms_per_step * 1e-3) / 1e9,
                         "peak_GBps": PCIE_PEAK_GBS, "frac": to_host / (ms_per_step * 1e-3) / 1e9 / PCIE_PEAK_GBS}
-        gather_name = "none" if not sharded else "shm" if ring_mode else "rccl" if lib_gather else f"{backend} (rehearsal)"
+        measured = [r["kind"] for r in results]
         out = {
             "metric": "env-steps/sec, Connect4(6,7,4) random rollout, batch="
             + ("2^20" if n == BATCH_PER_GPU else str(n)) + " per GPU",
@@ -778,52 +866,95 @@ def main() -> int:
                 "env_steps_per_step": steps_total / args.steps,
                 "rewards_to_host": handover != "none",
                 "handover": {"codes": f"2-bit outcome codes ({code_bytes} B per rank and step) -> page-locked slot -> "
-                             f"{args.host_threads} host threads expand into int8[{rows}, 2]",
+                             f"{primary['host_threads']} host threads expand into int8[{primary['rows']}, 2]",
                              "none": "rewards stay on the device"}[handover],
-                "gather": gather_name,
-                "sharding": (f"game ids split over {world} rank(s); no data-path collective: the host array int8[{world * n}, 2] is "
-                             f"in shared memory and every rank's own sink delivers its rows ({code_bytes} B of codes per step "
-                             f"over the rank's own PCIe link, {args.host_threads} host threads per rank); rank 0 consumes: it waits "
-                             f"for every rank's delivery of each step (futex) and releases the slot" if ring_mode else
-                             f"game ids split over {world} rank(s); per step RCCL gather (in-library: persistent communicator, "
-                             f"communication thread and stream) of 2-bit outcome codes ({code_bytes} B per rank) to rank 0, whose "
-                             f"sink expands them" if lib_gather else
-                             f"game ids split over {world} rank(s); per step {backend} gather of 2-bit outcome codes "
-                             f"({code_bytes} B per rank) to rank 0 (rehearsal of the RCCL gather on host copies)" if torch_gather else
-                             "single GPU"),
-                "gathered_rewards_verified": gather_ok,
+                "gather": "none" if not sharded else primary["kind"],
+                "gathers_measured": measured if sharded else None,
+                "sharding": sharding_text(primary),
+                "gathered_rewards_verified": primary["gather_ok"],
                 "numa_bound_cpus": bound_cpus,
                 "inflight_batches": depth,
-                "prewarm": {"ms": args.prewarm_ms, "steps": prewarm_steps},
-                "host_arrays": host_slots,
-                "loop": "native (bgs_pipeline_enqueue: one library call per timed region)" if exe is not None else "python (rehearsal)",
+                "prewarm": {"ms": args.prewarm_ms, "steps": primary["prewarm_steps"]},
+                "host_arrays": primary["host_slots"],
+                "loop": "native (bgs_pipeline_enqueue: one library call per timed region)",
                 "waves_per_simd_per_launch": int(os.environ["BGS_ROLLOUT_WPS"]),
                 "build_id": build,
             },
             "roofline": roof,
         }
-        if device_resident is not None:
-            device_resident["host_over_device"] = value / device_resident["value"]
-            out["device_resident"] = device_resident
-        if world == 1 and not sharded:
-            if not args.no_cpu_baseline:
-                os.sched_setaffinity(0, free_cpus)
-                head = final_host[:65536] if final_host is not None else batches[last % depth].reward[:65536]
-                out["cpu_baseline"] = cpu_baseline(SEED + last, head)
-                out["cpu_baseline"]["gpu_single_game_latency_us"] = gpu_single_game_latency()
-            if not args.no_other_configs:
-                out["grids_to_host"] = grids_to_host()
-                out["other_configs"] = other_configs()
-        print(json.dumps(out), flush=True)
+        if sharded and handover != "none":
+            # every hand-over this run measured, each with its own verification of rank 0's host array; `value` is the first
+            for r in results:
+                out[f"gather_{r['kind']}"] = block(r)
+        if primary["device_resident"] is not None:
+            primary["device_resident"]["host_over_device"] = value / primary["device_resident"]["value"]
+            out["device_resident"] = primary["device_resident"]
+        if primary.get("solo") is not None:
+            primary["solo"]["pipelined_over_solo"] = value / primary["solo"]["value"]
+            out["solo"] = primary["solo"]
+        out.update(extra or {})
+        return out
 
-    if exe is not None:
-        exe.close()
-    if gather is not None:
-        gather.close()
-    if sink is not None:
-        sink.close()
-    if ring is not None:
-        ring.close()
+    # A hand-over that hangs (a collective that never completes) must not take the whole line with it when another one
+    # has already been measured: the watchdog prints the line with what there is and ends the process.
+    results = []
+    state = {"line_printed": False}
+
+    def emit(extra=None):
+        if rank == 0 and not state["line_printed"] and results and "error" not in results[0]:
+            state["line_printed"] = True
+            print(json.dumps(build_line(results, extra)), flush=True)
+
+    import threading
+
+    for k, kind in enumerate(kinds):
+        dog = None
+        if k > 0:
+            limit = float(os.environ.get("BGS_BENCH_GATHER_TIMEOUT", "180"))
+
+            def bark(kind=kind, limit=limit):
+                print(f"bench.py: rank {rank}: the {kind} hand-over did not finish within {limit:.0f} s; giving it up", file=sys.stderr)
+                emit({f"gather_{kind}": {"error": f"did not finish within {limit:.0f} s"}})
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(0 if state["line_printed"] or rank != 0 else 3)
+
+            dog = threading.Timer(limit, bark)
+            dog.daemon = True
+            dog.start()
+        try:
+            res = measure(kind, with_device_resident=(k == 0 and not args.no_device_resident))
+        except Exception as exc:  # noqa: BLE001 -- reported in the line (or, for the first hand-over, fatal)
+            if k == 0:
+                raise
+            res = {"kind": kind, "error": f"{type(exc).__name__}: {exc}"}
+        finally:
+            if dog is not None:
+                dog.cancel()
+        if "error" in res and k == 0 and kind == "shm" and len(kinds) == 1:
+            # the shared host array could not be set up (every rank sees the same error): fall back to the gather
+            if rank == 0:
+                print(f"bench.py: {res['error']}; falling back to --gather rccl", file=sys.stderr)
+            res = measure("rccl", with_device_resident=not args.no_device_resident)
+        res.setdefault("kind", kind)
+        results.append(res)
+    results.sort(key=lambda r: "error" in r)   # (stable: the first hand-over that was measured carries `value`)
+    if "error" in results[0]:
+        print(f"bench.py: rank {rank}: {results[0]['error']}", file=sys.stderr)
+        return 1
+
+    extra = {}
+    if rank == 0 and world == 1 and not sharded:
+        primary = results[0]
+        if not args.no_cpu_baseline:
+            os.sched_setaffinity(0, free_cpus)
+            head = primary["final_host"][:65536] if primary["final_host"] is not None else batches[primary["last"] % depth].reward[:65536]
+            extra["cpu_baseline"] = cpu_baseline(SEED + primary["last"], head)
+            extra["cpu_baseline"]["gpu_single_game_latency_us"] = gpu_single_game_latency()
+        if not args.no_other_configs:
+            extra["grids_to_host"] = grids_to_host()
+            extra["other_configs"] = other_configs()
+    emit(extra)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -485,17 +485,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("gather,ranks", [("shm", 3), ("rccl", 2)])
+@pytest.mark.parametrize("gather,ranks", [("shm", 3), ("rccl", 2), ("both", 3)])
 def test_bench_multi_rank_rehearsal(gather, ranks):
     """bench.py's own N > 1 loops as child processes sharing this box's GPU (gloo carries the control messages; RCCL
-    cannot run several ranks on one GPU): `shm` -- the default: one host array in shared memory, every rank's sink
-    delivers its rows, rank 0 consumes (futex hand-shake inside the native loop); `rccl` -- the gather's rehearsal on
-    host copies.  Rank 0's host array must verify against a replay of the LAST rank's games."""
+    cannot run several ranks on one GPU): `shm` -- one host array in shared memory, every rank's sink delivers its rows,
+    rank 0 consumes (futex hand-shake inside the native loop); `rccl` -- the IN-LIBRARY gather (bgs_gather_*, the code a
+    real 8-GPU run executes) over the tests' shared-memory stand-in for RCCL; `both` -- the default of an N > 1 run: the
+    two one after the other, `value` from the shared array.  Rank 0's host array must verify against a replay of EVERY
+    rank's first games."""
+    from tests.test_gpu_gather_peers import build_fake_rccl
+
     port = _free_port()
     procs = []
     for rank in range(ranks):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(ranks), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+                   MASTER_PORT=str(port), BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", BGS_RCCL_LIB=build_fake_rccl())
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "25", "--warmup", "2", "--batch",
                str(1 << 16), "--no-cpu-baseline", "--gather", gather, "--host-threads", "2"]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -505,15 +509,24 @@ def test_bench_multi_rank_rehearsal(gather, ranks):
     d = json.loads(line)
     assert d["n_gpus"] == ranks and d["config"]["gathered_rewards_verified"] is True
     assert d["config"]["rewards_to_host"] is True and d["config"]["global_batch"] == ranks << 16
-    assert ("shared memory" in d["config"]["sharding"]) == (gather == "shm")
-    assert d["config"]["gather"] == ("shm" if gather == "shm" else "gloo (rehearsal)")
+    assert ("shared memory" in d["config"]["sharding"]) == (gather != "rccl")
+    assert d["config"]["gather"] == ("rccl" if gather == "rccl" else "shm")
+    for kind in (("shm", "rccl") if gather == "both" else (gather,)):
+        blk = d[f"gather_{kind}"]
+        assert blk["gathered_rewards_verified"] is True and blk["value"] > 0 and len(blk["values_of_3"]) == 3
+    if gather != "shm":
+        info = d["gather_rccl"]["gather_info"]
+        assert info["direct"] is False and info["batch"] == 6 and info["transport_check"] == "passed"
+        assert "libfake_rccl" in info["transport"] and "RCCL gather inside the library" in d["gather_rccl"]["sharding"]
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # only rank 0 prints the line
 
 
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 3` with no launcher around it: the script starts its three ranks as child processes (before
     it touches the GPU itself), relays rank 0's line and exits 0.  (gloo: the ranks share this box's one GPU.)"""
-    env = dict(os.environ, BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+    from tests.test_gpu_gather_peers import build_fake_rccl
+
+    env = dict(os.environ, BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", BGS_RCCL_LIB=build_fake_rccl())
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "20", "--warmup", "2",
@@ -523,6 +536,9 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["config"]["gathered_rewards_verified"] is True and d["config"]["gather"] == "shm"
+    # the default N > 1 run measures both hand-overs, each verified on its own
+    assert d["config"]["gathers_measured"] == ["shm", "rccl"]
+    assert d["gather_shm"]["gathered_rewards_verified"] is True and d["gather_rccl"]["gathered_rewards_verified"] is True
     assert d["config"]["global_batch"] == 3 << 16 and d["value"] > 0 and d["steps"] == 20
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
 
@@ -542,7 +558,7 @@ def test_bench_sharded_path_with_one_rank_over_rccl(gather):
     assert proc.returncode == 0, proc.stderr[-3000:]
     d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["gathered_rewards_verified"] is True and d["config"]["gather"] == gather
-    assert ("RCCL gather (in-library" in d["config"]["sharding"]) == (gather == "rccl")
+    assert ("RCCL gather inside the library" in d["config"]["sharding"]) == (gather == "rccl")
     assert d["config"]["rewards_to_host"] is True and d["value"] > 0
     assert d["config"]["loop"].startswith("native")
 

@@ -225,10 +225,13 @@ print("GATHER_OK", os.environ.get("BGS_GATHER_DIRECT", "0"))
 
 @pytest.mark.parametrize("direct", ["0", "1"])
 def test_in_library_rccl_gather_with_one_rank(direct):
-    """bgs_gather_* over the real RCCL with a world of one rank: persistent communicator (ncclCommInitRank), the
-    communication thread's send / receive group per step, rank 0's sink -- through the native loop and by single calls.
-    direct=1: the receives land straight in the sink's device-mapped slot.  (Child process under `timeout`: a collective
-    that does not complete must not take the test session along.)"""
+    """bgs_gather_* over the real RCCL library with a world of ONE rank -- all that RCCL itself allows on a one-GPU box.
+    What this runs: librccl loads, ncclGetUniqueId / ncclCommInitRank succeed, and the gather's one-rank form -- no
+    communication thread, no send and no receive (there is no peer): a step is the sink's bgs_sink_rollout -- delivers
+    every step through the native loop and by single calls; a short destination is refused.  The sends, receives, groups
+    and the direct / copy receive modes run with peers in tests/test_gpu_gather_peers.py (over the tests' stand-in
+    transport); BGS_GATHER_DIRECT is passed through here only to show that it is harmless with one rank.  (Child
+    process under `timeout`: a collective that does not complete must not take the test session along.)"""
     import socket
 
     with socket.socket() as s:

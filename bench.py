@@ -640,6 +640,14 @@ def main() -> int:
                 ring = SharedRewardRing(dist, n, host_slots)
             except RuntimeError as exc:  # raised on every rank or on none
                 return {"error": str(exc)}
+        # the ranks' meeting point around a timed region: words of a shared segment (microseconds), for every hand-over of a
+        # node's ranks -- the gather gets a one-page ring of its own for that
+        meet = ring
+        if lib_gather and dist is not None:
+            try:
+                meet = SharedRewardRing(dist, 4, 1)
+            except RuntimeError:
+                meet = None
         rows = world * n if lib_gather else n
         host_rewards = []
         if handover == "codes":
@@ -661,10 +669,10 @@ def main() -> int:
 
         def barrier():
             torch.cuda.synchronize()
-            if ring is not None:
+            if meet is not None:
                 # the ranks of a node meet on words of the shared segment within microseconds; a barrier collective is a
                 # launch + a kernel + a synchronise on every rank, tens of microseconds of a 0.7 ms region -- twice
-                ring.barrier()
+                meet.barrier()
             elif dist is not None:
                 dist.barrier()
                 torch.cuda.synchronize()
@@ -778,6 +786,8 @@ def main() -> int:
             sink.close()
         if ring is not None:
             ring.close()
+        elif meet is not None:
+            meet.close()
         return result
 
     def sharding_text(res):

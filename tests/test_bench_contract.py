@@ -77,6 +77,26 @@ def test_sharded_loops_with_one_rank_over_rccl_are_within_reach_of_the_plain_loo
     assert typical(shm) > 0.95 * typical(plain) and typical(rccl) > 0.65 * typical(shm)
 
 
+def test_round4_gather_machinery_is_off_the_step():
+    """Round 4: one run measures BOTH hand-overs of the N > 1 path (`--gather both`); over the real RCCL library with a
+    one-rank world the in-library gather -- whose machinery is now per group of steps, and absent when there is no peer --
+    stays within 5 % of the shared host array (round 3: 0.66-0.88), at 200 and at 20 steps; with three ranks sharing the GPU
+    over the tests' stand-in transport both hand-overs verify every rank's rows."""
+    typical = lambda values: sorted(values)[1]
+    for name in ("r04_dist_one_rank.json", "r04_dist_one_rank_steps20.json"):
+        d = _line(name)
+        assert d["config"]["gathers_measured"] == ["shm", "rccl"] and d["config"]["gather"] == "shm"
+        shm, rccl = d["gather_shm"], d["gather_rccl"]
+        assert shm["gathered_rewards_verified"] is True and rccl["gathered_rewards_verified"] is True
+        assert rccl["gather_info"]["transport"].startswith("librccl") and rccl["gather_info"]["transport_check"] == "none"
+        assert typical(rccl["values_of_3"]) > 0.95 * typical(shm["values_of_3"]), name
+    d = _line("r04_dist_three_ranks_standin.json")
+    assert d["n_gpus"] == 3 and d["gather_shm"]["gathered_rewards_verified"] is True
+    rccl = d["gather_rccl"]
+    assert rccl["gathered_rewards_verified"] is True and "libfake_rccl" in rccl["gather_info"]["transport"]
+    assert rccl["gather_info"]["transport_check"] == "passed" and rccl["gather_info"]["direct"] is False
+
+
 def test_bench_starts_ranks_itself_and_relays_their_failure():
     """`python bench.py --gpus 2` with no launcher: two child ranks are started (before the parent touches any GPU API);
     without a GPU each of them refuses, and the parent relays that as its own exit code and prints no line."""

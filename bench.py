@@ -282,6 +282,33 @@ def committed_counters(build_id, stem, kernel_substring=None):
     return None, f"no counters for build {build_id} ({'; '.join(seen) or 'no file'}): not quoted"
 
 
+def busy_block(build_id, case):
+    """Hardware busy counters of the rollout kernel (profiles/r*_valu_busy.json, tools/busy_counters.sh), for the build
+    that is running: how full the vector issue pipe is by the chip's own counters, next to the instruction-rate fraction."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_busy.json")), reverse=True)
+    for path in files:
+        with open(path) as fh:
+            c = json.load(fh)
+        if c.get("build_id") != build_id or case not in c.get("cases", {}):
+            continue
+        entry = c["cases"][case]
+        k = next(iter(entry["kernels"].values()))
+        d = k.get("derived") or {}
+        return {
+            "valu_busy_frac": d.get("valu_busy_frac"),
+            "frac_of_quad_cycles_with_two_valu_issued": d.get("frac_of_quads_with_two_valu_issued"),
+            "wave_time_split": d.get("wave_time_split"),
+            "waves_resident_per_simd": d.get("waves_resident_per_simd"),
+            "counted_as": entry["what"],
+            "counters_file": os.path.basename(path),
+            "basis": "rocprofv3 PMC: valu_busy_frac = SQ_ACTIVE_INST_VALU (quad-cycles with a VALU instruction in the pipe, summed "
+                     "over the chip) / (1024 SIMDs x the dispatch's quad-cycles from GRBM_GUI_ACTIVE) -- rocprofv3's VALUBusy; 1.0 = "
+                     "every SIMD starts one wave64 VALU instruction per quad-cycle.  The guide's issue peak (`peak`) is TWO per "
+                     "quad-cycle; SQ_ACTIVE_INST_VALU2 says how often the chip managed that on this instruction stream",
+        }
+    return None
+
+
 def valu_issue_block(counters, why_not, seconds_per_launch, build):
     if not counters or not counters.get("valu_wave_instructions_per_launch") or not seconds_per_launch:
         return {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_SIMD32, "unit": "Ginstr/s", "frac": None,
@@ -397,6 +424,7 @@ def run_other_config(name: str, steps: int) -> int:
         "parity_with_oracle": parity,
         "parity_sample": f"host rewards of the last timed step vs the CPU oracle, first {head} games, seed 0x{last_seed:016X}",
         "valu_issue": valu_issue_block(counters, why_not, ms * 1e-3, build),
+        "valu_busy": busy_block(build, {"connect_12x13x5": "k2c_8deep", "bounce_default": "k3p_8x"}[name]),
         "algorithmic": {"bytes_per_env_step": bytes_per_step, "GBps": value * bytes_per_step / 1e9,
                         "frac_of_hbm_peak": value * bytes_per_step / 1e9 / HBM_PEAK_GBS,
                         "note": "SURVEY 8d's per-ply byte model: a register/LDS-resident rollout does not move these bytes"},
@@ -836,6 +864,10 @@ def main() -> int:
         roof["kernel_ms_per_launch"] = kernel_ms
         roof["event_pairs"] = len(range(0, args.steps, stride))
         roof["launches_in_flight"] = depth
+        busy = busy_block(build, "k2o_3deep") if n == BATCH_PER_GPU and depth == 3 else None
+        if busy is not None:
+            roof["valu_busy"] = busy
+            roof["valu_busy_frac"] = busy["valu_busy_frac"]
         stored = STORED_BYTES_PER_GAME * n  # by construction: every game is written exactly once, when it ends
         moved = counters["hbm_bytes_per_launch"] if counters and counters.get("hbm_bytes_per_launch") else stored
         if kernel_ms:

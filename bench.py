@@ -563,9 +563,8 @@ def main() -> int:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         return launch_ranks(args.gpus)  # (before anything here has touched the GPU)
 
-    from simulator.game import _abi  # (first: asks for more hardware queues before torch brings the HIP runtime up)
+    from simulator.game import _abi
 
-    _abi._more_hardware_queues()
     import numpy as np
     import torch
 

@@ -45,7 +45,7 @@ constexpr size_t kStepBytes = (size_t)BGS_STEP_SHARDS * BGS_STEP_STRIDE * sizeof
 inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 struct Layout {
-    size_t planes, status, plies, reward, steps, worklist, work_count, gen_masks, gen_cfg, staging, total, staging_bytes;
+    size_t planes, status, plies, reward, steps, worklist, work_count, pool, gen_masks, gen_cfg, staging, total, staging_bytes;
 };
 
 // planes > 0: bit-packed boards (planes x uint64 per board); planes == 0: the generic layout, int8[n][h][w] in the same
@@ -62,6 +62,8 @@ Layout layout_for(int planes, int64_t n, int h, int w, size_t legal_bytes = 0) {
     l.steps = off; off += align_up(kStepBytes);
     l.worklist = off; off += align_up((size_t)n * 4);
     l.work_count = off; off += align_up(sizeof(uint32_t) * 2 * BGS_BOUNCE_MAX_PASSES);
+    // packed Bounce boards: the piece-list rollout's device-wide pool of parked boards (counters + entries, bgs_internal.h)
+    l.pool = off; off += planes == 4 ? align_up(sizeof(uint32_t) * BGS_BOUNCE_POOL_WORDS) : 0;
     l.gen_masks = off; off += align_up(sizeof(uint64_t) * 6 * (BGS_GENERIC_BOUNCE_MAX_CELLS / 64));
     l.gen_cfg = off; off += align_up((size_t)h * w);
     size_t per_board = (size_t)h * w;
@@ -172,6 +174,7 @@ int carve(bgs_batch* b, void* arena, size_t arena_bytes, const Layout& l) {
     b->d_steps = reinterpret_cast<unsigned long long*>(base + l.steps);
     b->d_worklist = reinterpret_cast<uint32_t*>(base + l.worklist);
     b->d_work_count = reinterpret_cast<uint32_t*>(base + l.work_count);
+    b->d_pool = reinterpret_cast<uint32_t*>(base + l.pool);
     b->d_gen_masks = reinterpret_cast<uint64_t*>(base + l.gen_masks);
     b->d_gen_cfg = reinterpret_cast<int8_t*>(base + l.gen_cfg);
     b->d_staging = base + l.staging;
@@ -292,6 +295,8 @@ int device_facts(bgs_batch* b) {
     if (const char* env = getenv("BGS_BOUNCE_PIECES")) b->bounce_pieces = atoi(env) != 0;
     b->bounce_block = 256;
     if (const char* env = getenv("BGS_BOUNCE_BLOCK")) b->bounce_block = atoi(env);
+    b->bounce_pool = 1;
+    if (const char* env = getenv("BGS_BOUNCE_POOL")) b->bounce_pool = atoi(env) != 0;
     b->bounce_flat_chunk = 32;
     if (const char* env = getenv("BGS_BOUNCE_CHUNK")) {
         const int v = atoi(env);
@@ -304,6 +309,11 @@ int device_facts(bgs_batch* b) {
     }
     b->launches_in_flight = 1;
     b->bounce_flat_waves = 0;
+    b->bounce_pieces_park = getenv("BGS_BOUNCE_PARK") ? b->bounce_park : kBouncePiecesPark;
+    if (const char* env = getenv("BGS_BOUNCE_PIECES_PARK")) {
+        const int v = atoi(env);
+        if (v >= 0 && v <= 63) b->bounce_pieces_park = v;
+    }
     if (const char* env = getenv("BGS_BOUNCE_FLAT_WAVES")) {
         const int v = atoi(env);
         if (v >= 1 && v <= (1 << 16)) b->bounce_flat_waves = v;

@@ -19,6 +19,8 @@ enum {
     BGS_BOUNCE_MAX_VALUE = 15,   // 4 value bit-planes
     BGS_BOUNCE_MAX_PASSES = 8,   // passes of the multi-pass Bounce rollout
     BGS_BOUNCE_MAX_PIECES = 16,  // piece-list rollout kernel (K3p): pieces on the configured start position
+    BGS_BOUNCE_POOL_GROUPS = 2048,  // K3p: workgroups of a launch that can park boards in the device-wide pool
+    BGS_BOUNCE_POOL_WORDS = 4 + 2 * 2048 + 2048 * 64 * 6,  // dwords: counters, per-group count / head, 64 entries of 6 dwords a group
     // the generic (reference-layout) kernels take over beyond the packed limits
     BGS_GENERIC_CONNECT_MAX_DIM = 64,      // height, width <= 64 (the oracle's own limit: nothing larger can be checked)
     BGS_GENERIC_BOUNCE_MAX_CELLS = 1024,   // height * width <= 1024, piece values <= 127 (int8)
@@ -54,6 +56,7 @@ struct BounceGeom {
 constexpr int kRolloutOpeningBlocks = 3;    // K2o: 4-ply blocks played in lock step before a board joins the refill loop
 constexpr int kGamesPerLaneOneWord = 8;     // one-word Connect boards: games per lane a launch aims for (512 per wave at 2^20)
 constexpr int kGamesPerLane = 4;            // every other rollout
+constexpr int kBouncePiecesPark = 40;       // K3p with the device-wide pool: 32 / 40 / 48 / 56 / 63 read 11.8 / 12.2 / 11.9 / 11.8 / 3.0 x 10^9 with 20 in flight
 constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBoards (0 = every wave drains alone)
 // K3p, automatic plan: the shape of a launch follows the number of launches the caller keeps in flight on the device
 // (bgs_set_launches_in_flight; the rollout executor passes its depth).  tail_cap: games longer than this are finished
@@ -94,6 +97,8 @@ struct bgs_batch {
     int bounce_block;        // K3p: threads per workgroup, 256 / 512 / 1024 (BGS_BOUNCE_BLOCK): the waves of a workgroup share their drain
     int bounce_flat_wps;     // waves per SIMD of a flat Bounce rollout launch (BGS_BOUNCE_FLAT_WPS)
     int bounce_flat_waves;   // > 0: that many waves per launch instead (BGS_BOUNCE_FLAT_WAVES)
+    int bounce_pool;         // K3p: the last wave of a workgroup parks its boards for other workgroups (BGS_BOUNCE_POOL=0: off)
+    int bounce_pieces_park;  // K3p: a draining wave parks its boards at this many or fewer (0..63; BGS_BOUNCE_PIECES_PARK, default: BGS_BOUNCE_PARK)
     int bounce_park;         // flat rollout: a draining wave parks its boards for its workgroup at this many or fewer (0..32; BGS_BOUNCE_PARK)
     int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (BGS_BOUNCE_CHUNK)
     int launches_in_flight;  // the caller's hint (bgs_set_launches_in_flight), 1 = one launch at a time: see bounce_shape()
@@ -120,6 +125,7 @@ struct bgs_batch {
     int8_t* d_gen_cfg;       // generic Bounce: the configured start grid
     uint32_t* d_worklist;    // [n] board indices still to play (Bounce multi-pass rollout)
     uint32_t* d_work_count;  // [2 * BGS_BOUNCE_MAX_PASSES] list lengths, then work-queue heads; device-resident
+    uint32_t* d_pool;        // packed Bounce: [BGS_BOUNCE_POOL_WORDS] the piece-list rollout's device-wide pool of parked boards
     // pinned bounce buffers for large device -> host copies (allocated on first use)
     void* pinned[2];
     hipEvent_t pinned_done[2];

@@ -1,9 +1,9 @@
-"""Drop-in `simulator` package backed by libbgs.so (HIP kernels for gfx950); see include/bgs.h and DESIGN.md."""
+"""Drop-in `simulator` package backed by libbgs.so (HIP kernels for gfx950); see include/bgs.h and DESIGN.md.
 
-__version__ = "0.0.6+mi355x.1"
+Importing the package changes nothing in the process: in particular it does not touch GPU_MAX_HW_QUEUES (round 3 did,
+for every HIP user of the process).  Pipelines deeper than the HIP runtime's 4 default hardware queues ask for more
+themselves, when they are built (`simulator.pipeline.request_hardware_queues`)."""
+
+__version__ = "0.0.6+mi355x.2"
 
 from .game import _abi as _abi
-
-# more than the HIP runtime's default 4 hardware queues, asked for while the runtime has not read the variable yet
-# (simulator.game._abi._more_hardware_queues; pipelines with more than 4 batches in flight need them)
-_abi._more_hardware_queues()

@@ -199,23 +199,20 @@ def _one_hip_runtime_per_process() -> None:
         ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
 
 
-HW_QUEUES_WANTED = 32
-hw_queues_too_late = False  # True: HIP was initialised with the default 4 hardware queues before this module could ask for more
+HW_QUEUES_WANTED = 24   # (16 / 20 / 24 / 28 / 32 Bounce batches in flight: 10.1 / 11.0 / 10.1 / 7.9 / 5.9 x 10^9 -- beyond 24 the queues thrash)
 
 
-def _more_hardware_queues() -> None:
+def request_hardware_queues(wanted: int = HW_QUEUES_WANTED) -> int:
     """The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues -- 4 by default -- and reads
-    the variable once, when it initialises: beyond 4 batches in flight nothing overlaps until it is raised (the Bounce
-    rollouts want 16 batches in flight on 32 queues: 5x one launch at a time; Connect's 3 are unaffected either way,
-    measured).  Ask for more while that is still possible; remember when it is not, so that `RolloutPipeline` can refuse
-    a depth it cannot deliver instead of silently running 4 wide."""
-    global hw_queues_too_late
-    if "GPU_MAX_HW_QUEUES" in os.environ:
-        return
-    if _gpu_runtime_is_up():
-        hw_queues_too_late = True
-    else:
-        os.environ["GPU_MAX_HW_QUEUES"] = str(HW_QUEUES_WANTED)
+    the variable once, when it initialises: beyond 4 batches in flight nothing overlaps until it is raised (Bounce
+    rollouts want 20 batches in flight: 9x one launch at a time; Connect's 3 are unaffected either way, measured).
+    OPT-IN: called by `RolloutPipeline` / `RolloutExecutor` users and bench.py when they need more than 4, never by
+    importing the package -- the setting is process-wide and other HIP users of the process (torch) see it too.
+    Returns the number of hardware queues this process has, or will have: `wanted` if the variable could still be set (or
+    was already set by the user to at least that), else what the runtime came up with."""
+    if "GPU_MAX_HW_QUEUES" not in os.environ and not _gpu_runtime_is_up():
+        os.environ["GPU_MAX_HW_QUEUES"] = str(int(wanted))
+    return hardware_queues()
 
 
 def _gpu_runtime_is_up() -> bool:
@@ -237,21 +234,31 @@ def _gpu_runtime_is_up() -> bool:
         return False
 
 
+_queues_at_start = None   # what the runtime came up with, once known
+
+
 def hardware_queues() -> int:
-    """Hardware queues this process's streams can spread over (what the HIP runtime was, or will be, initialised with)."""
-    if hw_queues_too_late:
-        return 4
+    """Hardware queues this process's streams can spread over: what the HIP runtime was initialised with (4 unless
+    GPU_MAX_HW_QUEUES said otherwise at that moment), or will be initialised with."""
+    global _queues_at_start
+    if _queues_at_start is not None:
+        return _queues_at_start
     try:
-        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        now = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
     except ValueError:
-        return 4
+        now = 4
+    if _gpu_runtime_is_up():
+        # the runtime has read the variable; a later change of the environment does not count.  (If somebody changed
+        # it between the runtime's start and this first look, the figure is optimistic: nothing here can tell.)
+        _queues_at_start = now
+    return now
 
 
 def lib() -> ctypes.CDLL:
     """Load libbgs.so; fail loudly when it is absent (build it with `python __graft_entry__.py`)."""
     global _lib
     if _lib is None:
-        _more_hardware_queues()
+        hardware_queues()   # (notes what the runtime has, if it is up already; changes nothing)
         _one_hip_runtime_per_process()
         if not os.path.exists(LIB_PATH):
             raise ImportError(

@@ -40,6 +40,12 @@ class RolloutExecutor:
         if sink is not None and gather is not None:
             raise ValueError("hand over through a sink OR a gather")
         self.batches, self.sink, self.gather = list(batches), sink, gather
+        if len(self.batches) > 4 and _abi.hardware_queues() < len(self.batches):
+            import warnings
+
+            warnings.warn(f"RolloutExecutor: {len(self.batches)} batches in flight on {_abi.hardware_queues()} hardware queues: the HIP "
+                          "runtime runs at most that many streams side by side (simulator.pipeline.request_hardware_queues() before "
+                          "the first HIP call asks for more)", RuntimeWarning, stacklevel=2)
         self.host = list(host_arrays)  # (kept alive: worker threads write them after enqueue() has returned)
         n_games = self.batches[0].n * (gather.world if gather is not None else 1)
         ptrs = (ctypes.c_void_p * max(len(self.host), 1))()
@@ -134,14 +140,32 @@ def default_depth(batch_cls, config_args: tuple = ()) -> int:
     return 3
 
 
-def check_depth(depth: int) -> None:
+def request_hardware_queues(wanted: int = _abi.HW_QUEUES_WANTED) -> int:
+    """Ask for `wanted` hardware queues while the HIP runtime has not started (see `_abi.request_hardware_queues`: opt-in,
+    process-wide); returns what the process has or will have."""
+    return _abi.request_hardware_queues(wanted)
+
+
+def usable_depth(depth: int, explicit: bool, what: str = "RolloutPipeline") -> int:
     """More than 4 batches in flight need more than the HIP runtime's default 4 hardware queues, and the runtime reads
-    GPU_MAX_HW_QUEUES only once, when it initialises: fail loudly when that moment has passed."""
-    if depth > 4 and _abi.hardware_queues() < depth:
-        raise RuntimeError(
-            f"{depth} batches in flight need GPU_MAX_HW_QUEUES >= {depth} (this process has {_abi.hardware_queues()}): the HIP "
-            "runtime was initialised before `simulator` could ask for more. Import `simulator` (or set GPU_MAX_HW_QUEUES=32) "
-            "before the first torch.cuda / HIP call, or pass depth <= 4.")
+    GPU_MAX_HW_QUEUES only once, when it initialises.  Ask for them if that is still possible; if the moment has passed, a
+    depth the CALLER chose raises (it cannot be delivered), a DEFAULT depth falls back to what the process has, with a
+    warning (round-3 advisor: a default-constructed pipeline must not start failing with the import order)."""
+    if depth <= 4:
+        return depth
+    have = request_hardware_queues(max(_abi.HW_QUEUES_WANTED, depth))
+    if have >= depth:
+        return depth
+    hint = ("call simulator.pipeline.request_hardware_queues() (or set GPU_MAX_HW_QUEUES) before the first torch.cuda / HIP call")
+    if explicit:
+        raise RuntimeError(f"{what}: {depth} batches in flight need GPU_MAX_HW_QUEUES >= {depth}, this process has {have}: the HIP "
+                           f"runtime was initialised before more could be asked for; {hint}, or pass depth <= {max(have, 4)}.")
+    import warnings
+
+    warnings.warn(f"{what}: the default of {depth} batches in flight needs {depth} hardware queues, this process has {have} "
+                  f"(the HIP runtime was up already); running {max(have, 4)} deep instead -- {hint} for the full depth.",
+                  RuntimeWarning, stacklevel=3)
+    return max(have, 4)
 
 
 class RolloutPipeline:
@@ -151,15 +175,16 @@ class RolloutPipeline:
         (default: `default_depth(batch_cls, config_args)` -- 3 for one-word Connect boards, 8 for larger ones, 20 for Bounce).
         `host_arrays`: optional list of arrays_per_stream * depth C-contiguous int8[n, 2] destinations (e.g. rows of a shared array,
         `SharedRewardRing.mine(slot)`); by default the pipeline allocates (and pre-faults) its own."""
-        _abi.lib()  # (asks for more hardware queues while that is still possible: before torch touches the GPU)
-        import torch
-
+        explicit = depth is not None
         if depth is None:
             depth = default_depth(batch_cls, config_args)
-            arrays_per_stream = min(arrays_per_stream, max(1, 48 // depth))
         if depth < 1:
             raise ValueError("depth must be >= 1")
-        check_depth(depth)
+        depth = usable_depth(depth, explicit)   # (before torch touches the GPU: the queues can still be asked for)
+        if not explicit:
+            arrays_per_stream = min(arrays_per_stream, max(1, 48 // depth))
+        import torch
+
         self.n, self.depth, self.max_plies = int(n), int(depth), int(max_plies)
         self._torch = torch
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]

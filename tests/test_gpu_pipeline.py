@@ -305,23 +305,32 @@ def test_grid_sink_delivers_the_boards_of_every_step(case):
 
 def test_rollout_pipeline_refuses_a_depth_it_cannot_deliver():
     """More than 4 batches in flight need more than the HIP runtime's default 4 hardware queues, which can only be asked
-    for before the runtime comes up: a process that initialised HIP first gets a loud error for depth 16, not 4-wide
-    execution; importing `simulator` first (what every other test process does) makes the default Bounce depth work."""
+    for before the runtime comes up.  Importing `simulator` asks for nothing (it used to set GPU_MAX_HW_QUEUES for the
+    whole process); a pipeline asks when it is built.  A process that initialised HIP first: an EXPLICIT depth of 16 is
+    refused loudly, the DEFAULT Bounce depth falls back to 4 with a warning; a process that builds the pipeline first
+    gets the full default depth."""
     code_late = (
-        "import sys, os; sys.path[:0] = [%r, %r]\n"
+        "import sys, os, warnings; sys.path[:0] = [%r, %r]\n"
         "os.environ.pop('GPU_MAX_HW_QUEUES', None)\n"
+        "import simulator\n"
+        "assert 'GPU_MAX_HW_QUEUES' not in os.environ\n"             # the import leaves the process alone
         "import torch; assert torch.cuda.is_available()\n"          # the HIP runtime is up, with 4 queues
         "import numpy as np\n"
         "from simulator.batch import BounceBatch\n"
-        "from simulator.pipeline import RolloutPipeline\n"
+        "from simulator.pipeline import RolloutPipeline, request_hardware_queues\n"
         "from simulator.game import _abi\n"
-        "assert _abi.hw_queues_too_late and _abi.hardware_queues() == 4\n"
+        "assert request_hardware_queues() == 4 and _abi.hardware_queues() == 4 and 'GPU_MAX_HW_QUEUES' not in os.environ\n"
         "g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]\n"
         "try:\n"
-        "    RolloutPipeline(BounceBatch, (g,), 512)\n"
+        "    RolloutPipeline(BounceBatch, (g,), 512, depth=16)\n"
         "    raise SystemExit('depth 16 on 4 hardware queues was accepted')\n"
         "except RuntimeError as exc:\n"
         "    assert 'GPU_MAX_HW_QUEUES' in str(exc)\n"
+        "with warnings.catch_warnings(record=True) as seen:\n"
+        "    warnings.simplefilter('always')\n"
+        "    with RolloutPipeline(BounceBatch, (g,), 512, max_plies=200) as pipe:\n"
+        "        assert pipe.depth == 4 and len(list(pipe.run(range(6)))) == 6\n"
+        "assert any('hardware queues' in str(w.message) for w in seen), [str(w.message) for w in seen]\n"
         "with RolloutPipeline(BounceBatch, (g,), 512, depth=3, max_plies=200) as pipe:\n"
         "    assert len(list(pipe.run(range(4)))) == 4\n"
         "print('LATE_OK')\n" % (ROOT, PKG))
@@ -329,13 +338,14 @@ def test_rollout_pipeline_refuses_a_depth_it_cannot_deliver():
         "import sys, os; sys.path[:0] = [%r, %r]\n"
         "os.environ.pop('GPU_MAX_HW_QUEUES', None)\n"
         "import numpy as np\n"
-        "import simulator\n"                                          # asks for 32 queues before anything touches the GPU
+        "import simulator\n"
         "from simulator.batch import BounceBatch\n"
         "from simulator.pipeline import RolloutPipeline\n"
         "from simulator.game import _abi\n"
-        "assert os.environ['GPU_MAX_HW_QUEUES'] == '32' and not _abi.hw_queues_too_late\n"
+        "assert 'GPU_MAX_HW_QUEUES' not in os.environ\n"
         "g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]\n"
-        "with RolloutPipeline(BounceBatch, (g,), 512, max_plies=200) as pipe:\n"
+        "with RolloutPipeline(BounceBatch, (g,), 512, max_plies=200) as pipe:\n"   # asks for the queues itself, in time
+        "    assert os.environ['GPU_MAX_HW_QUEUES'] == '24' and _abi.hardware_queues() == 24\n"
         "    assert pipe.depth == 20 and len(list(pipe.run(range(24)))) == 24\n"
         "print('EARLY_OK')\n" % (ROOT, PKG))
     for code, word in ((code_late, "LATE_OK"), (code_early, "EARLY_OK")):

@@ -12,7 +12,7 @@ from simulator.batch import BounceBatch
 g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 16
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 150
-KEYS = ("BGS_BOUNCE_GROUP", "BGS_BOUNCE_PIECES", "BGS_BOUNCE_PLAN", "BGS_BOUNCE_PARK", "BGS_BOUNCE_FLAT_WAVES")
+KEYS = ("BGS_BOUNCE_GROUP", "BGS_BOUNCE_PIECES", "BGS_BOUNCE_PLAN", "BGS_BOUNCE_PARK", "BGS_BOUNCE_FLAT_WAVES", "BGS_BOUNCE_POOL")
 
 def make(**env):
     for k in KEYS:
@@ -24,7 +24,11 @@ def make(**env):
 ref = make(BGS_BOUNCE_PIECES=0, BGS_BOUNCE_PLAN="single", BGS_BOUNCE_PARK=0)
 variants = {"K3p default (bulk + tail)": make(), "K3p single launch": make(BGS_BOUNCE_PLAN="single"),
             "K3p 64 waves": make(BGS_BOUNCE_FLAT_WAVES=64), "K3p park 5 / 300 waves": make(BGS_BOUNCE_PARK=5, BGS_BOUNCE_FLAT_WAVES=300),
-            "K3p tail at 96": make(BGS_BOUNCE_PLAN="96:1,0:8")}
+            "K3p tail at 96": make(BGS_BOUNCE_PLAN="96:1,0:8"),
+            # round 4: the device-wide pool of parked boards is on by default (every variant above); off, and in the shapes that
+            # stress it: many small workgroups' worth of waves, a parking threshold of 32 and of 3
+            "K3p no device-wide pool": make(BGS_BOUNCE_POOL=0), "K3p pool, 1024 waves, park 32": make(BGS_BOUNCE_FLAT_WAVES=1024, BGS_BOUNCE_PARK=32),
+            "K3p pool, 128 waves, park 3, single launch": make(BGS_BOUNCE_FLAT_WAVES=128, BGS_BOUNCE_PARK=3, BGS_BOUNCE_PLAN="single")}
 # the launch shapes of bounce_shape(): one launch at a time (the default above), 8 and 16 in flight
 for hint in (8, 16):
     variants[f"K3p shape of {hint} in flight"] = make()

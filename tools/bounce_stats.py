@@ -10,6 +10,8 @@ from simulator.game import _abi
 g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]
 n = 1 << 18
 b = BounceBatch(g, n, use_torch=True)
+if os.environ.get("HINT"):
+    b.set_launches_in_flight(int(os.environ["HINT"]))   # the launch shape of that many launches in flight
 out = []
 for i in range(3):
     b.reset_steps()

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
 import numpy as np
 from simulator.game import _abi
-_abi._more_hardware_queues()
+_abi.request_hardware_queues()
 import torch
 if os.environ.get("BGS_SCHEDULE_SPIN"):  # (experiment: synchronising calls spin instead of sleeping on an interrupt)
     import ctypes

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Parametrised sweeps on the GPU box (round 4: one script instead of a directory of one-off shell loops).
+
+    python3 tools/sweep.py bounce-block   [--reps N]     K3p workgroup size (BGS_BOUNCE_BLOCK) x parking threshold, 20 in flight
+    python3 tools/sweep.py bounce-park    [--reps N]     K3p parking threshold (BGS_BOUNCE_PIECES_PARK) with / without the device-wide pool
+    python3 tools/sweep.py bounce-tail    [--reps N]     ply cap of the bulk pass (BGS_BOUNCE_PLAN) x parking threshold, 20 in flight
+    python3 tools/sweep.py bounce-depth   [--reps N]     Bounce batches in flight (8 .. 28) with the default launch shape
+    python3 tools/sweep.py k2c-depth      [--reps N]     Connect(12,13,5) batches in flight (1 .. 12)
+    python3 tools/sweep.py headline-depth [--reps N]     Connect4(6,7,4) batches in flight (1 .. 8)
+Every point is a child process (the library reads its knobs when a batch is created; GPU_MAX_HW_QUEUES when HIP starts);
+prints one line per point and a JSON summary."""
+import argparse, json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RATE = os.path.join(ROOT, "tools", "rollout_rate.py")
+
+
+def point(config, depth, reps, env=None, extra=()):
+    e = dict(os.environ, **{k: str(v) for k, v in (env or {}).items()})
+    out = subprocess.run([sys.executable, RATE, config, "--depth", str(depth), "--reps", str(reps), *extra], env=e, capture_output=True, text=True)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return {"error": out.stderr.strip()[-300:]}
+    d = json.loads(lines[-1])
+    return {"solo": d["one_launch_at_a_time"]["env_steps_per_s"], "pipelined": d[f"{depth}_in_flight"]["env_steps_per_s"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=("bounce-block", "bounce-park", "bounce-tail", "bounce-depth", "k2c-depth", "headline-depth"))
+    ap.add_argument("--reps", type=int, default=0)
+    args = ap.parse_args()
+    rows = []
+    if args.what == "bounce-block":
+        for block in (256, 512, 1024):
+            for park in (16, 32):
+                r = point("bounce", 20, args.reps or 120, {"BGS_BOUNCE_BLOCK": block, "BGS_BOUNCE_PARK": park})
+                rows.append(dict({"block": block, "park": park}, **r))
+                print(rows[-1], flush=True)
+    elif args.what == "bounce-park":
+        for pool in (1, 0):
+            for park in ((32, 40, 48, 56, 63) if pool else (32, 48, 63)):
+                r = point("bounce", 20, args.reps or 120, {"BGS_BOUNCE_POOL": pool, "BGS_BOUNCE_PIECES_PARK": park})
+                rows.append(dict({"pool": pool, "park": park}, **r))
+                print(rows[-1], flush=True)
+    elif args.what == "bounce-tail":
+        for plan in ("auto", "128:1,0:8", "160:1,0:8", "224:1,0:8", "320:1,0:8", "512:1,0:8"):
+            for park in (36, 44):
+                env = {"BGS_BOUNCE_PIECES_PARK": park}
+                if plan != "auto":
+                    env["BGS_BOUNCE_PLAN"] = plan
+                rows.append(dict({"plan": plan, "park": park}, **point("bounce", 20, args.reps or 120, env)))
+                print(rows[-1], flush=True)
+    elif args.what == "bounce-depth":
+        for depth in (8, 12, 16, 20, 24, 28):
+            rows.append(dict({"depth": depth}, **point("bounce", depth, args.reps or 6 * depth)))
+            print(rows[-1], flush=True)
+    elif args.what == "k2c-depth":
+        for depth in (1, 2, 3, 4, 6, 8, 12):
+            rows.append(dict({"depth": depth}, **point("connect12x13", depth, args.reps or 40 * depth)))
+            print(rows[-1], flush=True)
+    else:
+        for depth in (1, 2, 3, 4, 6, 8):
+            rows.append(dict({"depth": depth}, **point("connect6x7", depth, args.reps or 60 * depth, {"BGS_ROLLOUT_WPS": 2})))
+            print(rows[-1], flush=True)
+    print(json.dumps({"sweep": args.what, "rows": rows}))
+
+
+if __name__ == "__main__":
+    main()

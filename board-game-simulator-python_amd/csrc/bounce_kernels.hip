@@ -354,17 +354,25 @@ __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                  uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
                  unsigned long long* __restrict__ steps, uint32_t games_per_wave, const uint32_t* __restrict__ worklist,
-                 const uint32_t* __restrict__ work_count) {
+                 const uint32_t* __restrict__ work_count, uint32_t* __restrict__ queue) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
     // A work list is the tail of a multi-pass rollout: a handful of very long games, each a chain of thousands of
     // dependent plies, and the launch ends when the longest is through.  Their waves go first in the SIMD's issue
     // arbitration: next to 16 batches' bulk waves a ply of theirs otherwise takes 2-3x as long as on an idle chip.
     if (worklist) __builtin_amdgcn_s_setprio(3);
     const int64_t total = worklist ? (int64_t)*work_count : n;
-    const int64_t begin = (int64_t)wave * games_per_wave;
-    const int64_t end = begin + games_per_wave < total ? begin + games_per_wave : total;
-    const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
-    if (avail == 0u) return;  // (whole wave; nothing to count)
+    // The whole batch: a wave owns the boards [wave, wave + 1) x games_per_wave.  A work list: its length is only known on
+    // the device, so the grid is a fixed, modest number of waves and every wave DRAWS chunks of the list from a queue
+    // until it is dry (round 3 launched one wave per 8 boards of the whole batch, 32768 waves for 2^18 boards, of which
+    // a hundred had work: their prologues were 1.9 x 10^7 of a step's 4 x 10^8 instructions, at 7 lanes).
+    int64_t begin = worklist ? 0 : (int64_t)wave * games_per_wave;
+    uint32_t avail = 0;
+    bool dry = worklist == nullptr;   // nothing (more) to draw
+    if (!worklist) {
+        const int64_t end = begin + games_per_wave < total ? begin + games_per_wave : total;
+        avail = begin < end ? (uint32_t)(end - begin) : 0u;
+        if (avail == 0u) return;  // (whole wave; nothing to count)
+    }
     uint32_t taken = 0;
     const uint32_t lane = threadIdx.x & 63u;
     const bool stores = GL == 1 || (lane & (GL - 1)) == 0;           // the lane that owns the board in memory
@@ -382,6 +390,14 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
     for (;;) {
         // ---- refill
         const uint64_t need = __builtin_amdgcn_ballot_w64(!live && stores);  // one bit per idle board slot
+        if (need && taken >= avail && !dry) {   // (a work list) the chunk is used up: the next one
+            uint32_t next = 0;
+            if (lane == 0u) next = atomicAdd(queue, games_per_wave);
+            begin = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+            taken = 0;
+            avail = begin < total ? (uint32_t)(total - begin < (int64_t)games_per_wave ? total - begin : (int64_t)games_per_wave) : 0u;
+            dry = avail == 0u;
+        }
         if (need && taken < avail) {
             const uint32_t rank = (uint32_t)__popcll(need & below_group);  // the same in every lane of a group
             if (!live && taken + rank < avail) {
@@ -450,7 +466,7 @@ k_bounce_rollout(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restric
             }
             dirty = false;
         }
-        if (!__builtin_amdgcn_ballot_w64(live) && taken >= avail) break;
+        if (!__builtin_amdgcn_ballot_w64(live) && taken >= avail && dry) break;
     }
     add_steps(steps, stepped);
 }
@@ -845,6 +861,37 @@ __device__ __forceinline__ Board pieces_to_planes(const BounceGeom& g, const Pie
                 if ((v >> p) & 1u) out.v[p] |= bit;
         }
     return out;
+}
+
+// What K3p writes when a board stops: the POSITIONS of its pieces (the packed bytes, as two 64-bit words into the board's
+// slots of planes 0 and 1) -- ten instructions.  The value planes, the batch's memory format, are made from them for all
+// boards at once by k_bounce_positions_to_planes behind the rollout kernel: full lanes, 2^18 boards in a few microseconds.
+// (Round 3 built the planes where the board stopped: ~150 instructions with two or three lanes active, in nine
+// iterations of ten -- 4 % of the kernel's instructions.)
+template <int PMAX>
+__device__ __forceinline__ void store_positions(uint64_t* __restrict__ planes, int64_t n, int64_t i, const PieceBoard<PMAX>& b) {
+    planes[i] = (uint64_t)b.pos[0] | ((uint64_t)b.pos[1] << 32);
+    if (PMAX > 8) planes[n + i] = (uint64_t)b.pos[2] | (PMAX > 12 ? (uint64_t)b.pos[PMAX > 12 ? 3 : 0] << 32 : 0ull);
+}
+
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_positions_to_planes(BounceGeom g, uint64_t* __restrict__ planes, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t lo = planes[i], hi = g.piece_count > 8 ? planes[n + i] : 0ull;
+    Board out;
+    out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
+#pragma unroll
+    for (int k = 0; k < BGS_BOUNCE_MAX_PIECES; ++k)
+        if (k < (int)g.piece_count) {
+            const uint32_t cell = (uint32_t)((k < 8 ? lo : hi) >> (8 * (k & 7))) & 63u;
+            const uint64_t bit = 1ull << cell;
+            const uint32_t v = g.piece_value[k];  // (uniform)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if ((v >> p) & 1u) out.v[p] |= bit;
+        }
+    store_board(planes, n, i, out);
 }
 
 template <int PMAX>
@@ -1264,7 +1311,7 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
         // ---- boards that stopped go to memory and free their lane (from the start position: every board is written)
         if (has && !run && !pending) {
             const int64_t i = game;
-            store_board(planes, n, i, pieces_to_planes(g, b));
+            store_positions<PMAX>(planes, n, i, b);
             status[i] = (uint8_t)st;
             plies_buf[i] = (uint16_t)plies;
             reward[i] = reward_pair(st);
@@ -1369,7 +1416,7 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
                 // the lane takes its next board at the top of the next iteration instead of idling through it
                 st = mover + 1u;
                 const int64_t i = game;
-                store_board(planes, n, i, pieces_to_planes(g, b));
+                store_positions<PMAX>(planes, n, i, b);
                 status[i] = (uint8_t)st;
                 plies_buf[i] = (uint16_t)plies;
                 reward[i] = reward_pair(st);
@@ -1625,10 +1672,11 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
     const int64_t slots_per_wave = BGS_WAVE / group;
     int64_t per_wave, waves;
     if (worklist) {
-        // the list's length is only known on the device: one refill round per wave, the grid covers the worst case
-        // (every board) and waves beyond the list return at once
+        // the list's length is only known on the device: a modest fixed grid whose waves draw chunks of one wave-load
+        // from the pass's queue until it is dry (never more waves than the whole batch could need)
         per_wave = slots_per_wave;
         waves = (b->n + per_wave - 1) / per_wave;
+        if (waves > 1024) waves = 1024;
     } else {
         const int64_t resident = (int64_t)b->num_cus * 4 * wps;
         per_wave = (b->n + resident - 1) / resident;
@@ -1641,7 +1689,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         constexpr int GL = decltype(group_tag)::value;
         hipLaunchKernelGGL((k_bounce_rollout<INITIAL, GL>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes,
                            b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap,
-                           b->d_steps, (uint32_t)per_wave, worklist, work_count);
+                           b->d_steps, (uint32_t)per_wave, worklist, work_count, queue);
     };
     auto launch_flat = [&](auto initial_tag) {
         constexpr bool INITIAL = decltype(initial_tag)::value;
@@ -1691,6 +1739,8 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
                            dim3(BLOCK), tile, b->stream, b->bg, b->d_planes, b->d_status, b->d_plies,
                            reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps, chunk, queue,
                            (uint32_t)b->bounce_pieces_park, pool);
+        // every board was written as the positions of its pieces: the value planes for all of them, at full lanes
+        hipLaunchKernelGGL(k_bounce_positions_to_planes, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->n);
     };
     auto with_block = [&](auto pmax_tag) {
         if (b->bounce_block >= 1024) launch_pieces(pmax_tag, std::integral_constant<int, 1024>{});

@@ -872,6 +872,30 @@ int bgs_step_actions(bgs_batch* b, const int32_t* actions, int actions_on_device
     return BGS_OK;
 }
 
+int bgs_step_actions_observe(bgs_batch* b, const int32_t* device_actions, void* device_observation, uint8_t* device_ended,
+                             int32_t* device_status) {
+    int rc = enter(b);
+    if (rc) return rc;
+    NEED(device_actions != nullptr && device_observation != nullptr, "actions and the observation's destination must not be NULL");
+    NEED(!b->generic || b->game == BGS_GAME_CONNECT, "generic Bounce boards have no 64-bit target masks (see bgs_export_device 't')");
+    // one-word Connect boards, even batch: the moves, the legal mask and the ended flags in ONE pass over the batch
+    if (!b->generic && b->game == BGS_GAME_CONNECT &&
+        bgs::connect_step_observe(b, device_actions, device_status, static_cast<uint8_t*>(device_observation), device_ended))
+        return finish_launch();
+    // everything else: the same result from the kernels of the separate calls, enqueued back to back
+    if (b->generic) bgs::generic_step_actions(b, device_actions, device_status);
+    else if (b->game == BGS_GAME_CONNECT) bgs::connect_step_actions(b, device_actions, device_status);
+    else bgs::bounce_step_actions(b, device_actions, device_status);
+    if (b->game == BGS_GAME_CONNECT) {
+        if (b->generic) bgs::generic_connect_legal(b, static_cast<uint8_t*>(device_observation), nullptr);
+        else bgs::connect_legal(b, static_cast<uint8_t*>(device_observation), nullptr);
+    } else {
+        bgs::bounce_targets(b, static_cast<uint64_t*>(device_observation), nullptr);
+    }
+    if (device_ended) bgs::status_to_ended(b, device_ended);
+    return finish_launch();
+}
+
 int bgs_rollout(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
     int rc = enter(b);
     if (rc) return rc;

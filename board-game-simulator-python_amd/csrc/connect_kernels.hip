@@ -739,6 +739,110 @@ k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __rest
     add_steps(steps, stepped);
 }
 
+// N2, one launch per policy ply (round 4): apply the moves an external policy chose AND emit what it needs for its next
+// choice -- the legal mask uint8[n][W] (State::get_actions as a mask, connect.cpp:43) and the ended flags -- in the same
+// pass over the batch.  A policy ply used to be two library launches (bgs_export_device 'l', then bgs_step_actions), each
+// reading every board; at 2^20 boards a per-ply launch is ~10 us whatever it does, so the two cost the loop twice what
+// one does.  One-word boards, even batch: a lane owns a PAIR of boards as in K1s (16-byte accesses on both planes, 8-byte
+// loads of the two actions); the legal bytes of the workgroup's 512 boards go through LDS and leave as 16-byte stores.
+// A board that has ended ignores its action (result 0 for a negative one, BGS_ERR_ILLEGAL otherwise, as bgs_step_actions).
+template <class G>
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_connect_step_observe(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
+                       int64_t n, const int32_t* __restrict__ actions, int32_t* __restrict__ result,
+                       uint8_t* __restrict__ legal, uint8_t* __restrict__ ended, unsigned long long* __restrict__ steps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t legal_tile[];   // [2 * BGS_BLOCK boards][W] bytes, in output order
+    const int64_t pairs = n >> 1;
+    const int h = g.h(), w = g.w();
+    uint64_t bottoms = 0, cells = 0;  // wave-uniform geometry masks
+    for (int x = 0; x < w; ++x) {
+        bottoms |= 1ull << (x * (h + 1));
+        cells |= ((1ull << h) - 1ull) << (x * (h + 1));
+    }
+    const uint32_t full = (uint32_t)(h * w);
+    const int64_t t = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    uint32_t stepped = 0;
+    if (t < pairs) {
+        const ulonglong2 a = reinterpret_cast<const ulonglong2*>(planes)[t];
+        const ulonglong2 b = reinterpret_cast<const ulonglong2*>(planes + n)[t];
+        const uint32_t s2 = reinterpret_cast<const uint16_t*>(status)[t];
+        const int2 act = reinterpret_cast<const int2*>(actions)[t];
+        uint64_t p[2][2] = {{a.x, b.x}, {a.y, b.y}};   // [board of the pair][player]
+        uint32_t st[2] = {s2 & 255u, s2 >> 8};
+        const int col[2] = {act.x, act.y};
+        int32_t rc[2] = {0, 0};
+        bool moved[2] = {false, false};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (col[q] >= 0) {
+                rc[q] = -2;  // BGS_ERR_ILLEGAL unless the move below goes through
+                const uint64_t landing = ((p[q][0] | p[q][1]) + bottoms) & cells;   // one bit per open column: its next cell
+                const uint64_t column = col[q] < w ? (((1ull << h) - 1ull) << (col[q] * (h + 1))) : 0ull;
+                const uint64_t stone = landing & column;
+                if (st[q] == BGS_ST_RUNNING && stone) {
+                    const uint32_t ply = (uint32_t)__popcll(p[q][0] | p[q][1]);
+                    const uint32_t me = ply & 1u;
+                    const uint64_t mine = (me ? p[q][1] : p[q][0]) | stone;
+                    p[q][0] = me ? p[q][0] : mine;
+                    p[q][1] = me ? mine : p[q][1];
+                    bool won;
+                    if (g.k() == 4) {
+                        won = four_in_a_row_at(mine, h, (uint32_t)__ffsll((unsigned long long)stone) - 1u);
+                    } else {
+                        Bits<1> bits;
+                        bits.w[0] = mine;
+                        won = has_run(g, bits);
+                    }
+                    st[q] = won ? me + 1u : (ply + 1u == full ? (uint32_t)BGS_ST_DRAW : (uint32_t)BGS_ST_RUNNING);
+                    moved[q] = true;
+                    rc[q] = 0;
+                    ++stepped;
+                }
+            }
+        }
+        if (moved[0] | moved[1]) {
+            // one ply changes only the mover's plane: a plane neither board of the pair changed is not stored
+            if (p[0][0] != a.x || p[1][0] != a.y) reinterpret_cast<ulonglong2*>(planes)[t] = ulonglong2{p[0][0], p[1][0]};
+            if (p[0][1] != b.x || p[1][1] != b.y) reinterpret_cast<ulonglong2*>(planes + n)[t] = ulonglong2{p[0][1], p[1][1]};
+            if (st[0] != (s2 & 255u) || st[1] != (s2 >> 8)) {
+                reinterpret_cast<uint16_t*>(status)[t] = (uint16_t)(st[0] | (st[1] << 8));
+                reinterpret_cast<uint32_t*>(reward)[t] = (uint32_t)reward_pair(st[0]) | ((uint32_t)reward_pair(st[1]) << 16);
+            }
+        }
+        if (result) reinterpret_cast<int2*>(result)[t] = int2{rc[0], rc[1]};
+        if (ended) reinterpret_cast<uint16_t*>(ended)[t] = (uint16_t)((st[0] != 0u ? 1u : 0u) | (st[1] != 0u ? 256u : 0u));
+        // the observation AFTER the move: which columns the side to move may play
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint64_t landing = st[q] == BGS_ST_RUNNING ? (((p[q][0] | p[q][1]) + bottoms) & cells) : 0ull;
+            uint8_t* mine = legal_tile + (2 * threadIdx.x + q) * w;
+            for (int x = 0; x < w; ++x) mine[x] = (uint8_t)(((landing >> (x * (h + 1))) & ((1ull << h) - 1ull)) != 0ull);
+        }
+    }
+    __syncthreads();
+    // the workgroup's 2 * BGS_BLOCK * W legal bytes are contiguous in the output and start at a multiple of 16
+    const int64_t first_board = (int64_t)blockIdx.x * BGS_BLOCK * 2;
+    const int64_t boards_here = n - first_board < 2 * BGS_BLOCK ? (n & ~(int64_t)1) - first_board : 2 * BGS_BLOCK;
+    if (boards_here > 0) {
+        const int64_t bytes = boards_here * w;
+        uint8_t* dst = legal + first_board * w;
+        for (int64_t o = (int64_t)threadIdx.x * 16; o < bytes; o += (int64_t)BGS_BLOCK * 16) {
+            if (o + 16 <= bytes) {
+                *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(legal_tile + o);
+            } else {
+                for (int64_t r = o; r < bytes; ++r) dst[r] = legal_tile[r];
+            }
+        }
+    }
+    add_steps(steps, stepped);
+}
+
+// the ended flags alone (the fall-back of bgs_step_actions_observe for the batches the fused kernel does not cover)
+__global__ void __launch_bounds__(BGS_BLOCK) k_status_to_ended(const uint8_t* __restrict__ status, int64_t n, uint8_t* __restrict__ ended) {
+    const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
+    if (i < n) ended[i] = status[i] != 0;
+}
+
 // Outcome codes of a wave's chunk, accumulated where the games end (the fused form of k_pack_outcomes): 2 bits per
 // game, 16 games per dword, in a wave-private slice of LDS; when the chunk is finished the wave stores its dwords to
 // `codes_out` -- for the host hand-over that is page-locked HOST memory mapped into the device, so the codes are in
@@ -1852,6 +1956,27 @@ void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t*
         hipLaunchKernelGGL((k_connect_step_actions<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g, b->d_planes,
                            b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_actions, d_status_out, b->d_steps);
     });
+}
+
+// true: the fused kernel ran (one-word board, even batch, 16-byte aligned legal destination); false: nothing was enqueued
+bool connect_step_observe(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out, uint8_t* d_legal, uint8_t* d_ended) {
+    if (b->cg.nw != 1 || (b->n & 1) || b->n < 2 || ((uintptr_t)d_legal & 15u) || ((uintptr_t)d_actions & 7u) ||
+        ((uintptr_t)d_status_out & 7u) || ((uintptr_t)d_ended & 1u))
+        return false;
+    const size_t tile = (size_t)2 * BGS_BLOCK * b->cg.w;
+    dispatch(b->cg, [&](auto g) {
+        using G = decltype(g);
+        if constexpr (G::NW == 1) {
+            hipLaunchKernelGGL((k_connect_step_observe<G>), dim3(grid_for(b->n >> 1)), dim3(BGS_BLOCK), tile, b->stream, g, b->d_planes,
+                               b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_actions, d_status_out, d_legal, d_ended,
+                               b->d_steps);
+        }
+    });
+    return true;
+}
+
+void status_to_ended(const bgs_batch* b, uint8_t* d_ended) {
+    hipLaunchKernelGGL(k_status_to_ended, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->d_status, b->n, d_ended);
 }
 
 // codes_out != nullptr asks the kernel to deliver the 2-bit outcome codes itself (uint32[(n + 15) / 16], device or

@@ -607,6 +607,35 @@ class _Batch:
             out = t.empty((self.n, 2), dtype=t.int8, device=f"cuda:{self.device}")
         return self._export("r", out)
 
+    def step_actions_observe(self, actions, observation=None, ended=None, status=None):
+        """ONE library call per policy ply (bgs_step_actions_observe): apply `actions` -- a DEVICE tensor, int32[n] columns for
+        Connect, int32[n, 4] moves for Bounce; negative = skip the board -- and write the observation of the boards after the
+        move for the policy's next choice: Connect the legal mask uint8[n, width], Bounce the target masks int64[n, width + 1]
+        (`observation`, allocated when None), plus `ended` uint8[n] and `status` int32[n] (per-board result) when given.
+        Everything stays on the device and on the batch's stream: no synchronisation, capturable in a HIP graph.  Returns the
+        observation tensor.  The loop: obs = batch.legal_tensor(); while ...: obs = batch.step_actions_observe(policy(obs), obs)."""
+        t = self._need_torch("step_actions_observe")
+        width = 1 if self.game == _abi.GAME_CONNECT else 4
+        want = (self.n,) if width == 1 else (self.n, 4)
+        if not (hasattr(actions, "data_ptr") and actions.is_cuda and actions.dtype == t.int32 and tuple(actions.shape) == want
+                and actions.is_contiguous()):
+            raise TypeError(f"actions must be a contiguous int32 device tensor of shape {want}")
+        if observation is None:
+            observation = (t.empty((self.n, self.width), dtype=t.uint8, device=actions.device) if width == 1
+                           else t.empty((self.n, self.width + 1), dtype=t.int64, device=actions.device))
+        shape = (self.n, self.width) if width == 1 else (self.n, self.width + 1)
+        dtypes = (t.uint8,) if width == 1 else (t.int64, getattr(t, "uint64", t.int64))   # (64-bit masks: either signedness)
+        if not (observation.is_cuda and observation.dtype in dtypes and tuple(observation.shape) == shape and observation.is_contiguous()):
+            raise TypeError(f"observation must be a contiguous {dtypes[0]} device tensor of shape {shape}")
+        for name, buf, dt in (("ended", ended, t.uint8), ("status", status, t.int32)):
+            if buf is not None and not (buf.is_cuda and buf.dtype == dt and tuple(buf.shape) == (self.n,) and buf.is_contiguous()):
+                raise TypeError(f"{name} must be a contiguous {dt} device tensor of shape ({self.n},)")
+        _abi.check(_abi.lib().bgs_step_actions_observe(
+            self._handle, ctypes.c_void_p(actions.data_ptr()), ctypes.c_void_p(observation.data_ptr()),
+            ctypes.c_void_p(ended.data_ptr()) if ended is not None else None,
+            ctypes.c_void_p(status.data_ptr()) if status is not None else None))
+        return observation
+
     def _need_torch(self, who: str):
         if self._torch is None:
             raise RuntimeError(f"{who} needs torch with a GPU")
@@ -811,6 +840,15 @@ class BounceBatch(_Batch):
     def step_actions(self, moves, want_status: bool = True):
         """moves int32[n, 4] = source x, y, target x, y; a negative first entry skips the board."""
         return self._step_actions(moves, 4, want_status)
+
+    def targets_tensor(self, out=None):
+        """int64[n, W + 1] on the device (bgs_export_device 't'; the bits of `targets`, as torch's signed 64-bit type)."""
+        t = self._need_torch("targets_tensor")
+        if self.generic:
+            raise ValueError("this board does not fit 64-bit target masks: use transition() / decode_moves()")
+        if out is None:
+            out = t.empty((self.n, self.width + 1), dtype=t.int64, device=f"cuda:{self.device}")
+        return self._export("t", out)
 
     @property
     def targets(self) -> np.ndarray:

@@ -80,6 +80,7 @@ SIGNATURES = {
     "bgs_read_action_count": (ctypes.c_int, [c_handle, _i32p]),
     "bgs_bounce_read_targets": (ctypes.c_int, [c_handle, _u64p]),
     "bgs_export_device": (ctypes.c_int, [c_handle, ctypes.c_int, ctypes.c_void_p]),
+    "bgs_step_actions_observe": (ctypes.c_int, [c_handle, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "bgs_pack_outcomes": (ctypes.c_int, [c_handle, ctypes.c_void_p]),
     "bgs_rollout_pack": (ctypes.c_int, [c_handle, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p]),
     "bgs_expand_outcomes": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),

@@ -154,6 +154,16 @@ int bgs_bounce_read_targets(bgs_batch* b, uint64_t* targets);
  * 'g' grid int8[n][h][w] (16-byte aligned destination), 'l' Connect legal mask uint8[n][w], 'c' action count int32[n],
  * 't' Bounce target masks uint64[n][w + 1], 'r' reward int8[n][2] */
 int bgs_export_device(bgs_batch* b, int what, void* device_dst);
+/* N2, ONE call per policy ply: bgs_step_actions with the actions in DEVICE memory (int32[n], Bounce int32[n][4]), then --
+ * in the same pass over the batch where the kernel exists (one-word Connect boards, even n; otherwise the separate
+ * kernels back to back) -- what the policy needs for its next choice, of the boards AFTER the move: device_observation =
+ * Connect uint8[n][width] legal mask ('l' above; 16-byte aligned), Bounce uint64[n][width + 1] target masks ('t');
+ * device_ended uint8[n] State::has_ended (may be NULL); device_status int32[n] per-board result as bgs_step_actions
+ * (may be NULL).  Everything is an enqueue on the batch's stream: no synchronisation, no allocation, capturable in a
+ * HIP graph.  The loop README.md:57-65 / examples/agent.py:13-27 make per board, for a batch and a device-side policy:
+ * observation -> policy -> bgs_step_actions_observe -> observation -> ... */
+int bgs_step_actions_observe(bgs_batch* b, const int32_t* device_actions, void* device_observation, uint8_t* device_ended,
+                             int32_t* device_status);
 
 /* ---- compact outcomes for the multi-GPU reward gather ------------------------------------------------ */
 /* 2 bits per board (0 running, 1 / 2 that player won, 3 draw), 4 boards per byte, board 4i in the low bits:

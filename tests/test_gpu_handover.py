@@ -293,6 +293,86 @@ def test_connect_policy_loop_on_device_tensors(bm, torch_mod):
     dev.close()
 
 
+@pytest.mark.parametrize("geometry,n", [((6, 7, 4), 1 << 16), ((6, 7, 4), 1022), ((4, 5, 3), 3000), ((8, 8, 5), 2048),
+                                         ((6, 7, 4), 4097), ((12, 13, 5), 1024), ((20, 20, 5), 256)])
+def test_one_call_per_policy_ply_connect(bm, torch_mod, geometry, n):
+    """bgs_step_actions_observe: the chosen moves, the NEXT legal mask, the ended flags and the per-board results in one
+    call -- one kernel for one-word boards and an even batch (config 2's geometry, a smaller and a larger one-word board,
+    batch sizes around the workgroup boundary), the separate kernels back to back otherwise (odd batch, multi-word and
+    generic boards) -- against the oracle's step_actions + legal() + ended, ply by ply, with refused moves (column out of
+    range, full column, boards that have ended) in between."""
+    torch = torch_mod
+    h, w, k = geometry
+    dev = bm.ConnectBatch(h, w, k, n, use_torch=True)
+    orc = oracle.ConnectOracle(h, w, k, n)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    legal = dev.legal_tensor()
+    ended = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+    status = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+    for ply in range(h * w + 2):
+        np.testing.assert_array_equal(legal.cpu().numpy(), orc.legal(), err_msg=f"legal before ply {ply}")
+        scores = torch.rand((n, w), device="cuda", generator=gen) + legal.float()
+        cols = scores.argmax(dim=1).to(torch.int32)          # a legal column while there is one -- ended boards get one too
+        if ply == 2:
+            cols[::5] = w          # out of range
+            cols[1::5] = -1        # skipped
+        if ply == h + 1:
+            cols[:] = 0            # column 0, full on many boards by now
+        want = orc.step_actions(cols.cpu().numpy())
+        out = dev.step_actions_observe(cols, legal, ended=ended, status=status)
+        assert out is legal
+        np.testing.assert_array_equal(status.cpu().numpy(), want, err_msg=f"status, ply {ply}")
+        np.testing.assert_array_equal(ended.cpu().numpy().astype(bool), orc.ended, err_msg=f"ended, ply {ply}")
+        np.testing.assert_array_equal(dev.reward, orc.reward, err_msg=f"reward, ply {ply}")
+    np.testing.assert_array_equal(legal.cpu().numpy(), orc.legal())
+    np.testing.assert_array_equal(dev.grid, orc.grid)
+    assert dev.steps == int(orc.plies.sum())
+    with pytest.raises(TypeError):
+        dev.step_actions_observe(cols.to(torch.int64), legal)
+    with pytest.raises(TypeError):
+        dev.step_actions_observe(cols, legal[:, :-1])
+    # the optional outputs are optional, and the observation is allocated when none is passed
+    dev.reset()
+    orc.reset()
+    cols = torch.full((n,), w // 2, dtype=torch.int32, device="cuda")
+    fresh = dev.step_actions_observe(cols)
+    orc.step_actions(cols.cpu().numpy())
+    np.testing.assert_array_equal(fresh.cpu().numpy(), orc.legal())
+    dev.close()
+
+
+def test_one_call_per_policy_ply_bounce(bm, torch_mod):
+    """The same call on Bounce (moves int32[n, 4] -> target masks uint64[n, W + 1] + ended): the kernels of the separate
+    calls back to back; compared with step_actions + the 't' export and with the oracle's rewards."""
+    torch = torch_mod
+    n = 2048
+    dev = bm.BounceBatch(DEFAULT_BOUNCE, n, use_torch=True)
+    ref = bm.BounceBatch(DEFAULT_BOUNCE, n, use_torch=True)
+    targets = dev.targets_tensor()
+    ended = torch.zeros((n,), dtype=torch.uint8, device="cuda")
+    rng = np.random.default_rng(3)
+    for ply in range(40):
+        t = targets.cpu().numpy().view(np.uint64)
+        moves = np.full((n, 4), -1, dtype=np.int32)
+        for i in range(n):   # the first target of a random movable column (host-side policy: this is a test of the call)
+            row = int(t[i, 6]) if t[i, 6] < 64 else -1
+            cols = [x for x in range(6) if t[i, x]] if row >= 0 else []
+            if cols:
+                x = cols[rng.integers(len(cols))]
+                cell = int(t[i, x]).bit_length() - 1
+                moves[i] = (x, row, cell % 6, cell // 6)
+        mv = torch.from_numpy(moves).cuda()
+        dev.step_actions_observe(mv, targets, ended=ended)
+        ref.step_actions(mv, want_status=False)
+        np.testing.assert_array_equal(targets.cpu().numpy(), ref.targets_tensor().cpu().numpy(), err_msg=f"targets, ply {ply}")
+        np.testing.assert_array_equal(ended.cpu().numpy().astype(bool), ref.has_ended, err_msg=f"ended, ply {ply}")
+    np.testing.assert_array_equal(dev.grid, ref.grid)
+    np.testing.assert_array_equal(dev.reward, ref.reward)
+    assert ref.has_ended.any()
+    dev.close()
+    ref.close()
+
+
 def test_bounce_device_targets_and_moves(bm, torch_mod):
     """Config 4's geometry: target masks ('t'), action counts ('c') and rewards ('r') exported to device memory,
     moves chosen on the device from the masks, against the oracle's action lists."""

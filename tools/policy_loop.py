@@ -1,34 +1,88 @@
 #!/usr/bin/env python3
-"""Policy-driven stepping: an external policy on the GPU picks every move.  Per ply: legal mask on
-the device (bgs_export_device 'l') -> torch policy -> bgs_step_actions with a device action tensor.  No host round
-trip inside the loop.  Prints env-steps/s for a uniform-random torch policy on Connect4(6,7,4), 2^20 boards."""
-import os, sys, time
+"""Policy-driven stepping (N2): env-steps/s of the loop  observation -> device policy -> move  on Connect4(6,7,4).
+
+Two forms of the library's part of a ply:
+  two calls   bgs_export_device 'l' (legal mask), then bgs_step_actions            -- what round 3 had
+  one call    bgs_step_actions_observe: the moves and the next legal mask in one pass over the batch (round 4)
+each eager and replayed from a HIP graph (one game's worth of plies captured once), with the same torch policy -- random
+scores on the legal columns, argmax: four torch kernels over n x 7 floats, 65 us a ply at 2^20 boards, several times the
+library's share -- and with NO policy (a fixed action tensor: the library's share alone; env-steps/s mean nothing there,
+boards fill up and refuse moves: read the microseconds per ply).
+    python3 tools/policy_loop.py [boards ...]      -> one JSON object per batch size"""
+import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
 import torch
 from simulator.batch import ConnectBatch
 
-n = 1 << 20
-batch = ConnectBatch(6, 7, 4, n, use_torch=True)
-legal = torch.empty((n, 7), dtype=torch.uint8, device="cuda")
-gen = torch.Generator(device="cuda").manual_seed(1)
+PLIES = 42
 
-def play_all():
-    batch.reset()
-    plies = 0
-    for _ in range(42):
-        batch.legal_tensor(legal)
-        # uniform over legal columns: random scores, illegal columns masked out; boards without a legal column skip
-        scores = torch.rand((n, 7), device="cuda", generator=gen) * legal
-        col = scores.argmax(dim=1).to(torch.int32)
-        col = torch.where(legal.any(dim=1), col, torch.full_like(col, -1))
-        batch.step_actions(col, want_status=False)
-        plies += 1
-    torch.cuda.synchronize()
 
-play_all()
-t0 = time.perf_counter()
-play_all()
-dt = time.perf_counter() - t0
-print(f"policy loop: {batch.steps} env-steps in {dt*1e3:.2f} ms = {batch.steps/dt/1e9:.2f} G env-steps/s "
-      f"(42 plies x [legal mask + torch policy + step_actions]); all ended: {bool(batch.has_ended.all())}")
+def measure(n):
+    stream = torch.cuda.Stream()
+    out = {"boards": n, "plies_per_game": PLIES}
+    with torch.cuda.stream(stream):
+        batch = ConnectBatch(6, 7, 4, n, use_torch=True)   # bound to `stream`
+        legal = torch.empty((n, 7), dtype=torch.uint8, device="cuda")
+        fixed = torch.randint(0, 7, (n,), dtype=torch.int32, device="cuda")
+
+        def policy():
+            return (torch.rand((n, 7), device="cuda") + legal).argmax(dim=1).to(torch.int32)   # ended boards ignore their move
+
+        def two_calls(with_policy):
+            for _ in range(PLIES):
+                batch.legal_tensor(legal)
+                batch.step_actions(policy() if with_policy else fixed, want_status=False)
+
+        def one_call(with_policy):
+            batch.legal_tensor(legal)
+            for _ in range(PLIES):
+                batch.step_actions_observe(policy() if with_policy else fixed, legal)
+
+        for name, loop in (("two_calls", two_calls), ("one_call", one_call)):
+            for with_policy in (True, False):
+                key = name + ("" if with_policy else "_no_policy")
+
+                def game():
+                    batch.reset()
+                    loop(with_policy)
+
+                game(); torch.cuda.synchronize()
+                batch.reset_steps()
+                reps = 5
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    game()
+                torch.cuda.synchronize()
+                eager = (time.perf_counter() - t0) / reps
+                steps = batch.steps / reps
+                graph = torch.cuda.CUDAGraph()
+                batch.reset(); torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=stream):
+                    loop(with_policy)
+                batch.reset(); graph.replay(); torch.cuda.synchronize()
+                batch.reset_steps()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    batch.reset()
+                    graph.replay()
+                torch.cuda.synchronize()
+                replay = (time.perf_counter() - t0) / reps
+                steps_g = batch.steps / reps
+                out[key] = {"eager_us_per_ply": eager / PLIES * 1e6, "graph_us_per_ply": replay / PLIES * 1e6,
+                            "env_steps_per_s_eager": steps / eager, "env_steps_per_s_graph": steps_g / replay,
+                            # what one ply of the LIBRARY moves per board, whatever the board's state: planes 16 B in + 8 B out
+                            # (the mover's), status 1 B, action 4 B, legal 7 B out = 36 B; two calls read the planes and the
+                            # status a second time: + 17 B.  (The policy's own traffic is not counted.)
+                            "library_bytes_per_board_ply": 53 if name == "two_calls" else 36,
+                            "library_GBps_graph": n * (53 if name == "two_calls" else 36) / (replay / PLIES) / 1e9}
+        for tag in ("", "_no_policy"):
+            out["one_call_over_two_calls_graph" + tag] = out["one_call" + tag]["env_steps_per_s_graph"] / out["two_calls" + tag]["env_steps_per_s_graph"]
+            out["one_call_over_two_calls_eager" + tag] = out["one_call" + tag]["env_steps_per_s_eager"] / out["two_calls" + tag]["env_steps_per_s_eager"]
+        batch.close()
+    return out
+
+
+if __name__ == "__main__":
+    sizes = [int(a) for a in sys.argv[1:]] or [1 << 16, 1 << 20]
+    print(json.dumps({"policy_loop": [measure(n) for n in sizes]}))

@@ -5,6 +5,7 @@
     python3 tools/sweep.py bounce-park    [--reps N]     K3p parking threshold (BGS_BOUNCE_PIECES_PARK) with / without the device-wide pool
     python3 tools/sweep.py bounce-tail    [--reps N]     ply cap of the bulk pass (BGS_BOUNCE_PLAN) x parking threshold, 20 in flight
     python3 tools/sweep.py bounce-depth   [--reps N]     Bounce batches in flight (8 .. 28) with the default launch shape
+    python3 tools/sweep.py k2c-shape      [--reps N]     Connect(12,13,5): waves per SIMD per launch (BGS_ROLLOUT_WPS) x launches in flight
     python3 tools/sweep.py k2c-depth      [--reps N]     Connect(12,13,5) batches in flight (1 .. 12)
     python3 tools/sweep.py headline-depth [--reps N]     Connect4(6,7,4) batches in flight (1 .. 8)
 Every point is a child process (the library reads its knobs when a batch is created; GPU_MAX_HW_QUEUES when HIP starts);
@@ -27,7 +28,7 @@ def point(config, depth, reps, env=None, extra=()):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=("bounce-block", "bounce-park", "bounce-tail", "bounce-depth", "k2c-depth", "headline-depth"))
+    ap.add_argument("what", choices=("bounce-block", "bounce-park", "bounce-tail", "bounce-depth", "k2c-shape", "k2c-depth", "headline-depth"))
     ap.add_argument("--reps", type=int, default=0)
     args = ap.parse_args()
     rows = []
@@ -55,6 +56,11 @@ def main():
         for depth in (8, 12, 16, 20, 24, 28):
             rows.append(dict({"depth": depth}, **point("bounce", depth, args.reps or 6 * depth)))
             print(rows[-1], flush=True)
+    elif args.what == "k2c-shape":
+        for depth in (1, 2, 4):
+            for wps in (1, 2, 3, 4, 6, 8):
+                rows.append(dict({"depth": depth, "wps": wps}, **point("connect12x13", depth, args.reps or 60 * depth, {"BGS_ROLLOUT_WPS": wps})))
+                print(rows[-1], flush=True)
     elif args.what == "k2c-depth":
         for depth in (1, 2, 3, 4, 6, 8, 12):
             rows.append(dict({"depth": depth}, **point("connect12x13", depth, args.reps or 40 * depth)))

@@ -379,7 +379,9 @@ def run_other_config(name: str, steps: int) -> int:
         dt = time.perf_counter() - t0
         return sum(b.steps for b in batches) / dt, dt / count * 1e3
 
-    slots = min(64, int(os.environ.get("BGS_BENCH_OTHER_SLOT_FACTOR", "2")) * depth)
+    # host arrays / sink slots per stream: deliveries complete in ticket order, and a Bounce step's duration varies with its
+    # longest games -- three per stream let the launching thread run past a slow stream (2 -> 3: 1.34 -> 1.37 x 10^10)
+    slots = min(64, int(os.environ.get("BGS_BENCH_OTHER_SLOT_FACTOR", "3" if name == "bounce_default" else "2")) * depth)
     streams, batches = make(depth)
     hosts = [np.zeros((n, 2), dtype=np.int8) for _ in range(slots)]
     sink = RewardSink(n, slots=slots, threads=4, device=0)
@@ -652,7 +654,7 @@ def main() -> int:
             host_threads = 6 if kind == "sink" else 4 if ring_mode else min(24, 4 + 2 * world)
         # The hand-over pipeline is deeper than the GPU's (three times as many host arrays / sink slots as streams), so the
         # launching thread waits for the delivery of step i - 3 * depth, not i - depth, before it enqueues step i (measured,
-        # tools/slots_sweep.sh: 3 per stream is 3 % faster than 2 on a 20-step run, 4 is slower: more arrays than the caches
+        # tools/sweep.py bench --env BGS_BENCH_SLOT_FACTOR=2,3,4: 3 per stream is 3 % faster than 2 on a 20-step run, 4 is slower: more arrays than the caches
         # hold).
         # Shared array: the consumer rank's launch loop also waits for EVERY rank's delivery of hand-over j - lag before it
         # enqueues hand-over j, so it runs `lag`, not `host_slots`, steps ahead of the deliveries: one more array per stream

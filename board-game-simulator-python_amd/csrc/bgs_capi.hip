@@ -504,7 +504,7 @@ int rollout_with_codes(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t 
 // batch of at most kSmallTransition boards the in-block and the out-block live in page-locked host memory that the
 // kernels read and write in place (a few hundred bytes over PCIe).  Optionally the launch sequence -- it depends only
 // on which of grid / plies / actions the caller passed -- is captured once per combination and replayed as a HIP graph.
-// Measured (tools/object_latency.py, tools/r3_transition.sh; Connect 6x7x4 / default Bounce, one thread, with the
+// Measured (tools/object_latency.py, round 3, r3_transition.sh in the git history; Connect 6x7x4 / default Bounce, one thread, with the
 // engines leaving out the load of a board the device already holds): staged 53 / 63 us per transition, in place 28 / 46,
 // graph 35 / 52 -- hipGraphLaunch costs more than the five launches it replaces.  From 8 threads the order of in place
 // and graph changed between runs (30 vs 42 and 48 vs 38 thousand Connect transitions per second).  The default goes one

@@ -64,7 +64,7 @@ constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBo
 // longest chain of dependent plies (17 us a ply on the piece-list kernel, 0.65 us on the 8-lanes-per-board kernel of
 // the tail) and by how many SIMDs it reaches, so: short bulk, many waves.  With 16 launches sharing the chip what counts
 // is instructions per ply, so: few long-lived waves that stay full, and a bulk pass long enough to keep the tail small.
-// 2^18 boards, 10^9 env-steps/s (tools/r3_bounce_solo.sh, r3_bounce_depth.sh, r3_bounce_depth2.sh):
+// 2^18 boards, 10^9 env-steps/s (round 3, r3_bounce_solo.sh in the git history, r3_bounce_depth.sh, r3_bounce_depth2.sh):
 //   in flight        1      4      8      16
 //   {384, 512}     1.11   2.16   6.05   9.7      (round 3's only shape until then)
 //   {64, 128}      1.92   3.10   6.53   7.7

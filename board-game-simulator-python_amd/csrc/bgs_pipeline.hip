@@ -32,7 +32,7 @@ using bgs::fail;
 // once per stream, one after the other (3 streams: 40-45 us at the end of a 0.7 ms region).  With one of these per
 // stream the round trips run side by side and BEHIND the last kernels, while the sink still expands the last delivery:
 // the draining thread only waits for the delivery and for their flags, and the caller's own hipDeviceSynchronize finds
-// idle streams (5 us).  tools/r3_drain.sh: 20-step regions 6.48 -> 6.83 x 10^11, last delivery expanded -> device
+// idle streams (5 us).  round 3, r3_drain.sh in the git history: 20-step regions 6.48 -> 6.83 x 10^11, last delivery expanded -> device
 // synchronised 55 -> 22 us.  The threads sleep between drains.
 struct StreamSyncer {
     std::thread th;
@@ -224,7 +224,7 @@ int bgs_pipeline_drain(bgs_pipeline* p) {
     int64_t newest = -1;
     for (int64_t t : p->ticket) newest = t > newest ? t : newest;
     // every stream is synchronised by its helper, starting NOW (see StreamSyncer); BGS_DRAIN_SERIAL_SYNC=1: by this
-    // thread, one after the other, once the deliveries are in (the A/B of tools/r3_drain.sh)
+    // thread, one after the other, once the deliveries are in (the A/B of round 3, r3_drain.sh in the git history)
     const size_t depth = p->batches.size();
     static const bool serial = getenv("BGS_DRAIN_SERIAL_SYNC") != nullptr;
     const bool helpers = depth > 1 && !serial;

@@ -1921,7 +1921,7 @@ void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
         const int64_t pairs = b->n >> 1;
         int64_t blocks = (pairs + BGS_BLOCK - 1) / BGS_BLOCK;
         // 16 workgroups of 4 waves per CU: twice what is resident, so a CU that finishes its share early takes more
-        // (tools/r3_k1.sh at 2^24 boards, one ply: 4 / 6 / 8 / 12 / 16 / 32 per CU = 4.35 / 4.68 / 4.75 / 4.96 / 4.94 / 4.83
+        // (round 3, r3_k1.sh in the git history at 2^24 boards, one ply: 4 / 6 / 8 / 12 / 16 / 32 per CU = 4.35 / 4.68 / 4.75 / 4.96 / 4.94 / 4.83
         // TB/s; with the non-temporal accesses 16 per CU reads 5.04)
         const int64_t resident = (int64_t)b->num_cus * 16;
         if (blocks > resident) blocks = resident;

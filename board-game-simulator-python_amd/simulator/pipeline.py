@@ -129,7 +129,7 @@ def default_depth(batch_cls, config_args: tuple = ()) -> int:
     issue at two waves per SIMD: 3 in flight fill the drain of one launch with the next, more only add to the tail.  A
     multi-word Connect board (12x13x5: the LDS-staged kernel, ONE wave per SIMD per launch, each issuing one VALU per
     ~9 cycles when alone) wants more waves per SIMD than three launches give: 8 in flight, 2.45 against 2.18 x 10^11
-    env-steps/s (tools/r3_k2c_depth.sh; 12-16 with larger chunks reach 2.5-2.56).  A Bounce rollout is a 5-15 ms launch
+    env-steps/s (round 3, r3_k2c_depth.sh in the git history; 12-16 with larger chunks reach 2.5-2.56).  A Bounce rollout is a 5-15 ms launch
     whose tail is a handful of long games: 20 in flight on 32 hardware queues (16 / 20 / 24 / 28 / 32 in flight read
     10.1 / 11.0 / 10.1 / 7.9 / 5.9 x 10^9 env-steps/s at 2^18 boards: beyond 24 the hardware queues thrash), 7x one launch
     at a time."""

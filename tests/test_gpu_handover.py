@@ -694,7 +694,7 @@ def test_rollout_pipeline_matches_the_oracle_step_by_step():
 def test_policy_loop_replays_from_a_hip_graph(bm, torch_mod):
     """Policy-driven stepping (N2) captured once and replayed: legal mask on the device -> a torch policy -> bgs_step_actions
     with device actions are plain enqueues on the batch's stream (no allocation, no synchronisation), so torch.cuda.graphs
-    can record a whole game's plies and replay them without per-launch host cost (tools/policy_graph.py: 1.8x at 2^16
+    can record a whole game's plies and replay them without per-launch host cost (tools/policy_loop.py: 1.8x at 2^16
     boards).  A deterministic policy (first legal column, shifted by the board index) so that eager, graph and oracle
     must agree board for board."""
     torch = torch_mod

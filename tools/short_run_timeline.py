@@ -3,7 +3,7 @@
 to host) for K steps with every launch bracketed by events -- start and end of every launch relative to the first, and
 the host's clock around enqueue / drain.  Prints one JSON object.   python tools/short_run_timeline.py [K] [repeats]
 With BGS_SINK_TRACE=1 the sink's threads report (stderr, microseconds of the same clock) when each delivery's codes were
-seen and expanded; tools/r3_drain.sh puts the two together for the last delivery of each repeat."""
+seen and expanded; round 3, r3_drain.sh in the git history puts the two together for the last delivery of each repeat."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]

@@ -8,6 +8,12 @@
     python3 tools/sweep.py k2c-shape      [--reps N]     Connect(12,13,5): waves per SIMD per launch (BGS_ROLLOUT_WPS) x launches in flight
     python3 tools/sweep.py k2c-depth      [--reps N]     Connect(12,13,5) batches in flight (1 .. 12)
     python3 tools/sweep.py headline-depth [--reps N]     Connect4(6,7,4) batches in flight (1 .. 8)
+    python3 tools/sweep.py bench --env NAME=v1,v2,... [--args "bench.py arguments"] [--repeat R]
+                                                         bench.py with one environment variable (or, NAME starting with "--",
+                                                         one command-line option) swept over values: value / median of 3 /
+                                                         device-resident per point.  Covers what round 3 kept as one-off
+                                                         scripts: BGS_BENCH_SLOT_FACTOR (slots), --host-threads, --prewarm-ms,
+                                                         --inflight, BGS_ROLLOUT_WPS, BGS_BENCH_PAIRS, BGS_SINK_SPIN_US, ...
 Every point is a child process (the library reads its knobs when a batch is created; GPU_MAX_HW_QUEUES when HIP starts);
 prints one line per point and a JSON summary."""
 import argparse, json, os, subprocess, sys
@@ -26,13 +32,38 @@ def point(config, depth, reps, env=None, extra=()):
     return {"solo": d["one_launch_at_a_time"]["env_steps_per_s"], "pipelined": d[f"{depth}_in_flight"]["env_steps_per_s"]}
 
 
+def bench_point(env, args):
+    e = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-other-configs", *args], env=e,
+                         capture_output=True, text=True)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return {"error": out.stderr.strip()[-300:]}
+    d = json.loads(lines[-1])
+    return {"value": d["value"], "median_of_3": d.get("value_median_of_3"), "device_resident": (d.get("device_resident") or {}).get("value"),
+            "ms_per_step": d["ms_per_step"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=("bounce-block", "bounce-park", "bounce-tail", "bounce-depth", "k2c-shape", "k2c-depth", "headline-depth"))
+    ap.add_argument("--env", default="", help="bench sweep: NAME=v1,v2,...")
+    ap.add_argument("--args", default="", help="bench sweep: further bench.py arguments")
+    ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("what", choices=("bench", "bounce-block", "bounce-park", "bounce-tail", "bounce-depth", "k2c-shape", "k2c-depth", "headline-depth"))
     ap.add_argument("--reps", type=int, default=0)
     args = ap.parse_args()
     rows = []
-    if args.what == "bounce-block":
+    if args.what == "bench":
+        name, _, values = args.env.partition("=")
+        if not name or not values:
+            ap.error("bench needs --env NAME=v1,v2,...")
+        for v in values.split(","):
+            for _ in range(args.repeat):
+                extra = args.args.split()
+                r = bench_point({}, extra + [name, v]) if name.startswith("--") else bench_point({name: v}, extra)
+                rows.append(dict({name: v}, **r))
+                print(rows[-1], flush=True)
+    elif args.what == "bounce-block":
         for block in (256, 512, 1024):
             for park in (16, 32):
                 r = point("bounce", 20, args.reps or 120, {"BGS_BOUNCE_BLOCK": block, "BGS_BOUNCE_PARK": park})

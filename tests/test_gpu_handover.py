@@ -293,6 +293,34 @@ def test_connect_policy_loop_on_device_tensors(bm, torch_mod):
     dev.close()
 
 
+def test_a_refused_hand_over_does_not_poison_the_sink(bm):
+    """Round-3 advisor: bgs_sink_rollout claimed its ticket before the rollout's arguments were checked, so a plain argument
+    error was published as a failed delivery and the sink's sticky flag failed EVERY later wait.  Arguments are now refused
+    before a ticket exists, and failures belong to tickets: after the refusal the sink delivers as before."""
+    n = 4096
+    dev = bm.ConnectBatch(6, 7, 4, n)
+    sink = bm.RewardSink(n, slots=2, threads=2)
+    host = np.zeros((n, 2), dtype=np.int8)
+    t0 = sink.rollout(dev, host, SEED, from_initial=True)
+    with pytest.raises(ValueError):
+        sink.rollout(dev, host, SEED + 1, max_plies=-1, from_initial=True)      # refused: no ticket was taken
+    with pytest.raises(ValueError):
+        sink.rollout(dev, np.zeros((n - 1, 2), dtype=np.int8), SEED + 1, from_initial=True)
+    sink.wait(t0)
+    orc = oracle.ConnectOracle(6, 7, 4, n)
+    orc.rollout(SEED)
+    np.testing.assert_array_equal(host, orc.reward)
+    for k in range(5):   # tickets go on where they were; every delivery is good
+        t = sink.rollout(dev, host, SEED + 10 + k, from_initial=True)
+        assert t == t0 + 1 + k
+        sink.wait(t)
+        orc.reset()
+        orc.rollout(SEED + 10 + k)
+        np.testing.assert_array_equal(host, orc.reward)
+    sink.close()
+    dev.close()
+
+
 @pytest.mark.parametrize("geometry,n", [((6, 7, 4), 1 << 16), ((6, 7, 4), 1022), ((4, 5, 3), 3000), ((8, 8, 5), 2048),
                                          ((6, 7, 4), 4097), ((12, 13, 5), 1024), ((20, 20, 5), 256)])
 def test_one_call_per_policy_ply_connect(bm, torch_mod, geometry, n):

@@ -432,6 +432,45 @@ def test_bounce_flat_rollout_shared_drain_protocol(batch_mod, park, waves, chunk
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("pool,park,waves,chunk", [("1", "40", "0", "0"), ("1", "63", "128", "32"), ("1", "3", "512", "64"),
+                                                   ("1", "32", "8", "32"), ("0", "40", "0", "0"), ("1", "40", "1024", "32")])
+def test_bounce_device_wide_pool_of_parked_boards(batch_mod, pool, park, waves, chunk):
+    """Round 4: the last wave of a workgroup parks its last boards in GLOBAL memory for the last waves of other workgroups
+    (K3p's device-wide pool), and boards leave the kernel as piece positions that a follow-up kernel turns into value
+    planes.  Parking thresholds 3 / 32 / 40 / 63, a handful and a thousand waves, the pool off: every board finished exactly
+    once and equal to the oracle (grids, rewards, plies, status, step count), uncapped and with caps that stop every
+    board of a wave in the same iteration (the race that loses parked boards), repeated."""
+    import os
+
+    env = {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_POOL": pool, "BGS_BOUNCE_PIECES_PARK": park}
+    if waves != "0":
+        env["BGS_BOUNCE_FLAT_WAVES"] = waves
+    if chunk != "0":
+        env["BGS_BOUNCE_CHUNK"] = chunk
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for n in (4099, 20011, 70001):
+            want = {}
+            for cap in (3000, 7, 2):
+                orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+                want[cap] = (orc.rollout(SEED ^ n, first_game=n, max_plies=cap), orc)
+            for rep in range(3):
+                for cap in (3000, 7, 2):
+                    dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+                    dev.set_first_game(n)
+                    dev.rollout(SEED ^ n, max_plies=cap, from_initial=True)
+                    assert_same(dev, want[cap][1], f"pool {pool} park {park} waves {waves} n={n} cap={cap} rep {rep}")
+                    assert dev.steps == want[cap][0], (n, cap, rep, dev.steps, want[cap][0])
+                    dev.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("pieces", ["1", "0"])
 def test_bounce_short_caps_leave_no_parked_board_behind(batch_mod, pieces):
     """With a ply cap every board of a wave stops in the same iteration.  The last wave of a workgroup used to leave then --

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_* (tools/profile_all.sh) -> profiles/r03_*.json, including profiles/r03_rollout_counters.json, the
-per-launch PMC figures of the bench kernel that bench.py quotes when its build id matches the running library."""
+"""gpurun_out/prof_* (tools/profile_all.sh) -> profiles/<round>_*.json (round: BGS_PROFILE_ROUND, default r04), including
+profiles/<round>_rollout_counters.json, the per-launch PMC figures of the bench kernel that bench.py quotes when its build
+id matches the running library."""
 import json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
 OUT = os.path.join(ROOT, "profiles")
+ROUND = os.environ.get("BGS_PROFILE_ROUND", "r04")
 
 
 def summary(tag, want=""):
@@ -24,10 +26,10 @@ def main():
     build = _abi.build_id()
     method = ("tools/profile_all.sh: rocprofv3 --kernel-trace --stats, then --pmc in separate passes (SQ_*; FETCH_SIZE; "
               "WRITE_SIZE), per-dispatch means; FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads), KiB -> B")
-    for tag, want, name in (("bench", "k_connect_rollout_opened", "r03_bench_kernel.json"), ("k1", "step_random", "r03_k1.json"),
-                            ("k2c", "_lds", "r03_k2c.json"), ("k2b", "k_connect_rollout_aligned_wide", "r03_k2b.json"),
-                            ("bounce", "k_bounce", "r03_bounce.json"), ("bounce_solo", "k_bounce", "r03_bounce_solo.json"), ("bounce_k3f", "k_bounce", "r03_bounce_k3f.json"),
-                            ("bounce8", "k_bounce_rollout", "r03_bounce_lane_groups.json")):
+    for tag, want, name in (("bench", "k_connect_rollout_opened", f"{ROUND}_bench_kernel.json"), ("k1", "step_random", f"{ROUND}_k1.json"),
+                            ("k2c", "_lds", f"{ROUND}_k2c.json"), ("k2b", "k_connect_rollout_aligned_wide", f"{ROUND}_k2b.json"),
+                            ("bounce", "k_bounce", f"{ROUND}_bounce.json"), ("bounce_solo", "k_bounce", f"{ROUND}_bounce_solo.json"), ("bounce_k3f", "k_bounce", f"{ROUND}_bounce_k3f.json"),
+                            ("bounce8", "k_bounce_rollout", f"{ROUND}_bounce_lane_groups.json")):
         try:
             s = summary(tag, want)
         except Exception as exc:  # a tag that was not profiled in this pass
@@ -76,11 +78,11 @@ def main():
         with open(os.path.join(OUT, name), "w") as fh:
             json.dump(dict({"build_id": build, "method": method}, **total, **extra, kernels=s), fh, indent=1)
     misc = summary("misc")
-    with open(os.path.join(OUT, "r03_misc_kernel_stats.json"), "w") as fh:
+    with open(os.path.join(OUT, f"{ROUND}_misc_kernel_stats.json"), "w") as fh:
         json.dump({"build_id": build, "command": "rocprofv3 --kernel-trace --stats -- python3 tools/measure_all.py", "kernels": misc}, fh, indent=1)
     mfile = os.path.join(ROOT, "gpurun_out", "measure_all.json")
     if os.path.exists(mfile) and os.path.getsize(mfile):
-        with open(mfile) as fh, open(os.path.join(OUT, "r03_secondary_measurements.json"), "w") as out:
+        with open(mfile) as fh, open(os.path.join(OUT, f"{ROUND}_secondary_measurements.json"), "w") as out:
             out.write(fh.read())
     bench = summary("bench", "k_connect_rollout_opened")
     k = next(iter(bench.values()))
@@ -109,7 +111,7 @@ def main():
         "method": method + "; command: python3 bench.py --steps 10 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-device-resident --no-other-configs --no-repeats; "
         "mix_cycles_per_instruction from tools/valu_mix.py",
     }
-    with open(os.path.join(OUT, "r03_rollout_counters.json"), "w") as fh:
+    with open(os.path.join(OUT, f"{ROUND}_rollout_counters.json"), "w") as fh:
         json.dump(counters, fh, indent=1)
     print(json.dumps({kk: counters[kk] for kk in ("build_id", "valu_wave_instructions_per_launch", "hbm_bytes_per_launch",
                                                   "active_lanes_per_valu_instruction", "mean_us")}))

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-3 profiles of every kernel of the path, one command (on the GPU box):  bash tools/profile_all.sh
+# Profiles of every kernel of the path, one command (on the GPU box):  bash tools/profile_all.sh
 # Each kernel gets rocprofv3 --kernel-trace --stats, an SQ counter pass and separate FETCH_SIZE / WRITE_SIZE passes
 # (tools/profile_kernel.sh: the program directly after "--"); tools/collect_profiles.py turns the CSVs into
-# profiles/r03_*.json and the counters file bench.py reads (keyed by the library's build id).
+# profiles/<round>_*.json and the counters file bench.py reads (keyed by the library's build id).
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 # K2a: the bench itself (hand-over included), 12 timed launches in the counter passes
@@ -17,12 +17,12 @@ bash tools/profile_kernel.sh k1 python3 tools/k1_steps.py
 bash tools/profile_kernel.sh k2c python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9
 # K3: Bounce 9x6, 2^18 boards, max_plies 4096: the piece-list kernel + tail pass (default at this size), the flat cell
 # search it replaces (K3f, one launch) and lane-group mode
-# (the launch shape follows the launches-in-flight hint: "bounce" = the shape of 16 in flight, which bench.py's
+# (the launch shape follows the launches-in-flight hint: "bounce" = the shape of 20 in flight, which bench.py's
 # other_configs runs, counted one launch at a time; "bounce_solo" = the shape of a launch that is alone)
-bash tools/profile_kernel.sh bounce python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 16
+bash tools/profile_kernel.sh bounce python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 20
 bash tools/profile_kernel.sh bounce_solo python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 1
-BGS_BOUNCE_PIECES=0 BGS_BOUNCE_PLAN=single bash tools/profile_kernel.sh bounce_k3f python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 16
-BGS_BOUNCE_GROUP=8 bash tools/profile_kernel.sh bounce8 python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 16
+BGS_BOUNCE_PIECES=0 BGS_BOUNCE_PLAN=single bash tools/profile_kernel.sh bounce_k3f python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 20
+BGS_BOUNCE_GROUP=8 bash tools/profile_kernel.sh bounce8 python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 20
 # K2b: the register kernel K2c replaced on 12x13x5, for the instruction-count comparison
 BGS_ROLLOUT_NO_LDS=1 bash tools/profile_kernel.sh k2b python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9
 # K4 and the rest (reset, unpack, legal, ...): kernel stats only
@@ -32,3 +32,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_misc_
 cd $R
 python3 tools/valu_mix.py > gpurun_out/valu_mix.json
 python3 tools/collect_profiles.py
+# the hardware busy counters (VALU busy, dual issue, wave-time split) of the rollout kernels
+bash tools/busy_counters.sh
+python3 tools/busy_counters.py

@@ -327,6 +327,11 @@ def valu_issue_block(counters, why_not, seconds_per_launch, build):
         "counters_file": counters.get("file"),
         "kernels": counters.get("kernel"),
     }
+    # The chip's own busy measure, live: rocprofv3 counts exactly one quad-cycle of SQ_ACTIVE_INST_VALU per wave64 VALU
+    # instruction on gfx950 (profiles/r04_valu_busy.json: the two counters agree to the digit on every kernel), so VALUBusy =
+    # instructions per SIMD per quad-cycle = achieved / (1024 SIMDs x 2.4 GHz / 4).  Above 1: the SIMDs started two
+    # instructions in some quad-cycles (SQ_ACTIVE_INST_VALU2).
+    out["valu_busy_from_rate"] = rate / (VALU_PEAK_SIMD32 / 2.0)
     if counters.get("mix_cycles_per_instruction"):
         mix_peak = VALU_PEAK_SIMD32 * 2.0 / counters["mix_cycles_per_instruction"]
         out["mix_ceiling"] = {"Ginstr_per_s": mix_peak, "frac": rate / mix_peak,
@@ -357,6 +362,10 @@ def run_other_config(name: str, steps: int) -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the rollout engine has no CPU fallback", file=sys.stderr)
         return 2
+    if os.environ.get("BGS_BIND_NUMA", "1") != "0":   # launching thread and sink workers next to the GPU, as the headline
+        import ctypes
+
+        _abi.check(_abi.lib().bgs_bind_host_thread(0, ctypes.byref(ctypes.c_int(0))))
     grid = np.array(BOUNCE_GRID, dtype=np.int8)
 
     def make(count):

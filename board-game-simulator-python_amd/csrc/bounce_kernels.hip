@@ -673,6 +673,7 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             taken = avail - taken < wanted ? avail : taken + wanted;
         }
         const bool draining = dry && taken >= avail;  // (wave-uniform) nothing left to draw
+        bool adopted_now = false;   // (wave-uniform) this iteration's adoption attempt found something
         if (draining && need) {
             // ---- idle lanes adopt parked boards.  count[] and head[] are adjacent: lanes 0..7 fetch them in one access
             const uint32_t wanted = (uint32_t)__popcll(need);
@@ -704,6 +705,7 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
                     assigned += got;
                 }
             }
+            adopted_now = assigned != 0u;
         }
 
         // ---- the action lists of the boards that need one (new boards, boards that have just moved); a board whose
@@ -744,7 +746,9 @@ k_bounce_rollout_flat(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             // The last wave leaves only after an adoption attempt with ALL its lanes idle has found nothing: if its
             // lanes were busy at the top of this iteration and their boards all stopped in it (a ply cap does that), the
             // boards other waves parked meanwhile would otherwise never be played.
-            if (last && need != ~0ull) continue;
+            // (... NOTHING: boards adopted in this very iteration may all have stopped in it -- a ply cap does that -- with
+            // more still parked; round 4, found on the Connect kernel that shares the protocol)
+            if (last && (need != ~0ull || adopted_now)) continue;
             if (last) break;
             if (leave() > 1u) break;    // others are still running: whatever gets parked later is theirs
             last = true;                // everybody else has left: sweep up what they parked
@@ -1185,6 +1189,7 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
             taken = avail - taken < wanted ? avail : taken + wanted;
         }
         const bool draining = dry && taken >= avail;  // (wave-uniform) nothing left to draw
+        bool adopted_now = false;     // (wave-uniform) this iteration's adoption attempt found something
         bool lds_exhausted = false;   // this iteration's adoption attempt took everything the workgroup's LDS pool held
 #ifdef BGS_BOUNCE_STATS
         if (draining) ++stat_drain_iters;
@@ -1276,6 +1281,7 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
                 }
             }
             if (__builtin_amdgcn_ballot_w64(adopted_one)) {
+                adopted_now = true;
                 PieceBoard<PMAX> fresh = b;
                 pieces_rebuild(g, fresh);
                 if (adopted_one) b = fresh;
@@ -1323,7 +1329,7 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
             // The last wave leaves only after an adoption attempt with ALL its lanes idle has found nothing: if its
             // lanes were busy at the top of this iteration and their boards all stopped in it (a ply cap does that), the
             // boards other waves parked meanwhile would otherwise never be played.
-            if (last && need != ~0ull) continue;
+            if (last && (need != ~0ull || adopted_now)) continue;   // (boards adopted in this very iteration may all have stopped in it)
             if (last) {
                 // the workgroup is done.  The launch: whoever is not its last wave simply goes; the last one sweeps the
                 // device-wide pool (an attempt with all lanes idle has just found nothing: it is empty)

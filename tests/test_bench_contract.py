@@ -1,4 +1,4 @@
-"""bench.py's output contract, checked on the committed round-2 bench line (CPU only), and its loud failure
+"""bench.py's output contract, checked on the committed round-4 bench lines (CPU only), and its loud failure
 without a GPU."""
 
 import json
@@ -17,7 +17,7 @@ def _line(name):
 
 
 def test_committed_bench_line_has_every_contract_field():
-    d = _line("r03_bench.json")
+    d = _line("r04_bench.json")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -38,7 +38,14 @@ def test_committed_bench_line_has_every_contract_field():
     for key in ("value", "unit", "cores", "kind", "sample", "single_game_latency_us"):
         assert key in cpu, key
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and "restatement" in cpu["sample"]
+    assert cpu["kind_note"].startswith("restatement") and cpu["all_cores"]["cores"] >= cpu["cores"] and cpu["all_cores"]["value"] > 0
     assert cpu["parity_with_host_rewards"] is True
+    # round 4: the chip's own busy counters beside the instruction-rate fraction, and one launch at a time beside `value`
+    busy = roof["valu_busy"]
+    assert busy["counters_file"].startswith("r04_") and 0.85 < busy["valu_busy_frac"] < 1.0 == (roof["valu_busy_frac"] > 0)
+    assert abs(sum(busy["wave_time_split"].values()) - 1.0) < 0.02 and 0 < busy["frac_of_quad_cycles_with_two_valu_issued"] < 0.5
+    assert roof["valu_busy_from_rate"] == pytest.approx(roof["achieved"] / 614.4)
+    assert d["solo"]["rewards_to_host"] is False and 0.3 * d["value"] < d["solo"]["value"] < d["value"]
     assert d["value"] > 1e9  # the north star's floor was 1e9 env-steps/s on EIGHT GPUs
     assert d["value"] >= 0.9 * d["device_resident"]["value"]  # the hand-over costs less than 10 % of the device-resident rate
     assert len(d["values_of_3"]) == 3 and d["value"] == d["values_of_3"][0]
@@ -46,21 +53,23 @@ def test_committed_bench_line_has_every_contract_field():
     for name, floor in (("connect_12x13x5", 1e11), ("bounce_default", 5e9)):   # BASELINE configs 3 and 4 in the same line
         o = d["other_configs"][name]
         assert o["parity_with_oracle"] is True and o["value"] > floor and o["solo"]["value"] > 0
-        assert o["valu_issue"]["frac"] is not None and o["valu_issue"]["counters_file"].startswith("r03_")
-    assert d["grids_to_host"]["value"] > 2e10 and d["grids_to_host"]["host_grids_equal_device_grids"] is True
+        assert o["valu_issue"]["frac"] is not None and o["valu_issue"]["counters_file"].startswith("r04_")
+        assert o["valu_busy"]["counters_file"].startswith("r04_")
+    assert d["other_configs"]["bounce_default"]["value"] > 1.2e10   # round 3: 1.05e10
+    assert d["grids_to_host"]["value"] > 5e9 and d["grids_to_host"]["host_grids_equal_device_grids"] is True
 
 
 def test_short_run_stays_close_to_the_long_one():
     """The driver times 20 steps: pre-warm, the native loop and the polled last delivery keep that figure within 20 % of
     the 200-step one (round 2: 13 % below at 5.7e11, with outliers to -40 %), and its three regions within 8 % of each other."""
-    long, short = _line("r03_bench.json"), _line("r03_bench_steps20.json")
+    long, short = _line("r04_bench.json"), _line("r04_bench_steps20.json")
     # (the median of the three regions: on the shared test hosts any single 0.7 ms region can be hit by a neighbour)
     assert short["steps"] == 20 and short["value_median_of_3"] > 0.88 * long["value_median_of_3"]
     assert short["value"] > 0.8 * long["value"]
 
 
 def test_counters_file_names_its_build():
-    with open(os.path.join(ROOT, "profiles", "r03_rollout_counters.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r04_rollout_counters.json")) as fh:
         c = json.load(fh)
     assert len(c["build_id"]) == 16 and c["valu_wave_instructions_per_launch"] > 1e6
     assert 2.0 < c["mix_cycles_per_instruction"] < 6.0

@@ -389,8 +389,10 @@ def run_other_config(name: str, steps: int) -> int:
         return sum(b.steps for b in batches) / dt, dt / count * 1e3
 
     # host arrays / sink slots per stream: deliveries complete in ticket order, and a Bounce step's duration varies with its
-    # longest games -- three per stream let the launching thread run past a slow stream (2 -> 3: 1.34 -> 1.37 x 10^10)
-    slots = min(64, int(os.environ.get("BGS_BENCH_OTHER_SLOT_FACTOR", "3" if name == "bounce_default" else "2")) * depth)
+    # longest games (a tail pass of 3.6 ms on one stream beside steps of 1 ms on the others) -- enough slots let the
+    # launching thread run past a slow stream: 2 / 3 / 5 / 8 per stream read 1.24 / 1.33-1.38 / 1.33-1.37 / 1.36-1.38 x 10^10
+    # against 1.38-1.42 device-resident (tools/bounce_slots_probe.sh)
+    slots = min(256, int(os.environ.get("BGS_BENCH_OTHER_SLOT_FACTOR", "6" if name == "bounce_default" else "2")) * depth)
     streams, batches = make(depth)
     hosts = [np.zeros((n, 2), dtype=np.int8) for _ in range(slots)]
     sink = RewardSink(n, slots=slots, threads=4, device=0)

@@ -646,8 +646,8 @@ static int make_sink(int device, int64_t max_games, int slots, int threads, size
                      bgs_reward_sink** out) {
     NEED(out != nullptr, "out is NULL");
     *out = nullptr;
-    NEED(max_games >= 1 && slots >= 1 && slots <= 64 && threads >= 1 && threads <= 256,
-         "need max_games >= 1, 1 <= slots <= 64, 1 <= threads <= 256");
+    NEED(max_games >= 1 && slots >= 1 && slots <= 256 && threads >= 1 && threads <= 256,
+         "need max_games >= 1, 1 <= slots <= 256, 1 <= threads <= 256");
     int rc = enter_device(device);
     if (rc) return rc;
     bgs_reward_sink* s = new (std::nothrow) bgs_reward_sink();

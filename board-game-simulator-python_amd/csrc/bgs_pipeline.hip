@@ -109,8 +109,8 @@ int bgs_pipeline_create(bgs_batch* const* batches, int depth, bgs_reward_sink* s
     NEED(depth >= 1 && depth <= 64, "depth must be in 1..64");
     NEED(!(sink && gather), "a pipeline hands over through a sink OR a gather");
     NEED(max_plies >= 0, "max_plies must be >= 0");
-    NEED((sink || gather) ? (host_rewards != nullptr && n_host >= 1 && n_host <= 64) : n_host == 0,
-         "a hand-over needs 1..64 host arrays, a pipeline without one takes none");
+    NEED((sink || gather) ? (host_rewards != nullptr && n_host >= 1 && n_host <= 256) : n_host == 0,
+         "a hand-over needs 1..256 host arrays, a pipeline without one takes none");
     for (int k = 0; k < depth; ++k) {
         NEED(batches[k] != nullptr, "batch %d is NULL", k);
         NEED(batches[k]->device == batches[0]->device && batches[k]->n == batches[0]->n, "the batches must be alike");

@@ -182,7 +182,11 @@ class RolloutPipeline:
             raise ValueError("depth must be >= 1")
         depth = usable_depth(depth, explicit)   # (before torch touches the GPU: the queues can still be asked for)
         if not explicit:
-            arrays_per_stream = min(arrays_per_stream, max(1, 48 // depth))
+            # Bounce: deliveries complete in step order and a step's duration varies with its longest games, so the launching
+            # thread needs room to run past a slow stream (bench: 2 / 3 / 8 arrays per stream = 1.24 / 1.35 / 1.37 x 10^10)
+            if getattr(batch_cls, "game", 0) == _abi.GAME_BOUNCE:
+                arrays_per_stream = max(arrays_per_stream, 6)
+            arrays_per_stream = min(arrays_per_stream, max(1, 256 // depth))
         import torch
 
         self.n, self.depth, self.max_plies = int(n), int(depth), int(max_plies)

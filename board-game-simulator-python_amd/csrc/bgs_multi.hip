@@ -302,7 +302,12 @@ struct bgs_gather {
     std::vector<int64_t> cover_seq;      // [slots] sequence number of the group the slot's last step left in ...
     std::vector<int> cover_ev;           // [slots] ... and the slot whose `sent` event was recorded behind that group
     int64_t group_seq = 0;
-    std::vector<std::pair<hipStream_t, int64_t>> waited;  // launch stream -> newest group it has been told to wait for
+    struct Waited {
+        hipStream_t stream;
+        int64_t seq;    // newest group the stream has been told to wait for
+        int64_t step;   // ... at this step (an entry older than `slots` steps is not trusted: the handle may be a new stream's)
+    };
+    std::vector<Waited> waited;
     bgs_reward_sink* sink = nullptr;     // rank 0
     std::mutex mu;
     std::condition_variable cv;
@@ -634,14 +639,15 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
             // one wait per launch stream and GROUP, not per step: a stream that has been told to wait for a group has
             // waited for every earlier one (the communication stream runs them in order)
             wait_seq = g->cover_seq[slot];
-            auto it = std::find_if(g->waited.begin(), g->waited.end(), [&](const std::pair<hipStream_t, int64_t>& w) { return w.first == b->stream; });
+            auto it = std::find_if(g->waited.begin(), g->waited.end(), [&](const bgs_gather::Waited& w) { return w.stream == b->stream; });
             if (it == g->waited.end()) {
                 if (g->waited.size() >= 256) g->waited.clear();   // (streams come and go: forgetting one costs a redundant wait)
-                g->waited.emplace_back(b->stream, wait_seq);
+                g->waited.push_back({b->stream, wait_seq, t});
                 wait_ev = g->cover_ev[slot];
-            } else if (it->second < wait_seq) {
-                it->second = wait_seq;
-                wait_ev = g->cover_ev[slot];
+            } else {
+                if (it->seq < wait_seq || t - it->step > g->slots) wait_ev = g->cover_ev[slot];
+                it->seq = std::max(it->seq, wait_seq);
+                it->step = t;
             }
         }
     }

@@ -1010,8 +1010,23 @@ def main() -> int:
             extra["other_configs"] = other_configs()
     emit(extra)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        # The ranks part company here.  If a hand-over failed on some rank only, the others may never reach this barrier:
+        # it is given half a minute, then the process ends as it is -- the line has been printed.
+        done = threading.Event()
+
+        def part():
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            finally:
+                done.set()
+
+        threading.Thread(target=part, daemon=True).start()
+        if not done.wait(30.0 if any("error" in r for r in results) else 120.0):
+            print(f"bench.py: rank {rank}: the closing barrier did not complete; leaving", file=sys.stderr)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
     return 0
 
 

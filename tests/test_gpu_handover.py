@@ -321,12 +321,12 @@ def test_a_refused_hand_over_does_not_poison_the_sink(bm):
     dev.close()
 
 
-@pytest.mark.parametrize("geometry,n", [((6, 7, 4), 1 << 16), ((6, 7, 4), 1022), ((4, 5, 3), 3000), ((8, 8, 5), 2048),
+@pytest.mark.parametrize("geometry,n", [((6, 7, 4), 1 << 20), ((6, 7, 4), 1 << 16), ((6, 7, 4), 1022), ((4, 5, 3), 3000), ((8, 8, 5), 2048),
                                          ((6, 7, 4), 4097), ((12, 13, 5), 1024), ((20, 20, 5), 256)])
 def test_one_call_per_policy_ply_connect(bm, torch_mod, geometry, n):
     """bgs_step_actions_observe: the chosen moves, the NEXT legal mask, the ended flags and the per-board results in one
     call -- one kernel for one-word boards and an even batch (config 2's geometry, a smaller and a larger one-word board,
-    batch sizes around the workgroup boundary), the separate kernels back to back otherwise (odd batch, multi-word and
+    the BASELINE batch of 2^20 boards and sizes around the workgroup boundary), the separate kernels back to back otherwise (odd batch, multi-word and
     generic boards) -- against the oracle's step_actions + legal() + ended, ply by ply, with refused moves (column out of
     range, full column, boards that have ended) in between."""
     torch = torch_mod

@@ -580,7 +580,8 @@ def main() -> int:
     # that holds a HIP context keeps hardware queues mapped, and the Bounce child's 20 streams then share the queue slots
     # with them (1.29 against 1.37 x 10^10 with the parent's context alive)
     early_other = None
-    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and os.environ.get("BGS_FORCE_DIST") != "1" and not args.no_other_configs:
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and os.environ.get("BGS_FORCE_DIST") != "1" and not args.no_other_configs
+            and os.path.exists("/dev/kfd")):   # (no GPU driver, no children: the refusal below comes at once)
         early_other = other_configs()
 
     from simulator.game import _abi

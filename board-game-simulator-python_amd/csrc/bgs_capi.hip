@@ -872,28 +872,42 @@ int bgs_step_actions(bgs_batch* b, const int32_t* actions, int actions_on_device
     return BGS_OK;
 }
 
-int bgs_step_actions_observe(bgs_batch* b, const int32_t* device_actions, void* device_observation, uint8_t* device_ended,
-                             int32_t* device_status) {
+int bgs_env_step(bgs_batch* b, const int32_t* device_actions, void* device_observation, uint8_t* device_ended,
+                 int8_t* device_reward, int32_t* device_status, uint32_t flags) {
     int rc = enter(b);
     if (rc) return rc;
     NEED(device_actions != nullptr && device_observation != nullptr, "actions and the observation's destination must not be NULL");
+    NEED((flags & ~(uint32_t)BGS_ENV_AUTO_RESET) == 0, "unknown flags 0x%x", flags);
     NEED(!b->generic || b->game == BGS_GAME_CONNECT, "generic Bounce boards have no 64-bit target masks (see bgs_export_device 't')");
-    // one-word Connect boards, even batch: the moves, the legal mask and the ended flags in ONE pass over the batch
+    const bool auto_reset = (flags & BGS_ENV_AUTO_RESET) != 0;
+    NEED(!auto_reset || !b->generic, "BGS_ENV_AUTO_RESET needs a bit-packed board (Connect up to 192 bits, Bounce up to 64 cells)");
+    // one-word Connect boards, even batch: moves, rewards, ended flags, reset and the legal mask in ONE pass over the batch
     if (!b->generic && b->game == BGS_GAME_CONNECT &&
-        bgs::connect_step_observe(b, device_actions, device_status, static_cast<uint8_t*>(device_observation), device_ended))
+        bgs::connect_step_observe(b, device_actions, device_status, static_cast<uint8_t*>(device_observation), device_ended,
+                                  device_reward, auto_reset))
         return finish_launch();
     // everything else: the same result from the kernels of the separate calls, enqueued back to back
     if (b->generic) bgs::generic_step_actions(b, device_actions, device_status);
     else if (b->game == BGS_GAME_CONNECT) bgs::connect_step_actions(b, device_actions, device_status);
     else bgs::bounce_step_actions(b, device_actions, device_status);
+    if (device_ended) bgs::status_to_ended(b, device_ended);
+    if (device_reward) HIP_TRY(hipMemcpyAsync(device_reward, b->d_reward, (size_t)b->n * 2, hipMemcpyDeviceToDevice, b->stream));
+    if (auto_reset) {
+        if (b->game == BGS_GAME_CONNECT) bgs::connect_reset_ended(b);
+        else bgs::bounce_reset_ended(b);
+    }
     if (b->game == BGS_GAME_CONNECT) {
         if (b->generic) bgs::generic_connect_legal(b, static_cast<uint8_t*>(device_observation), nullptr);
         else bgs::connect_legal(b, static_cast<uint8_t*>(device_observation), nullptr);
     } else {
         bgs::bounce_targets(b, static_cast<uint64_t*>(device_observation), nullptr);
     }
-    if (device_ended) bgs::status_to_ended(b, device_ended);
     return finish_launch();
+}
+
+int bgs_step_actions_observe(bgs_batch* b, const int32_t* device_actions, void* device_observation, uint8_t* device_ended,
+                             int32_t* device_status) {
+    return bgs_env_step(b, device_actions, device_observation, device_ended, nullptr, device_status, 0u);
 }
 
 int bgs_rollout(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {

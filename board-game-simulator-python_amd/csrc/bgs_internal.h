@@ -138,7 +138,10 @@ namespace bgs {
 void connect_reset(const bgs_batch* b);
 void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count);  // count plies per board
 void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out);
-bool connect_step_observe(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out, uint8_t* d_legal, uint8_t* d_ended);
+bool connect_step_observe(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out, uint8_t* d_legal, uint8_t* d_ended,
+                          int8_t* d_reward_out, bool auto_reset);
+void connect_reset_ended(const bgs_batch* b);   // boards that have ended -> the initial state (packed boards)
+void bounce_reset_ended(const bgs_batch* b);
 void status_to_ended(const bgs_batch* b, uint8_t* d_ended);  // uint8[n]: the board has ended (any game)
 void connect_transition(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
                         int8_t* d_winner, int32_t* d_plies, uint8_t* d_legal, int8_t* d_reward_out);

@@ -182,9 +182,10 @@ __device__ __forceinline__ void store_board(uint64_t* __restrict__ planes, int64
 
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_reset(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies,
-               uint16_t* __restrict__ reward, int64_t n) {
+               uint16_t* __restrict__ reward, int64_t n, int only_ended) {
     const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (only_ended && status[i] == 0) return;   // (bgs_env_step with BGS_ENV_AUTO_RESET: finished boards start over)
 #pragma unroll
     for (int j = 0; j < 4; ++j) planes[(int64_t)j * n + i] = g.init[j];
     status[i] = (uint8_t)g.init_status;
@@ -1661,7 +1662,12 @@ inline unsigned grid_for(int64_t n) { return (unsigned)((n + BGS_BLOCK - 1) / BG
 
 void bounce_reset(const bgs_batch* b) {
     hipLaunchKernelGGL(k_bounce_reset, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->d_status,
-                       b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n);
+                       b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, 0);
+}
+
+void bounce_reset_ended(const bgs_batch* b) {
+    hipLaunchKernelGGL(k_bounce_reset, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->d_status,
+                       b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, 1);
 }
 
 void bounce_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {

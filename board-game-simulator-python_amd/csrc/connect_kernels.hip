@@ -276,9 +276,10 @@ __device__ __forceinline__ void store_planes(uint64_t* __restrict__ planes, int6
 // ------------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(BGS_BLOCK) k_connect_reset(uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
-                                                             uint16_t* __restrict__ reward, int64_t n, int words) {
+                                                             uint16_t* __restrict__ reward, int64_t n, int words, int only_ended) {
     const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (only_ended && status[i] == 0) return;   // (bgs_env_step with BGS_ENV_AUTO_RESET: finished boards start over)
     for (int j = 0; j < words; ++j) planes[(int64_t)j * n + i] = 0;
     status[i] = 0;
     reward[i] = 0;
@@ -750,7 +751,8 @@ template <class G>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_step_observe(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                        int64_t n, const int32_t* __restrict__ actions, int32_t* __restrict__ result,
-                       uint8_t* __restrict__ legal, uint8_t* __restrict__ ended, unsigned long long* __restrict__ steps) {
+                       uint8_t* __restrict__ legal, uint8_t* __restrict__ ended, unsigned long long* __restrict__ steps,
+                       uint16_t* __restrict__ reward_out, uint32_t auto_reset) {
     extern __shared__ __attribute__((aligned(16))) uint8_t legal_tile[];   // [2 * BGS_BLOCK boards][W] bytes, in output order
     const int64_t pairs = n >> 1;
     const int h = g.h(), w = g.w();
@@ -800,6 +802,18 @@ k_connect_step_observe(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__
                 }
             }
         }
+        // what the caller learns about the boards AFTER the move: ended flags and, for a vector environment, the reward pairs
+        if (ended) reinterpret_cast<uint16_t*>(ended)[t] = (uint16_t)((st[0] != 0u ? 1u : 0u) | (st[1] != 0u ? 256u : 0u));
+        if (reward_out) reinterpret_cast<uint32_t*>(reward_out)[t] = (uint32_t)reward_pair(st[0]) | ((uint32_t)reward_pair(st[1]) << 16);
+        if (auto_reset) {   // a finished board starts over in the same pass: the observation below is the new game's
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (st[q] != BGS_ST_RUNNING) {
+                    p[q][0] = p[q][1] = 0;
+                    st[q] = BGS_ST_RUNNING;
+                    moved[q] = true;   // (the board in memory changes)
+                }
+        }
         if (moved[0] | moved[1]) {
             // one ply changes only the mover's plane: a plane neither board of the pair changed is not stored
             if (p[0][0] != a.x || p[1][0] != a.y) reinterpret_cast<ulonglong2*>(planes)[t] = ulonglong2{p[0][0], p[1][0]};
@@ -810,7 +824,6 @@ k_connect_step_observe(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__
             }
         }
         if (result) reinterpret_cast<int2*>(result)[t] = int2{rc[0], rc[1]};
-        if (ended) reinterpret_cast<uint16_t*>(ended)[t] = (uint16_t)((st[0] != 0u ? 1u : 0u) | (st[1] != 0u ? 256u : 0u));
         // the observation AFTER the move: which columns the side to move may play
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -1899,7 +1912,12 @@ void dispatch(const ConnectGeom& cg, F&& f) {
 
 void connect_reset(const bgs_batch* b) {
     hipLaunchKernelGGL(k_connect_reset, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->d_planes, b->d_status,
-                       reinterpret_cast<uint16_t*>(b->d_reward), b->n, b->planes);
+                       reinterpret_cast<uint16_t*>(b->d_reward), b->n, b->planes, 0);
+}
+
+void connect_reset_ended(const bgs_batch* b) {
+    hipLaunchKernelGGL(k_connect_reset, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->d_planes, b->d_status,
+                       reinterpret_cast<uint16_t*>(b->d_reward), b->n, b->planes, 1);
 }
 
 // geometry + board policy: nibble column state where it applies (one word, W <= 8, H <= 8), generic otherwise
@@ -1959,9 +1977,10 @@ void connect_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t*
 }
 
 // true: the fused kernel ran (one-word board, even batch, 16-byte aligned legal destination); false: nothing was enqueued
-bool connect_step_observe(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out, uint8_t* d_legal, uint8_t* d_ended) {
+bool connect_step_observe(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out, uint8_t* d_legal, uint8_t* d_ended,
+                          int8_t* d_reward_out, bool auto_reset) {
     if (b->cg.nw != 1 || (b->n & 1) || b->n < 2 || ((uintptr_t)d_legal & 15u) || ((uintptr_t)d_actions & 7u) ||
-        ((uintptr_t)d_status_out & 7u) || ((uintptr_t)d_ended & 1u))
+        ((uintptr_t)d_status_out & 7u) || ((uintptr_t)d_ended & 1u) || ((uintptr_t)d_reward_out & 3u))
         return false;
     const size_t tile = (size_t)2 * BGS_BLOCK * b->cg.w;
     dispatch(b->cg, [&](auto g) {
@@ -1969,7 +1988,7 @@ bool connect_step_observe(const bgs_batch* b, const int32_t* d_actions, int32_t*
         if constexpr (G::NW == 1) {
             hipLaunchKernelGGL((k_connect_step_observe<G>), dim3(grid_for(b->n >> 1)), dim3(BGS_BLOCK), tile, b->stream, g, b->d_planes,
                                b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_actions, d_status_out, d_legal, d_ended,
-                               b->d_steps);
+                               b->d_steps, reinterpret_cast<uint16_t*>(d_reward_out), auto_reset ? 1u : 0u);
         }
     });
     return true;

@@ -607,6 +607,13 @@ class _Batch:
             out = t.empty((self.n, 2), dtype=t.int8, device=f"cuda:{self.device}")
         return self._export("r", out)
 
+    def env_step(self, actions, observation=None, ended=None, reward=None, status=None, auto_reset: bool = True):
+        """The step of a vector environment (bgs_env_step): `step_actions_observe` plus `reward` int8[n, 2] -- the finished
+        game's pair where `ended` is set, 0 / 0 while a game runs -- and, with auto_reset, boards that have ended put back to
+        the initial state in the same call, so that the returned observation is already the new game's.  All device tensors,
+        no synchronisation.  Returns the observation tensor."""
+        return self._observe(actions, observation, ended, reward, status, _abi.ENV_AUTO_RESET if auto_reset else 0)
+
     def step_actions_observe(self, actions, observation=None, ended=None, status=None):
         """ONE library call per policy ply (bgs_step_actions_observe): apply `actions` -- a DEVICE tensor, int32[n] columns for
         Connect, int32[n, 4] moves for Bounce; negative = skip the board -- and write the observation of the boards after the
@@ -614,6 +621,9 @@ class _Batch:
         (`observation`, allocated when None), plus `ended` uint8[n] and `status` int32[n] (per-board result) when given.
         Everything stays on the device and on the batch's stream: no synchronisation, capturable in a HIP graph.  Returns the
         observation tensor.  The loop: obs = batch.legal_tensor(); while ...: obs = batch.step_actions_observe(policy(obs), obs)."""
+        return self._observe(actions, observation, ended, None, status, 0)
+
+    def _observe(self, actions, observation, ended, reward, status, flags: int):
         t = self._need_torch("step_actions_observe")
         width = 1 if self.game == _abi.GAME_CONNECT else 4
         want = (self.n,) if width == 1 else (self.n, 4)
@@ -630,10 +640,13 @@ class _Batch:
         for name, buf, dt in (("ended", ended, t.uint8), ("status", status, t.int32)):
             if buf is not None and not (buf.is_cuda and buf.dtype == dt and tuple(buf.shape) == (self.n,) and buf.is_contiguous()):
                 raise TypeError(f"{name} must be a contiguous {dt} device tensor of shape ({self.n},)")
-        _abi.check(_abi.lib().bgs_step_actions_observe(
+        if reward is not None and not (reward.is_cuda and reward.dtype == t.int8 and tuple(reward.shape) == (self.n, 2) and reward.is_contiguous()):
+            raise TypeError(f"reward must be a contiguous int8 device tensor of shape ({self.n}, 2)")
+        _abi.check(_abi.lib().bgs_env_step(
             self._handle, ctypes.c_void_p(actions.data_ptr()), ctypes.c_void_p(observation.data_ptr()),
             ctypes.c_void_p(ended.data_ptr()) if ended is not None else None,
-            ctypes.c_void_p(status.data_ptr()) if status is not None else None))
+            ctypes.c_void_p(reward.data_ptr()) if reward is not None else None,
+            ctypes.c_void_p(status.data_ptr()) if status is not None else None, ctypes.c_uint32(flags)))
         return observation
 
     def _need_torch(self, who: str):

@@ -23,6 +23,7 @@ BGS_ERR_NO_DEVICE = -4
 
 BUF_PLANES, BUF_STATUS, BUF_PLIES, BUF_REWARD, BUF_STEPS, BUF_STAGING = range(6)
 ROLLOUT_FROM_INITIAL = 1
+ENV_AUTO_RESET = 1
 
 GAME_CONNECT = 1
 GAME_BOUNCE = 2
@@ -81,6 +82,7 @@ SIGNATURES = {
     "bgs_bounce_read_targets": (ctypes.c_int, [c_handle, _u64p]),
     "bgs_export_device": (ctypes.c_int, [c_handle, ctypes.c_int, ctypes.c_void_p]),
     "bgs_step_actions_observe": (ctypes.c_int, [c_handle, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "bgs_env_step": (ctypes.c_int, [c_handle, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
     "bgs_pack_outcomes": (ctypes.c_int, [c_handle, ctypes.c_void_p]),
     "bgs_rollout_pack": (ctypes.c_int, [c_handle, ctypes.c_uint64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p]),
     "bgs_expand_outcomes": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),

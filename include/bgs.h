@@ -164,6 +164,15 @@ int bgs_export_device(bgs_batch* b, int what, void* device_dst);
  * observation -> policy -> bgs_step_actions_observe -> observation -> ... */
 int bgs_step_actions_observe(bgs_batch* b, const int32_t* device_actions, void* device_observation, uint8_t* device_ended,
                              int32_t* device_status);
+/* ... and as the step of a VECTOR ENVIRONMENT (the learner's side of README.md:57-65 for n boards at once): the same call
+ * plus device_reward int8[n][2] = State::get_reward of the boards after the move (connect.cpp:41 / bounce.cpp:38: the
+ * finished game's pair where device_ended is set, 0 / 0 while it runs; may be NULL), and with BGS_ENV_AUTO_RESET a board
+ * that has ended is put back to Config::sample_initial_state() (connect.cpp:32, bounce.cpp:29) in the same pass -- its
+ * observation is then the new game's, its ended flag and reward still those of the game that just finished.  Bit-packed
+ * boards only with BGS_ENV_AUTO_RESET. */
+#define BGS_ENV_AUTO_RESET 1u
+int bgs_env_step(bgs_batch* b, const int32_t* device_actions, void* device_observation, uint8_t* device_ended,
+                 int8_t* device_reward, int32_t* device_status, uint32_t flags);
 
 /* ---- compact outcomes for the multi-GPU reward gather ------------------------------------------------ */
 /* 2 bits per board (0 running, 1 / 2 that player won, 3 draw), 4 boards per byte, board 4i in the low bits:

@@ -369,6 +369,96 @@ def test_one_call_per_policy_ply_connect(bm, torch_mod, geometry, n):
     dev.close()
 
 
+@pytest.mark.parametrize("geometry,n", [((6, 7, 4), 1 << 16), ((6, 7, 4), 4097), ((5, 4, 3), 2000), ((12, 13, 5), 1024)])
+def test_vector_environment_step_with_auto_reset_connect(bm, torch_mod, geometry, n):
+    """bgs_env_step: the moves, the reward pairs, the ended flags, the restart of finished boards and the next legal mask in
+    one call (one kernel on one-word boards with an even batch, the separate kernels otherwise).  Against the oracle with the
+    restart done by hand on its arrays: 3 games' worth of plies, so every board is restarted several times; without
+    auto_reset the call is step_actions_observe + rewards."""
+    torch = torch_mod
+    h, w, k = geometry
+    dev = bm.ConnectBatch(h, w, k, n, use_torch=True)
+    orc = oracle.ConnectOracle(h, w, k, n)
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    legal = dev.legal_tensor()
+    ended = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    reward = torch.zeros((n, 2), dtype=torch.int8, device="cuda")
+    status = torch.zeros(n, dtype=torch.int32, device="cuda")
+    episodes = 0
+    for ply in range(3 * h * w):
+        np.testing.assert_array_equal(legal.cpu().numpy(), orc.legal(), err_msg=f"legal before ply {ply}")
+        cols = (torch.rand((n, w), device="cuda", generator=gen) + legal.float()).argmax(dim=1).to(torch.int32)
+        if ply % 7 == 3:
+            cols[::11] = -1    # skipped boards
+        want = orc.step_actions(cols.cpu().numpy())
+        dev.env_step(cols, legal, ended=ended, reward=reward, status=status)
+        np.testing.assert_array_equal(status.cpu().numpy(), want, err_msg=f"status, ply {ply}")
+        done = orc.ended.copy()
+        np.testing.assert_array_equal(ended.cpu().numpy().astype(bool), done, err_msg=f"ended, ply {ply}")
+        np.testing.assert_array_equal(reward.cpu().numpy(), orc.reward, err_msg=f"reward, ply {ply}")
+        episodes += int(done.sum())
+        # the restart, by hand: Config::sample_initial_state for the boards that have ended
+        orc.grid[done] = -1
+        orc.player[done] = 0
+        orc.winner[done] = -1
+        orc.plies[done] = 0
+        np.testing.assert_array_equal(dev.grid, orc.grid, err_msg=f"grid, ply {ply}")
+        assert not dev.has_ended.any()
+    assert episodes > 2 * n
+    # without the restart: boards stay ended, the rewards are the batch's
+    dev.reset()
+    orc.reset()
+    for ply in range(h * w + 1):
+        cols = (torch.rand((n, w), device="cuda", generator=gen) + legal.float()).argmax(dim=1).to(torch.int32)
+        orc.step_actions(cols.cpu().numpy())
+        dev.env_step(cols, legal, ended=ended, reward=reward, auto_reset=False)
+    assert orc.ended.all()
+    np.testing.assert_array_equal(ended.cpu().numpy().astype(bool), orc.ended)
+    np.testing.assert_array_equal(reward.cpu().numpy(), orc.reward)
+    np.testing.assert_array_equal(dev.grid, orc.grid)
+    dev.close()
+
+
+def test_vector_environment_step_with_auto_reset_bounce(bm, torch_mod):
+    """The same on Bounce (target masks as the observation; the separate kernels back to back): against the oracle's
+    step_actions with the restart done by hand on its arrays."""
+    torch = torch_mod
+    n = 1024
+    dev = bm.BounceBatch(DEFAULT_BOUNCE, n, use_torch=True)
+    orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+    start = orc.grid.copy()
+    targets = dev.targets_tensor()
+    ended = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    reward = torch.zeros((n, 2), dtype=torch.int8, device="cuda")
+    rng = np.random.default_rng(5)
+    episodes = 0
+    for ply in range(90):
+        t = targets.cpu().numpy().view(np.uint64)
+        moves = np.full((n, 4), -1, dtype=np.int32)
+        for i in range(n):
+            row = int(t[i, 6]) if t[i, 6] < 64 else -1
+            cols = [x for x in range(6) if t[i, x]] if row >= 0 else []
+            if cols:
+                x = cols[rng.integers(len(cols))]
+                cells = [c for c in range(54) if (int(t[i, x]) >> c) & 1]
+                cell = cells[rng.integers(len(cells))]
+                moves[i] = (x, row, cell % 6, cell // 6)
+        want = orc.step_actions(moves)
+        assert (want == 0).all()
+        dev.env_step(torch.from_numpy(moves).cuda(), targets, ended=ended, reward=reward)
+        done = orc.ended.copy()
+        np.testing.assert_array_equal(ended.cpu().numpy().astype(bool), done, err_msg=f"ended, ply {ply}")
+        np.testing.assert_array_equal(reward.cpu().numpy(), orc.reward, err_msg=f"reward, ply {ply}")
+        episodes += int(done.sum())
+        orc.grid[done] = start[done]
+        orc.player[done] = 0
+        orc.winner[done] = -1
+        orc.plies[done] = 0
+        np.testing.assert_array_equal(dev.grid, orc.grid, err_msg=f"grid, ply {ply}")
+    assert episodes > n
+    dev.close()
+
+
 def test_one_call_per_policy_ply_bounce(bm, torch_mod):
     """The same call on Bounce (moves int32[n, 4] -> target masks uint64[n, W + 1] + ended): the kernels of the separate
     calls back to back; compared with step_actions + the 't' export and with the oracle's rewards."""

@@ -4,6 +4,7 @@
 Two forms of the library's part of a ply:
   two calls   bgs_export_device 'l' (legal mask), then bgs_step_actions            -- what round 3 had
   one call    bgs_step_actions_observe: the moves and the next legal mask in one pass over the batch (round 4)
+  env step    bgs_env_step: the same pass plus reward pairs, ended flags and the restart of finished boards (a vector environment)
 each eager and replayed from a HIP graph (one game's worth of plies captured once), with the same torch policy -- random
 scores on the legal columns, argmax: four torch kernels over n x 7 floats, 65 us a ply at 2^20 boards, several times the
 library's share -- and with NO policy (a fixed action tensor: the library's share alone; env-steps/s mean nothing there,
@@ -39,7 +40,15 @@ def measure(n):
             for _ in range(PLIES):
                 batch.step_actions_observe(policy() if with_policy else fixed, legal)
 
-        for name, loop in (("two_calls", two_calls), ("one_call", one_call)):
+        ended = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        reward = torch.zeros((n, 2), dtype=torch.int8, device="cuda")
+
+        def env_step(with_policy):   # the vector-environment step: + reward pairs, ended flags, finished boards restarted
+            batch.legal_tensor(legal)
+            for _ in range(PLIES):
+                batch.env_step(policy() if with_policy else fixed, legal, ended=ended, reward=reward)
+
+        for name, loop in (("two_calls", two_calls), ("one_call", one_call), ("env_step", env_step)):
             for with_policy in (True, False):
                 key = name + ("" if with_policy else "_no_policy")
 
@@ -74,8 +83,8 @@ def measure(n):
                             # what one ply of the LIBRARY moves per board, whatever the board's state: planes 16 B in + 8 B out
                             # (the mover's), status 1 B, action 4 B, legal 7 B out = 36 B; two calls read the planes and the
                             # status a second time: + 17 B.  (The policy's own traffic is not counted.)
-                            "library_bytes_per_board_ply": 53 if name == "two_calls" else 36,
-                            "library_GBps_graph": n * (53 if name == "two_calls" else 36) / (replay / PLIES) / 1e9}
+                            "library_bytes_per_board_ply": {"two_calls": 53, "one_call": 36, "env_step": 39}[name],
+                            "library_GBps_graph": n * {"two_calls": 53, "one_call": 36, "env_step": 39}[name] / (replay / PLIES) / 1e9}
         for tag in ("", "_no_policy"):
             out["one_call_over_two_calls_graph" + tag] = out["one_call" + tag]["env_steps_per_s_graph"] / out["two_calls" + tag]["env_steps_per_s_graph"]
             out["one_call_over_two_calls_eager" + tag] = out["one_call" + tag]["env_steps_per_s_eager"] / out["two_calls" + tag]["env_steps_per_s_eager"]

@@ -4,6 +4,7 @@
 // with BGS_ERR_NO_DEVICE.
 #include "../../include/bgs.h"
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -522,6 +523,8 @@ struct SmallTransition {
     uint8_t* d_out = nullptr;
     hipGraphExec_t exec[8] = {};
     bool graph_failed = false;
+    uint32_t ticket = 0;       // of the last fused call: the kernel writes it behind its records (the block's last word)
+    uint32_t unsynced = 0;     // fused calls since the stream was last synchronised
 };
 std::mutex g_small_mu;
 std::unordered_map<const bgs_batch*, SmallTransition> g_small;
@@ -546,8 +549,10 @@ int small_transition(const bgs_batch* b, SmallTransition** out) {
     SmallTransition& t = g_small[b];
     if (!t.h_in) {
         void *hi = nullptr, *ho = nullptr, *di = nullptr, *dv = nullptr;
-        HIP_TRY(hipHostMalloc(&hi, kSmallBlock, hipHostMallocMapped));
-        HIP_TRY(hipHostMalloc(&ho, kSmallBlock, hipHostMallocMapped));
+        // coherent: the fused kernel's ticket (and the records before it) are read while the stream is still busy
+        HIP_TRY(hipHostMalloc(&hi, kSmallBlock, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostMalloc(&ho, kSmallBlock, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(ho, 0, kSmallBlock);
         HIP_TRY(hipHostGetDevicePointer(&di, hi, 0));
         HIP_TRY(hipHostGetDevicePointer(&dv, ho, 0));
         t.h_in = static_cast<uint8_t*>(hi); t.h_out = static_cast<uint8_t*>(ho);
@@ -1169,7 +1174,7 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
     const bool load = grid != nullptr;
     if (load) NEED(player != nullptr && winner != nullptr, "player and winner are required with a grid");
     // small batches: blocks in host memory the device addresses, launches replayed from a graph (see SmallTransition)
-    const int mode = (b->n <= kSmallTransition && in_bytes <= kSmallBlock && out_bytes <= kSmallBlock) ? transition_mode() : 0;
+    const int mode = (b->n <= kSmallTransition && in_bytes <= kSmallBlock && out_bytes <= kSmallBlock - 64) ? transition_mode() : 0;
     SmallTransition* small = nullptr;
     uint8_t *d_in, *d_out, *h_in, *h_out;
     if (mode) {
@@ -1205,6 +1210,13 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
         if (load || actions) HIP_TRY(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, b->stream));
         HIP_TRY(hipMemsetAsync(d_out, 0, 8 * n, b->stream));
     }
+    // The fused kernel publishes a ticket behind its records: the host takes them as soon as it SEES the ticket, which is
+    // earlier than the stream's completion signal comes back (BGS_TRANSITION_SPIN=0: wait for the stream as before).  The
+    // kernel that wrote the ticket has nothing left to do, so the next call may reuse the blocks; the stream itself is
+    // synchronised now and then, and whenever the ticket does not show within 2 ms (a failed launch reports itself there).
+    static const bool spin_wanted = [] { const char* e = getenv("BGS_TRANSITION_SPIN"); return !(e && e[0] == '0'); }();
+    const bool spin = mode == 3 && spin_wanted && !b->generic;
+    bool fused = false;
     auto launch_all = [&]() -> int {
         int32_t* d_load = reinterpret_cast<int32_t*>(d_out + out_load);
         int32_t* d_step = reinterpret_cast<int32_t*>(d_out + out_step);
@@ -1225,8 +1237,11 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
             // the move and the whole observation in one launch (k_connect_transition / k_bounce_transition)
             const int32_t* da = actions ? reinterpret_cast<const int32_t*>(d_in + in_actions) : nullptr;
             int8_t* orw = reinterpret_cast<int8_t*>(d_out + out_reward);
-            if (connect) bgs::connect_transition(b, da, d_step, og, op, ow, ol, d_out + out_legal, orw);
-            else bgs::bounce_transition(b, da, d_step, og, op, ow, ol, reinterpret_cast<uint64_t*>(d_out + out_legal), orw);
+            uint32_t* d_done = spin ? reinterpret_cast<uint32_t*>(d_out + kSmallBlock - 64) : nullptr;
+            const uint32_t ticket = spin ? ++small->ticket : 0;
+            if (connect) bgs::connect_transition(b, da, d_step, og, op, ow, ol, d_out + out_legal, orw, d_done, ticket);
+            else bgs::bounce_transition(b, da, d_step, og, op, ow, ol, reinterpret_cast<uint64_t*>(d_out + out_legal), orw, d_done, ticket);
+            fused = true;
             return finish_launch();
         }
         if (actions) {
@@ -1283,7 +1298,19 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
         if (rc) return rc;
     }
     if (!mode) HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    bool seen = false;
+    if (spin && fused && ++small->unsynced < 1024) {
+        const volatile uint32_t* done = reinterpret_cast<const volatile uint32_t*>(h_out + kSmallBlock - 64);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t turn = 1; !(seen = __atomic_load_n(done, __ATOMIC_ACQUIRE) == small->ticket); ++turn) {
+            __builtin_ia32_pause();
+            if ((turn & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    if (!seen) {
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        if (small) small->unsynced = 0;
+    }
     // a malformed board was left untouched and an illegal move changed nothing: report the first problem per board
     const int32_t* load_status = reinterpret_cast<const int32_t*>(h_out + out_load);
     const int32_t* step_status = reinterpret_cast<const int32_t*>(h_out + out_step);

@@ -144,7 +144,8 @@ void connect_reset_ended(const bgs_batch* b);   // boards that have ended -> the
 void bounce_reset_ended(const bgs_batch* b);
 void status_to_ended(const bgs_batch* b, uint8_t* d_ended);  // uint8[n]: the board has ended (any game)
 void connect_transition(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
-                        int8_t* d_winner, int32_t* d_plies, uint8_t* d_legal, int8_t* d_reward_out);
+                        int8_t* d_winner, int32_t* d_plies, uint8_t* d_legal, int8_t* d_reward_out, uint32_t* d_done = nullptr,
+                        uint32_t ticket = 0);  // d_done: host word the one-workgroup kernel sets to `ticket` behind its records
 bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, uint32_t* codes_out);
 void connect_unpack_grid(const bgs_batch* b, int8_t* d_grid);
 void connect_cell_planes(const bgs_batch* b, uint64_t* d_dst);  // wire format of the grid hand-over (see the kernel)
@@ -158,7 +159,8 @@ void bounce_reset(const bgs_batch* b);
 void bounce_step_random(const bgs_batch* b, uint64_t seed, uint32_t count);
 void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out);
 void bounce_transition(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
-                       int8_t* d_winner, int32_t* d_plies, uint64_t* d_targets, int8_t* d_reward_out);
+                       int8_t* d_winner, int32_t* d_plies, uint64_t* d_targets, int8_t* d_reward_out, uint32_t* d_done = nullptr,
+                       uint32_t ticket = 0);
 void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags);
 void bounce_unpack_grid(const bgs_batch* b, int8_t* d_grid);
 void bounce_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies);

@@ -1491,7 +1491,7 @@ k_bounce_transition(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __rest
                     uint16_t* __restrict__ reward, int64_t n, const int32_t* __restrict__ moves, int32_t* __restrict__ result,
                     unsigned long long* __restrict__ steps, int8_t* __restrict__ grid, int8_t* __restrict__ player,
                     int8_t* __restrict__ winner, int32_t* __restrict__ plies_out, uint64_t* __restrict__ targets,
-                    uint16_t* __restrict__ reward_out) {
+                    uint16_t* __restrict__ reward_out, uint32_t* __restrict__ done, uint32_t ticket) {
     const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
     uint32_t stepped = 0;
     if (i < n) {
@@ -1546,6 +1546,11 @@ k_bounce_transition(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __rest
         reward_out[i] = pair;
     }
     add_steps(steps, stepped);
+    if (done) {  // (see publish_ticket in connect_kernels.hip: one workgroup, records in host memory)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(done, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // packed planes -> reference layout int8[n][H][W]: one lane expands one board into the workgroup's LDS tile, the
@@ -1854,10 +1859,12 @@ void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_
 }
 
 void bounce_transition(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
-                       int8_t* d_winner, int32_t* d_plies, uint64_t* d_targets, int8_t* d_reward_out) {
+                       int8_t* d_winner, int32_t* d_plies, uint64_t* d_targets, int8_t* d_reward_out, uint32_t* d_done,
+                       uint32_t ticket) {
     hipLaunchKernelGGL(k_bounce_transition, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->d_status,
                        b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_moves, d_status_out, b->d_steps, d_grid,
-                       d_player, d_winner, d_plies, d_targets, reinterpret_cast<uint16_t*>(d_reward_out));
+                       d_player, d_winner, d_plies, d_targets, reinterpret_cast<uint16_t*>(d_reward_out),
+                       grid_for(b->n) == 1 ? d_done : nullptr, ticket);
 }
 
 void bounce_unpack_grid(const bgs_batch* b, int8_t* d_grid) {

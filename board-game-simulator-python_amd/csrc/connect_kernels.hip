@@ -1773,6 +1773,16 @@ k_connect_legal(G g, const uint64_t* __restrict__ planes, const uint8_t* __restr
     if (count) count[i] = __popc(open);
 }
 
+// One-workgroup kernels whose records go to host memory the device addresses: after every thread's stores, thread 0
+// publishes the call's ticket behind them (release at system scope) -- the host reads the records as soon as it sees
+// the ticket, without waiting for the stream's completion signal.
+__device__ __forceinline__ void publish_ticket(uint32_t* done, uint32_t ticket) {
+    if (!done) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The object API's round trip on a small batch (bgs_transition, n <= 64): the chosen move, if any, and then everything a
 // State shows -- grid, player, winner, plies, open columns, reward pair -- in ONE launch instead of five (step, unpack,
 // meta, legal, reward copy).  A thread owns a board; the outputs are plain per-board records (the caller passes host
@@ -1782,7 +1792,8 @@ __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_transition(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward, int64_t n,
                      const int32_t* __restrict__ actions, int32_t* __restrict__ result, unsigned long long* __restrict__ steps,
                      int8_t* __restrict__ grid, int8_t* __restrict__ player, int8_t* __restrict__ winner,
-                     int32_t* __restrict__ plies, uint8_t* __restrict__ legal, uint16_t* __restrict__ reward_out) {
+                     int32_t* __restrict__ plies, uint8_t* __restrict__ legal, uint16_t* __restrict__ reward_out,
+                     uint32_t* __restrict__ done, uint32_t ticket) {
     constexpr int NW = G::NW;
     const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
     uint32_t stepped = 0;
@@ -1834,6 +1845,7 @@ k_connect_transition(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ s
         reward_out[i] = pair;
     }
     add_steps(steps, stepped);
+    publish_ticket(done, ticket);
 }
 
 // reference layout -> packed planes, with validation (gravity, stone counts, cell codes)
@@ -2178,12 +2190,14 @@ void connect_legal(const bgs_batch* b, uint8_t* d_legal, int32_t* d_count) {
 }
 
 void connect_transition(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
-                        int8_t* d_winner, int32_t* d_plies, uint8_t* d_legal, int8_t* d_reward_out) {
+                        int8_t* d_winner, int32_t* d_plies, uint8_t* d_legal, int8_t* d_reward_out, uint32_t* d_done,
+                        uint32_t ticket) {
     dispatch(b->cg, [&](auto g) {
         using G = decltype(g);
         hipLaunchKernelGGL((k_connect_transition<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g, b->d_planes,
                            b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_actions, d_status_out, b->d_steps,
-                           d_grid, d_player, d_winner, d_plies, d_legal, reinterpret_cast<uint16_t*>(d_reward_out));
+                           d_grid, d_player, d_winner, d_plies, d_legal, reinterpret_cast<uint16_t*>(d_reward_out),
+                           grid_for(b->n) == 1 ? d_done : nullptr, ticket);
     });
 }
 

@@ -54,18 +54,22 @@ class _Engine(EngineBase):
         """One fused call (bgs_transition): optional load, optional move, then the observations a State needs.  The
         load is left out when the device batch already holds exactly that board (see connect.py)."""
         call = self.call
-        if grid is not None and self.held == (grid.tobytes(), player, winner, plies):
-            grid = None
+        held = self.held
+        if grid is not None and held is not None and grid is held[0] and (player, winner, plies) == held[1:]:
+            grid = None  # the very array the last round trip handed out (read-only, owned by its State)
         self.held = None
         status = call(grid, player, winner, plies, move)
         if status == _abi.BGS_ERR_ILLEGAL:
             raise RuntimeError(f"illegal action: {tuple(move[:2])} -> {tuple(move[2:])}")
         if status != 0:
             raise RuntimeError("malformed Bounce state")
-        grid_out, player_out, winner_out, plies_out = call.grid_out.copy(), int(call.player_out[0]), int(call.winner_out[0]), int(call.plies_out[0])
-        self.held = (grid_out.tobytes(), player_out, winner_out, plies_out)
+        grid_out, reward_out = call.grid_out.copy(), call.reward_out.copy()
+        grid_out.flags.writeable = False
+        reward_out.flags.writeable = False
+        player_out, winner_out, plies_out = int(call.player_out[0]), int(call.winner_out[0]), int(call.plies_out[0])
+        self.held = (grid_out, player_out, winner_out, plies_out)
         moves = self.batch.decode_moves(call.legal_out[0], winner_out)
-        return grid_out, player_out, winner_out, plies_out, moves, call.reward_out.copy()
+        return grid_out, player_out, winner_out, plies_out, moves, reward_out
 
     def initial(self):
         with self.lock:
@@ -119,7 +123,7 @@ class Config(ValueObject):
         return _Engine.get(self._grid)
 
     def sample_initial_state(self) -> "State":
-        return State(self, *self._engine().initial())
+        return State._fresh(self, *self._engine().initial())
 
     def to_json(self) -> Dict[str, Any]:
         return {"grid": self._grid.tolist()}
@@ -148,6 +152,19 @@ class State(ValueObject):
         r = np.array(reward, dtype=np.int8)  # the pair the device computed (State::get_reward, bounce.cpp:38)
         r.setflags(write=False)
         object.__setattr__(self, "_reward", r)
+
+    @classmethod
+    def _fresh(cls, config, grid, player, winner, plies, moves, reward) -> "State":
+        """A State of what an engine's round trip returned: read-only arrays nobody else holds, ints, a tuple of moves."""
+        s = _new(cls)
+        _state_config(s, config)
+        _state_grid(s, grid)
+        _state_player(s, player)
+        _state_winner(s, winner)
+        _state_plies(s, plies)
+        _state_moves(s, moves)
+        _state_reward(s, reward)
+        return s
 
     def __setattr__(self, name, value):
         raise AttributeError("State is immutable")
@@ -204,7 +221,7 @@ class State(ValueObject):
             raise RuntimeError(f"invalid Bounce state JSON: {exc}") from None
         if grid.shape != config._grid.shape:
             raise RuntimeError("state grid does not match the config")
-        return State(config, *config._engine().load(grid, player, winner, player))
+        return State._fresh(config, *config._engine().load(grid, player, winner, player))
 
 
 class Action(ValueObject):
@@ -219,11 +236,10 @@ class Action(ValueObject):
     def _of(cls, state: State, source: Cell, target: Cell) -> "Action":
         """An Action of one of the state's own decoded moves (tuples of ints already): `state.actions` builds a dozen
         of these per ply, a third of the Python side of a transition."""
-        a = object.__new__(cls)
-        put = object.__setattr__
-        put(a, "state", state)
-        put(a, "_source", source)
-        put(a, "_target", target)
+        a = _new(cls)
+        _action_state(a, state)
+        _action_source(a, source)
+        _action_target(a, target)
         return a
 
     def __setattr__(self, name, value):
@@ -245,7 +261,7 @@ class Action(ValueObject):
 
     def sample_next_state(self) -> State:
         s = self.state
-        return State(s.config, *s.config._engine().after(s._grid, s._player, s._winner, s._plies, self._source, self._target))
+        return State._fresh(s.config, *s.config._engine().after(s._grid, s._player, s._winner, s._plies, self._source, self._target))
 
     def to_json(self) -> Dict[str, Any]:
         return {"source": list(self._source), "target": list(self._target)}
@@ -260,3 +276,10 @@ class Action(ValueObject):
 
 Config.State = State
 State.Action = Action
+
+# The slots' own setters (see connect.py): the classes refuse attribute assignment, these are how the module fills them.
+_new = object.__new__
+_state_config, _state_grid, _state_player = State.config.__set__, State._grid.__set__, State._player.__set__
+_state_winner, _state_plies, _state_moves = State._winner.__set__, State._plies.__set__, State._moves.__set__
+_state_reward = State._reward.__set__
+_action_state, _action_source, _action_target = Action.state.__set__, Action._source.__set__, Action._target.__set__

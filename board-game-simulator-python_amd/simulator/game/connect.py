@@ -48,18 +48,22 @@ class _Engine(EngineBase):
         load is left out when the device batch already holds exactly that board (the usual case: a game played move by
         move), which saves the pack kernel and the grid's trip to the device."""
         call = self.call
-        if grid is not None and self.held == (grid.tobytes(), player, winner):
-            grid = None
+        held = self.held
+        if grid is not None and held is not None and grid is held[0] and player == held[1] and winner == held[2]:
+            grid = None  # the very array the last round trip handed out (read-only, owned by its State)
         self.held = None
         status = call(grid, player, winner, None, column)
         if status == _abi.BGS_ERR_ILLEGAL:
             raise RuntimeError(f"illegal action: column {column}")
         if status != 0:
             raise RuntimeError("malformed Connect state")
-        legal = tuple(c for c, open_ in enumerate(call.legal_out[0].tolist()) if open_)
-        grid_out, player_out, winner_out = call.grid_out.copy(), int(call.player_out[0]), int(call.winner_out[0])
-        self.held = (grid_out.tobytes(), player_out, winner_out)
-        return grid_out, player_out, winner_out, legal, call.reward_out.copy()
+        legal = tuple([c for c, open_ in enumerate(call.legal_out[0].tolist()) if open_])
+        grid_out, reward_out = call.grid_out.copy(), call.reward_out.copy()
+        grid_out.flags.writeable = False
+        reward_out.flags.writeable = False
+        player_out, winner_out = int(call.player_out[0]), int(call.winner_out[0])
+        self.held = (grid_out, player_out, winner_out)
+        return grid_out, player_out, winner_out, legal, reward_out
 
     def initial(self):
         with self.lock:
@@ -107,7 +111,7 @@ class Config(ValueObject):
         return _Engine.get(self.height, self.width, self.count)
 
     def sample_initial_state(self) -> "State":
-        return State(self, *self._engine().initial())
+        return State._fresh(self, *self._engine().initial())
 
     def to_json(self) -> Dict[str, Any]:
         return {"height": self.height, "width": self.width, "count": self.count}
@@ -135,6 +139,18 @@ class State(ValueObject):
         r = np.array(reward, dtype=np.int8)  # the pair the device computed (State::get_reward, connect.cpp:41)
         r.setflags(write=False)
         object.__setattr__(self, "_reward", r)
+
+    @classmethod
+    def _fresh(cls, config, grid, player, winner, legal, reward) -> "State":
+        """A State of what an engine's round trip returned: read-only arrays nobody else holds, ints, a tuple."""
+        s = _new(cls)
+        _state_config(s, config)
+        _state_grid(s, grid)
+        _state_player(s, player)
+        _state_winner(s, winner)
+        _state_legal(s, legal)
+        _state_reward(s, reward)
+        return s
 
     def __setattr__(self, name, value):
         raise AttributeError("State is immutable")
@@ -185,7 +201,7 @@ class State(ValueObject):
             raise RuntimeError(f"invalid Connect state JSON: {exc}") from None
         if grid.shape != (config.height, config.width):
             raise RuntimeError("state grid does not match the config")
-        return State(config, *config._engine().load(grid, player, winner))
+        return State._fresh(config, *config._engine().load(grid, player, winner))
 
 
 class Action(ValueObject):
@@ -198,9 +214,9 @@ class Action(ValueObject):
     @classmethod
     def _of(cls, state: State, column: int) -> "Action":
         """An Action of one of the state's own legal columns (ints already)."""
-        a = object.__new__(cls)
-        object.__setattr__(a, "state", state)
-        object.__setattr__(a, "column", column)
+        a = _new(cls)
+        _action_state(a, state)
+        _action_column(a, column)
         return a
 
     def __setattr__(self, name, value):
@@ -214,7 +230,7 @@ class Action(ValueObject):
 
     def sample_next_state(self) -> State:
         s = self.state
-        return State(s.config, *s.config._engine().after(s._grid, s._player, s._winner, self.column))
+        return State._fresh(s.config, *s.config._engine().after(s._grid, s._player, s._winner, self.column))
 
     def to_json(self) -> Dict[str, Any]:
         return {"column": self.column}
@@ -229,3 +245,10 @@ class Action(ValueObject):
 
 Config.State = State
 State.Action = Action
+
+# The slots' own setters: the classes refuse attribute assignment (immutable values, README.md:67), and going through
+# `object.__setattr__(obj, "name", value)` for each of a ply's dozen objects was a third of the Python side of a transition.
+_new = object.__new__
+_state_config, _state_grid, _state_player = State.config.__set__, State._grid.__set__, State._player.__set__
+_state_winner, _state_legal, _state_reward = State._winner.__set__, State._legal.__set__, State._reward.__set__
+_action_state, _action_column = Action.state.__set__, Action.column.__set__

@@ -332,6 +332,8 @@ int device_facts(bgs_batch* b) {
         // with 8 lanes per board -- see bounce_rollout()
         const char* plan = getenv("BGS_BOUNCE_PLAN");
         if (!plan) plan = "auto";
+        const char* wave_pass = getenv("BGS_BOUNCE_WAVE_PASS");
+        b->bounce_wave_pass = !(wave_pass && wave_pass[0] == '0');
         b->bounce_passes = 0;
         b->bounce_plan_auto = strcmp(plan, "auto") == 0;
         if (!b->bounce_plan_auto && strcmp(plan, "single") != 0) {
@@ -342,7 +344,7 @@ int device_facts(bgs_batch* b) {
                 int lanes = 1;
                 if (endp && *endp == ':') lanes = (int)strtol(endp + 1, &endp, 10);
                 b->bounce_pass_cap[b->bounce_passes] = cap > 0 ? (uint32_t)cap : 0xFFFFFFFFu;
-                b->bounce_pass_group[b->bounce_passes] = lanes == 8 ? 8 : 1;
+                b->bounce_pass_group[b->bounce_passes] = lanes == 8 ? 8 : lanes == 64 ? 64 : 1;   // 64: one board per wave (K3w), later passes only
                 ++b->bounce_passes;
                 if (!endp || *endp != ',') break;
                 p = endp + 1;

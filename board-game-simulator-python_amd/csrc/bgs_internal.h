@@ -102,6 +102,7 @@ struct bgs_batch {
     int bounce_park;         // flat rollout: a draining wave parks its boards for its workgroup at this many or fewer (0..32; BGS_BOUNCE_PARK)
     int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (BGS_BOUNCE_CHUNK)
     int launches_in_flight;  // the caller's hint (bgs_set_launches_in_flight), 1 = one launch at a time: see bounce_shape()
+    int bounce_wave_pass;    // 1: the automatic plan ends with the one-board-per-wave pass (K3w); BGS_BOUNCE_WAVE_PASS=0 switches it off
     int bounce_plan_auto;    // 1: the library chooses between one launch and bulk + tail passes (BGS_BOUNCE_PLAN unset or "auto")
     int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board
     uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];

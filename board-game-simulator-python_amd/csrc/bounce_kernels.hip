@@ -1661,6 +1661,238 @@ k_bounce_compact(const uint8_t* __restrict__ status, const uint16_t* __restrict_
         worklist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)i;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3w: ONE BOARD PER WAVE, a piece per lane -- the last pass of the rollout, for the handful of games per batch that
+// run for thousands of plies (one or two per 2^18 never end and stop at max_plies).  Such a game is a chain of dependent
+// plies; the launch is over when it is, so what counts is the LATENCY of its ply, i.e. how many instructions the wave
+// that holds it has to issue per ply.  The 8-lanes-per-board kernel walks a column's closure cell by cell (a lane runs
+// `reach`: ~1000 instructions a ply on the longest column).  Here the lanes ARE the pieces (lane k = the k-th occupied
+// cell, re-derived from the planes every ply, so the lanes are always in cell order):
+//   A   every lane runs its own piece's segment (the same code as K3p's phase A; the step loop runs to the largest value
+//       on the board, lanes drop out at their own);
+//   hit "which pieces does my segment land on": the cells of the other pieces come over v_readlane, one bit test each;
+//   B1  the closure of "lands on" -- Warshall with one ROW PER LANE: pivot p's row comes over v_readlane, every lane
+//       that has bit p takes it in (three instructions a pivot instead of K3p's multiply over six packed dwords);
+//   B2  a source's targets = the OR of its members' landing masks (masks over v_readlane, selected by sign-extended
+//       member bits), counts; the sources of the active row are neighbouring lanes in column order, so "actions before
+//       mine" is a prefix sum over 16 lanes (four DPP row shifts), the total is lane 15's;
+//   pick the lane whose range holds the index works out (source, target); a ballot and one v_readlane hand it to all.
+// ~320 VALU and ~50 v_readlane a ply against ~1000.  The board itself (four value planes) is wave-uniform.
+// Results cannot differ from the other kernels': the same rules, the same canonical action order (sources by column,
+// targets by cell index), the RNG keyed by game id and ply.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kWaveMemoBits = 6, kWaveMemoSlots = 1u << kWaveMemoBits;
+
+struct WaveMoves {
+    uint64_t targets;    // this lane's piece, if it is a source: its legal landing cells
+    uint32_t count;      // popcount(targets)
+    uint32_t before;     // actions of the sources left of this lane's
+    uint32_t cell;       // this lane's piece stands here
+    uint32_t n;          // actions of the board (uniform)
+};
+
+__device__ __forceinline__ uint32_t row_shift_right(uint32_t x, int by) {   // lane i of a 16-lane row gets lane i - by's x, 0 below
+    switch (by) {
+        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+        case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+        default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    }
+}
+
+template <int PMAX>
+__device__ __forceinline__ void enumerate_wave(const BounceGeom& g, const Board& b, uint32_t player, WaveMoves& m) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t occ = occupancy(b);
+    const uint32_t pieces = (uint32_t)__popcll(occ);          // (uniform; <= PMAX: the host only sends such boards)
+    const bool alive = lane < pieces;
+    const uint32_t cell = alive ? select_bit64(occ, lane) : 0u;
+    const uint32_t value = alive ? value_at(b, (int)cell) : 0u;
+    m.cell = cell;
+    const uint64_t empty_interior = ~occ & g.interior;
+    const uint64_t landing = empty_interior | (player ? g.goal_bottom : g.goal_top);
+    const uint32_t up = player ? 0u : (uint32_t)g.w, down = player ? (uint32_t)g.w : 0u;
+    // A: the landing cells of this lane's piece
+    uint64_t a0 = alive ? 1ull << cell : 0ull, al = 0, ar = 0, land = 0;
+    for (uint32_t s = 1; __builtin_amdgcn_ballot_w64(s <= value) != 0ull; ++s) {
+        if (s <= value) {
+            const uint64_t via_left = a0 | al, via_right = a0 | ar;
+            const uint64_t nf = ((via_left | ar) << up) >> down;
+            const uint64_t nl = (via_left & g.not_col0) >> 1;
+            const uint64_t nr = (via_right & g.not_collast) << 1;
+            if (s < value) {
+                a0 = nf & empty_interior;
+                al = nl & empty_interior;
+                ar = nr & empty_interior;
+            } else {
+                land = nf | nl | nr;
+            }
+        }
+    }
+    // who stands on them (bit j = the piece of lane j); a segment never returns to its own start cell
+    uint32_t row = 0;
+    // (no "is there a piece j" tests: a lane without a piece has no landing cells and an empty row, so whatever bit the
+    // others compute FOR it selects nothing -- and a branch costs a lone wave more than the three instructions it skips)
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) {
+        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cell, j);
+        row |= ((uint32_t)(land >> cj) & 1u) << j;
+    }
+    // B1: the closure over bounces, a row per lane
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+        const uint32_t rp = (uint32_t)__builtin_amdgcn_readlane((int)row, p);
+        row |= (uint32_t)__builtin_amdgcn_sbfe((int)row, p, 1) & rp;
+    }
+    // B2: a source's targets are the landing cells of its closure
+    const uint64_t sources = movable(g, occ, player);
+    const bool is_source = alive && ((sources >> cell) & 1ull);
+    const uint32_t members = row | (1u << lane);
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) {
+        const uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)land, j);
+        const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(land >> 32), j);
+        const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)members, j, 1);
+        lo |= lj & sel;
+        hi |= hj & sel;
+    }
+    const uint64_t targets = is_source ? ((((uint64_t)hi << 32) | lo) & landing) : 0ull;
+    const uint32_t count = (uint32_t)__popcll(targets);
+    uint32_t incl = count;   // the lanes are in cell order and the sources share a row: a prefix sum is "in column order"
+    incl += row_shift_right(incl, 1);
+    incl += row_shift_right(incl, 2);
+    incl += row_shift_right(incl, 4);
+    incl += row_shift_right(incl, 8);
+    m.targets = targets;
+    m.count = count;
+    m.before = incl - count;
+    m.n = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+}
+
+template <int PMAX>
+__global__ void __launch_bounds__(BGS_WAVE)
+k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+                      uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
+                      unsigned long long* __restrict__ steps, const uint32_t* __restrict__ worklist,
+                      const uint32_t* __restrict__ work_count) {
+    static_assert(PMAX <= 16, "the prefix sum runs over one 16-lane row");
+    __builtin_amdgcn_s_setprio(3);   // (see k_bounce_rollout: these waves are the launch's critical path)
+    const uint32_t lane = threadIdx.x & 63u;
+    // the wave's memo of action lists (see the ply loop): 64 positions, 14 KB
+    __shared__ uint64_t memo_key[kWaveMemoSlots][4];
+    __shared__ uint64_t memo_targets[kWaveMemoSlots][PMAX];
+    __shared__ uint32_t memo_lane[kWaveMemoSlots][PMAX];
+    __shared__ uint32_t memo_n[kWaveMemoSlots];
+    __shared__ uint32_t memo_tag[kWaveMemoSlots];
+    for (uint32_t e = lane; e < kWaveMemoSlots; e += BGS_WAVE) memo_tag[e] = 0xFFFFFFFFu;   // (no side is 0xFFFFFFFF)
+    __syncthreads();   // (one wave: orders the LDS accesses of its lanes)
+    const uint32_t total = *work_count;
+    uint32_t stepped = 0;
+    for (uint32_t entry = blockIdx.x; entry < total; entry += gridDim.x) {
+        const uint32_t game = (uint32_t)__builtin_amdgcn_readfirstlane((int)worklist[entry]);
+        const int64_t i = game;
+        Board b = load_board(planes, n, i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)   // (wave-uniform: keep the planes in scalar registers)
+            b.v[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b.v[j] >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b.v[j]);
+        uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)status[i]);
+        uint32_t plies = (uint32_t)__builtin_amdgcn_readfirstlane((int)plies_buf[i]);
+        if (st != BGS_ST_RUNNING || plies >= max_plies) continue;
+        if ((uint32_t)__popcll(occupancy(b)) > (uint32_t)PMAX) continue;   // (never: the host checks the piece count)
+        const uint32_t first_ply = plies;
+        WaveMoves mv;
+        Philox4 blk;
+        blk.v[0] = blk.v[1] = blk.v[2] = blk.v[3] = 0;
+        bool have_block = false;
+        // One enumeration site.  `side` is whose action list is built next; after a move it is the other player's, and
+        // an empty list there means the game is over: the mover wins if HE could still move, else it is a draw -- one more
+        // enumeration, for the mover (`blocked`).  A board that arrives blocked is settled by the same rule with the
+        // roles of a move that never happened (settle_blocked).
+        uint32_t side = plies & 1u;
+        bool blocked = false;
+        for (;;) {
+            // The games this pass exists for do not wander: the one endless game of a 2^18-board batch of the default start
+            // visits 27 positions in 4096 plies, four of them in its last 2000 (tools/bounce_endless.py).  The action list of a
+            // position is a function of the position, so the wave keeps the lists it has built in LDS, keyed by the board and
+            // the side (direct-mapped, compared in full: a hit IS the list enumerate_wave would build, for any board of the
+            // batch), and a ply on a known position costs a look-up instead of the search.
+            uint32_t slot;
+            {
+                uint32_t h = (uint32_t)b.v[0] * 0x9E3779B1u ^ (uint32_t)(b.v[0] >> 32) * 0x85EBCA77u;
+                h ^= ((uint32_t)b.v[1] * 0xC2B2AE3Du) ^ ((uint32_t)(b.v[1] >> 32) * 0x27D4EB2Fu);
+                h ^= ((uint32_t)b.v[2] * 0x165667B1u) ^ ((uint32_t)(b.v[2] >> 32) * 0xD3A2646Cu);
+                h ^= ((uint32_t)b.v[3] * 0xFD7046C5u) ^ ((uint32_t)(b.v[3] >> 32) * 0xB55A4F09u);
+                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((h ^ (h >> 15)) * 0x2C1B3C6Du) >> (32 - kWaveMemoBits))) ^ side;
+                slot &= kWaveMemoSlots - 1u;
+            }
+            const bool known = memo_tag[slot] == side && memo_key[slot][0] == b.v[0] && memo_key[slot][1] == b.v[1] &&
+                               memo_key[slot][2] == b.v[2] && memo_key[slot][3] == b.v[3];
+            if (__builtin_amdgcn_readfirstlane((int)known)) {
+                const uint32_t at = lane < (uint32_t)PMAX ? lane : 0u;
+                const uint32_t packed = memo_lane[slot][at];
+                mv.targets = lane < (uint32_t)PMAX ? memo_targets[slot][at] : 0ull;
+                mv.cell = packed & 255u;
+                mv.count = lane < (uint32_t)PMAX ? (packed >> 8) & 255u : 0u;
+                mv.before = packed >> 16;
+                mv.n = memo_n[slot];
+            } else {
+                enumerate_wave<PMAX>(g, b, side, mv);
+                if (lane < (uint32_t)PMAX) {
+                    memo_targets[slot][lane] = mv.targets;
+                    memo_lane[slot][lane] = mv.cell | (mv.count << 8) | (mv.before << 16);
+                }
+                if (lane == 0u) {
+                    memo_key[slot][0] = b.v[0];
+                    memo_key[slot][1] = b.v[1];
+                    memo_key[slot][2] = b.v[2];
+                    memo_key[slot][3] = b.v[3];
+                    memo_n[slot] = mv.n;
+                    memo_tag[slot] = side;
+                }
+                __syncthreads();   // (uniform branch, one wave: lane 0's key before anybody's next look-up)
+            }
+            if (blocked) {
+                st = mv.n ? side + 1u : BGS_ST_DRAW;
+                break;
+            }
+            if (mv.n == 0) {
+                blocked = true;
+                side = 1u - side;
+                continue;
+            }
+            if (plies >= max_plies) break;
+            if (!have_block || (plies & 3u) == 0u) {
+                blk = philox4x32_10(seed, first_game + (uint64_t)game, plies >> 2);
+                have_block = true;
+            }
+            const uint32_t idx = sample_index(philox_word(blk, plies), mv.n);
+            const uint32_t k = idx - mv.before;
+            const bool here = k < mv.count;   // (unsigned: idx < before wraps; count is 0 on every lane that is no source)
+            uint32_t pair = here ? (mv.cell | (select_bit64(mv.targets, here ? k : 0u) << 8)) : 0u;
+            const uint64_t owner = __builtin_amdgcn_ballot_w64(here);   // exactly one lane
+            pair = (uint32_t)__builtin_amdgcn_readlane((int)pair, (__ffsll((unsigned long long)owner) - 1) & 63);
+            const int s = (int)(pair & 255u), t = (int)(pair >> 8);
+            move_piece(b, s, t);
+            ++plies;
+            if ((1ull << t) & (g.goal_top | g.goal_bottom)) {
+                st = side + 1u;
+                break;
+            }
+            side = 1u - side;
+        }
+        if (lane == 0u) {
+            store_board(planes, n, i, b);
+            status[i] = (uint8_t)st;
+            plies_buf[i] = (uint16_t)plies;
+            reward[i] = reward_pair(st);
+            stepped += plies - first_ply;
+        }
+    }
+    add_steps(steps, stepped);
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + BGS_BLOCK - 1) / BGS_BLOCK); }
 
 }  // namespace
@@ -1686,6 +1918,22 @@ void bounce_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
 // group = lanes per board (1 or 8), wps = waves per SIMD the grid is sized for.
 static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool from_initial, int group, int wps,
                            const uint32_t* worklist, const uint32_t* work_count, uint32_t* queue) {
+    if (group == 64) {   // K3w: a work list of a few very long games, one wave each (a wave strides over the list)
+        auto launch_wave = [&](auto pmax_tag) {
+            constexpr int PMAX = decltype(pmax_tag)::value;
+            // one-wave workgroups; a wave without a list entry leaves at once, so the grid is sized for the longest list the
+            // automatic plan produces (5 % of 2^18 boards after a 64-ply bulk pass: three entries a wave)
+            static const int grid_env = [] { const char* e = getenv("BGS_BOUNCE_WAVE_GRID"); return e ? atoi(e) : 0; }();
+            const unsigned wave_grid = grid_env > 0 ? (unsigned)grid_env : 4096u;
+            hipLaunchKernelGGL((k_bounce_rollout_wave<PMAX>), dim3(wave_grid), dim3(BGS_WAVE), 0,
+                               b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
+                               seed, b->first_game, cap, b->d_steps, worklist, work_count);
+        };
+        if (b->bg.piece_count <= 8) launch_wave(std::integral_constant<int, 8>{});
+        else if (b->bg.piece_count <= 12) launch_wave(std::integral_constant<int, 12>{});
+        else launch_wave(std::integral_constant<int, 16>{});
+        return;
+    }
     const int64_t slots_per_wave = BGS_WAVE / group;
     int64_t per_wave, waves;
     if (worklist) {
@@ -1819,7 +2067,17 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
             pass_group_of[0] = 1;
             pass_cap_of[1] = cap;
             pass_group_of[1] = 8;
+            // ... or, where it can take them (at most 16 pieces), ONE BOARD PER WAVE (K3w): its ply is shorter still, and it
+            // remembers the action lists of the positions it has seen, which is what a game that never ends consists of.
+            // Measured (tools/k3w_probe.sh, 2^18 default boards): one launch at a time 1.40 -> 1.92-2.09 x 10^9 env-steps/s,
+            // 20 in flight 1.42 -> 1.54-1.57 x 10^10; an 8-lane pass in between (to 2x / 4x the bulk cap) reads the same.
+            // BGS_BOUNCE_WAVE_PASS=0: the 8-lane tail as before.
+            if (b->bounce_wave_pass && b->bg.piece_count <= BGS_BOUNCE_MAX_PIECES) pass_group_of[1] = 64;
         }
+        for (int i = 1; i < passes; ++i)   // K3w needs a work list and at most 16 pieces on every board it is handed: boards of
+            if (pass_group_of[i] == 64 && !(from_initial && b->bg.piece_count >= 1 && b->bg.piece_count <= BGS_BOUNCE_MAX_PIECES))
+                pass_group_of[i] = 8;      // the configured start position (a loaded batch may hold anything)
+        if (passes >= 1 && pass_group_of[0] == 64) pass_group_of[0] = 1;
         if (passes <= 1) {  // single launch (BGS_BOUNCE_PLAN=single, or a plan with one entry)
             launch_rollout(b, seed, cap, from_initial, b->bounce_group, b->bounce_group == 1 ? b->rollout_wps : 8, nullptr, nullptr,
                            queues);

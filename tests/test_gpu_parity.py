@@ -650,6 +650,36 @@ def test_bounce_piece_list_rollout(batch_mod, name):
             os.environ["BGS_BOUNCE_GROUP"] = old
 
 
+@pytest.mark.parametrize("name", list(PIECE_LIST_GRIDS))
+def test_bounce_one_board_per_wave_pass(batch_mod, name):
+    """K3w, the last pass of the automatic plan (one board per wave, a piece per lane: the few games that run for thousands
+    of plies), forced onto MOST of a batch by a plan whose earlier passes stop after 6 and 20 plies -- against the oracle on
+    grids of 2 to 16 pieces (the 8-, 12- and 16-lane instantiations), values up to 15, a blocked start position, ply caps
+    that stop games inside the pass; grids it cannot take (40 pieces, 12 columns) keep the kernels they had."""
+    import os
+
+    grid = PIECE_LIST_GRIDS[name]
+    env = {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PLAN": "6:1,20:8,0:64"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for n, cap in ((2500, 4096), (700, 57), (64, 21), (300, 22)):
+            dev = batch_mod.BounceBatch(grid, n)
+            orc = oracle.BounceOracle(grid, n)
+            dev.set_first_game(7 << 32)
+            dev.rollout(SEED + 11, max_plies=cap, from_initial=True)
+            total = orc.rollout(SEED + 11, first_game=7 << 32, max_plies=cap)
+            assert_same(dev, orc, f"{name} n={n} cap={cap}")
+            assert dev.steps == total == int(orc.plies.sum())
+            dev.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("launches", [1, 4, 8, 16, 64])
 def test_bounce_launch_shape_follows_the_hint_and_the_boards_do_not(batch_mod, launches):
     """`set_launches_in_flight` only shapes the launch (bulk-pass ply cap, boards per wave: bounce_shape() in

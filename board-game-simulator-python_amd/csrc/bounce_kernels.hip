@@ -1785,7 +1785,11 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
     __shared__ uint32_t memo_lane[kWaveMemoSlots][PMAX];
     __shared__ uint32_t memo_n[kWaveMemoSlots];
     __shared__ uint32_t memo_tag[kWaveMemoSlots];
-    for (uint32_t e = lane; e < kWaveMemoSlots; e += BGS_WAVE) memo_tag[e] = 0xFFFFFFFFu;   // (no side is 0xFFFFFFFF)
+    __shared__ uint32_t memo_last[kWaveMemoSlots / 2];   // per set: the way used last
+    for (uint32_t e = lane; e < kWaveMemoSlots; e += BGS_WAVE) {
+        memo_tag[e] = 0xFFFFFFFFu;   // (no side is 0xFFFFFFFF)
+        memo_last[e >> 1] = 1u;
+    }
     __syncthreads();   // (one wave: orders the LDS accesses of its lanes)
     const uint32_t total = *work_count;
     uint32_t stepped = 0;
@@ -1816,27 +1820,46 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             // The games this pass exists for do not wander: the one endless game of a 2^18-board batch of the default start
             // visits 27 positions in 4096 plies, four of them in its last 2000 (tools/bounce_endless.py).  The action list of a
             // position is a function of the position, so the wave keeps the lists it has built in LDS, keyed by the board and
-            // the side (direct-mapped, compared in full: a hit IS the list enumerate_wave would build, for any board of the
-            // batch), and a ply on a known position costs a look-up instead of the search.
-            uint32_t slot;
+            // the side (compared in full: a hit IS the list enumerate_wave would build, for any board of the batch), and a ply
+            // on a known position costs a look-up instead of the search.  32 sets of two ways, the way not used last is
+            // replaced: direct-mapped, two of a game's handful of hot positions shared a slot in one launch of ten and every
+            // ply of that game missed (4.7 ms against 2.5).
+            uint32_t set;
             {
                 uint32_t h = (uint32_t)b.v[0] * 0x9E3779B1u ^ (uint32_t)(b.v[0] >> 32) * 0x85EBCA77u;
                 h ^= ((uint32_t)b.v[1] * 0xC2B2AE3Du) ^ ((uint32_t)(b.v[1] >> 32) * 0x27D4EB2Fu);
                 h ^= ((uint32_t)b.v[2] * 0x165667B1u) ^ ((uint32_t)(b.v[2] >> 32) * 0xD3A2646Cu);
                 h ^= ((uint32_t)b.v[3] * 0xFD7046C5u) ^ ((uint32_t)(b.v[3] >> 32) * 0xB55A4F09u);
-                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((h ^ (h >> 15)) * 0x2C1B3C6Du) >> (32 - kWaveMemoBits))) ^ side;
-                slot &= kWaveMemoSlots - 1u;
+                set = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((h ^ (h >> 15)) * 0x2C1B3C6Du) >> (33 - kWaveMemoBits))) ^ side;
+                set &= kWaveMemoSlots / 2u - 1u;
             }
-            const bool known = memo_tag[slot] == side && memo_key[slot][0] == b.v[0] && memo_key[slot][1] == b.v[1] &&
-                               memo_key[slot][2] == b.v[2] && memo_key[slot][3] == b.v[3];
-            if (__builtin_amdgcn_readfirstlane((int)known)) {
+            // (both ways' keys and tags are read at once and compared afterwards: one LDS round trip, then the records of
+            // the way that hit.  Written with && the compiler reads tag, then the key word by word: six round trips of ~110
+            // cycles each, 40 % of a remembered ply.)
+            const uint32_t w0 = 2u * set, w1 = w0 + 1u;
+            const uint32_t tag0 = memo_tag[w0], tag1 = memo_tag[w1], last = memo_last[set];
+            uint32_t differ0 = tag0 ^ side, differ1 = tag1 ^ side;   // (32-bit xor / or chains: 17 instructions a way)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t ka = memo_key[w0][j], kc = memo_key[w1][j];
+                differ0 |= ((uint32_t)ka ^ (uint32_t)b.v[j]) | ((uint32_t)(ka >> 32) ^ (uint32_t)(b.v[j] >> 32));
+                differ1 |= ((uint32_t)kc ^ (uint32_t)b.v[j]) | ((uint32_t)(kc >> 32) ^ (uint32_t)(b.v[j] >> 32));
+            }
+            const uint32_t found = (uint32_t)__builtin_amdgcn_readfirstlane((int)((differ0 == 0u ? 1u : 0u) | (differ1 == 0u ? 2u : 0u)));
+            const uint32_t way = found ? found >> 1 : ((uint32_t)__builtin_amdgcn_readfirstlane((int)last) ^ 1u) & 1u;   // hit, or the victim
+            const uint32_t slot = w0 + way;
+            if (found) {
                 const uint32_t at = lane < (uint32_t)PMAX ? lane : 0u;
                 const uint32_t packed = memo_lane[slot][at];
                 mv.targets = lane < (uint32_t)PMAX ? memo_targets[slot][at] : 0ull;
                 mv.cell = packed & 255u;
                 mv.count = lane < (uint32_t)PMAX ? (packed >> 8) & 255u : 0u;
                 mv.before = packed >> 16;
-                mv.n = memo_n[slot];
+                mv.n = (uint32_t)__builtin_amdgcn_readfirstlane((int)memo_n[slot]);
+                if (way != ((uint32_t)__builtin_amdgcn_readfirstlane((int)last) & 1u)) {
+                    if (lane == 0u) memo_last[set] = way;
+                    __syncthreads();
+                }
             } else {
                 enumerate_wave<PMAX>(g, b, side, mv);
                 if (lane < (uint32_t)PMAX) {
@@ -1850,8 +1873,9 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
                     memo_key[slot][3] = b.v[3];
                     memo_n[slot] = mv.n;
                     memo_tag[slot] = side;
+                    memo_last[set] = way;
                 }
-                __syncthreads();   // (uniform branch, one wave: lane 0's key before anybody's next look-up)
+                __syncthreads();   // (uniform branch, one wave: lane 0's stores before anybody's next look-up)
             }
             if (blocked) {
                 st = mv.n ? side + 1u : BGS_ST_DRAW;

@@ -76,8 +76,9 @@ def main():
                 rows.append(dict({"pool": pool, "park": park}, **r))
                 print(rows[-1], flush=True)
     elif args.what == "bounce-tail":
-        for plan in ("auto", "128:1,0:8", "160:1,0:8", "224:1,0:8", "320:1,0:8", "512:1,0:8"):
-            for park in (36, 44):
+        # the bulk pass's ply cap in front of the one-board-per-wave tail pass (lanes 64; round 3's tail: lanes 8)
+        for plan in ("auto", "64:1,0:64", "96:1,0:64", "128:1,0:64", "160:1,0:64", "224:1,0:64", "160:1,0:8"):
+            for park in (40,):
                 env = {"BGS_BOUNCE_PIECES_PARK": park}
                 if plan != "auto":
                     env["BGS_BOUNCE_PLAN"] = plan

@@ -1485,7 +1485,66 @@ k_bounce_step_actions(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
 }
 
 // The object API's round trip on a small batch (see k_connect_transition): the chosen move, if any, then grid, player,
-// winner, plies, the targets record and the reward pair of every board in one launch.
+// winner, plies, the targets record and the reward pair of every board in one launch.  One board, by one thread:
+__device__ __forceinline__ uint32_t bounce_transition_one(const BounceGeom& g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
+                                                          uint16_t* __restrict__ plies_buf, uint16_t* __restrict__ reward, int64_t n, int64_t i,
+                                                          const int32_t* __restrict__ moves, int32_t* __restrict__ result,
+                                                          int8_t* __restrict__ grid, int8_t* __restrict__ player, int8_t* __restrict__ winner,
+                                                          int32_t* __restrict__ plies_out, uint64_t* __restrict__ targets,
+                                                          uint16_t* __restrict__ reward_out) {
+    uint32_t stepped = 0;
+    Board b = load_board(planes, n, i);
+    uint32_t st = status[i];
+    uint32_t plies = plies_buf[i];
+    uint16_t pair = reward[i];
+    if (moves) {
+        const int sx = moves[4 * i], sy = moves[4 * i + 1], tx = moves[4 * i + 2], ty = moves[4 * i + 3];
+        int32_t rc = 0;
+        if (sx >= 0) {
+            rc = -2;  // BGS_ERR_ILLEGAL
+            const bool inside = sx < g.w && sy >= 0 && sy < g.h && tx >= 0 && tx < g.w && ty >= 0 && ty < g.h;
+            if (inside && st == BGS_ST_RUNNING && plies < kMaxPlies) {
+                const uint32_t mover = plies & 1u;
+                const uint64_t occ = occupancy(b);
+                const int s = sy * g.w + sx, t = ty * g.w + tx;
+                if (((movable(g, occ, mover) >> s) & 1ull) && ((reach(g, b, occ, mover, s) >> t) & 1ull)) {
+                    move_piece(b, s, t);
+                    ++plies;
+                    uint32_t n_next;
+                    const uint32_t after = settle(g, b, mover, t, n_next);
+                    store_board(planes, n, i, b);
+                    plies_buf[i] = (uint16_t)plies;
+                    if (after != BGS_ST_RUNNING) {
+                        st = after;
+                        pair = reward_pair(st);
+                        status[i] = (uint8_t)st;
+                        reward[i] = pair;
+                    }
+                    stepped = 1;
+                    rc = 0;
+                }
+            }
+        }
+        result[i] = rc;
+    }
+    const int hw = g.h * g.w;
+    for (int c = 0; c < hw; ++c) grid[i * hw + c] = (int8_t)value_at(b, c);
+    player[i] = (int8_t)(plies & 1u);
+    winner[i] = st == 0 ? -1 : (st == BGS_ST_DRAW ? 2 : (int8_t)(st - 1));
+    plies_out[i] = (int32_t)plies;
+    const uint64_t occ = occupancy(b);
+    const uint32_t mover = plies & 1u;
+    const uint64_t src = st == BGS_ST_RUNNING ? movable(g, occ, mover) : 0ull;
+    const int row = src ? (int)(((uint32_t)(__ffsll((unsigned long long)src) - 1) * g.inv_w) >> 16) : 0;
+    for (int x = 0; x < g.w; ++x) {
+        const int c = row * g.w + x;
+        targets[i * (g.w + 1) + x] = ((src >> c) & 1ull) ? reach(g, b, occ, mover, c) : 0ull;
+    }
+    targets[i * (g.w + 1) + g.w] = src ? (uint64_t)row : ~0ull;
+    reward_out[i] = pair;
+    return stepped;
+}
+
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_bounce_transition(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                     uint16_t* __restrict__ reward, int64_t n, const int32_t* __restrict__ moves, int32_t* __restrict__ result,
@@ -1494,57 +1553,9 @@ k_bounce_transition(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __rest
                     uint16_t* __restrict__ reward_out, uint32_t* __restrict__ done, uint32_t ticket) {
     const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
     uint32_t stepped = 0;
-    if (i < n) {
-        Board b = load_board(planes, n, i);
-        uint32_t st = status[i];
-        uint32_t plies = plies_buf[i];
-        uint16_t pair = reward[i];
-        if (moves) {
-            const int sx = moves[4 * i], sy = moves[4 * i + 1], tx = moves[4 * i + 2], ty = moves[4 * i + 3];
-            int32_t rc = 0;
-            if (sx >= 0) {
-                rc = -2;  // BGS_ERR_ILLEGAL
-                const bool inside = sx < g.w && sy >= 0 && sy < g.h && tx >= 0 && tx < g.w && ty >= 0 && ty < g.h;
-                if (inside && st == BGS_ST_RUNNING && plies < kMaxPlies) {
-                    const uint32_t mover = plies & 1u;
-                    const uint64_t occ = occupancy(b);
-                    const int s = sy * g.w + sx, t = ty * g.w + tx;
-                    if (((movable(g, occ, mover) >> s) & 1ull) && ((reach(g, b, occ, mover, s) >> t) & 1ull)) {
-                        move_piece(b, s, t);
-                        ++plies;
-                        uint32_t n_next;
-                        const uint32_t after = settle(g, b, mover, t, n_next);
-                        store_board(planes, n, i, b);
-                        plies_buf[i] = (uint16_t)plies;
-                        if (after != BGS_ST_RUNNING) {
-                            st = after;
-                            pair = reward_pair(st);
-                            status[i] = (uint8_t)st;
-                            reward[i] = pair;
-                        }
-                        stepped = 1;
-                        rc = 0;
-                    }
-                }
-            }
-            result[i] = rc;
-        }
-        const int hw = g.h * g.w;
-        for (int c = 0; c < hw; ++c) grid[i * hw + c] = (int8_t)value_at(b, c);
-        player[i] = (int8_t)(plies & 1u);
-        winner[i] = st == 0 ? -1 : (st == BGS_ST_DRAW ? 2 : (int8_t)(st - 1));
-        plies_out[i] = (int32_t)plies;
-        const uint64_t occ = occupancy(b);
-        const uint32_t mover = plies & 1u;
-        const uint64_t src = st == BGS_ST_RUNNING ? movable(g, occ, mover) : 0ull;
-        const int row = src ? (int)(((uint32_t)(__ffsll((unsigned long long)src) - 1) * g.inv_w) >> 16) : 0;
-        for (int x = 0; x < g.w; ++x) {
-            const int c = row * g.w + x;
-            targets[i * (g.w + 1) + x] = ((src >> c) & 1ull) ? reach(g, b, occ, mover, c) : 0ull;
-        }
-        targets[i * (g.w + 1) + g.w] = src ? (uint64_t)row : ~0ull;
-        reward_out[i] = pair;
-    }
+    if (i < n)
+        stepped = bounce_transition_one(g, planes, status, plies_buf, reward, n, i, moves, result, grid, player, winner, plies_out, targets,
+                                        reward_out);
     add_steps(steps, stepped);
     if (done) {  // (see publish_ticket in connect_kernels.hip: one workgroup, records in host memory)
         __threadfence_system();
@@ -1917,6 +1928,116 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
     add_steps(steps, stepped);
 }
 
+// The object API's round trip for ONE board (the engines of simulator.game.bounce hold one-board batches) on one wave, a piece
+// per lane: K3w's enumerate_wave in place of the thread-per-board kernel's walks.  A transition is a legality test, the
+// terminal test and the next action list -- up to thirteen closures walked one after the other by one thread (~4 us of a
+// 14 us call); here at most three enumerations of ~0.4 us.  A board of more than PMAX pieces (a State loaded from JSON may
+// hold anything) is served by lane 0 with the thread-per-board code.  Same records, same ticket.
+template <int PMAX>
+__global__ void __launch_bounds__(BGS_WAVE)
+k_bounce_transition_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+                         uint16_t* __restrict__ reward, const int32_t* __restrict__ moves, int32_t* __restrict__ result,
+                         unsigned long long* __restrict__ steps, int8_t* __restrict__ grid, int8_t* __restrict__ player,
+                         int8_t* __restrict__ winner, int32_t* __restrict__ plies_out, uint64_t* __restrict__ targets,
+                         uint16_t* __restrict__ reward_out, uint32_t* __restrict__ done, uint32_t ticket) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t stepped = 0;
+    Board b = load_board(planes, 1, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        b.v[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b.v[j] >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b.v[j]);
+    if ((uint32_t)__popcll(occupancy(b)) > (uint32_t)PMAX) {
+        if (lane == 0u)
+            stepped = bounce_transition_one(g, planes, status, plies_buf, reward, 1, 0, moves, result, grid, player, winner, plies_out,
+                                            targets, reward_out);
+    } else {
+        uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)status[0]);
+        uint32_t plies = (uint32_t)__builtin_amdgcn_readfirstlane((int)plies_buf[0]);
+        uint32_t pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)reward[0]);
+        WaveMoves mv;
+        bool listed = false;   // mv is the action list of (b, plies & 1)
+        if (moves) {
+            const int sx = __builtin_amdgcn_readfirstlane(moves[0]), sy = __builtin_amdgcn_readfirstlane(moves[1]);
+            const int tx = __builtin_amdgcn_readfirstlane(moves[2]), ty = __builtin_amdgcn_readfirstlane(moves[3]);
+            int32_t rc = 0;
+            if (sx >= 0) {
+                rc = -2;  // BGS_ERR_ILLEGAL
+                const bool inside = sx < g.w && sy >= 0 && sy < g.h && tx >= 0 && tx < g.w && ty >= 0 && ty < g.h;
+                if (inside && st == BGS_ST_RUNNING && plies < kMaxPlies) {
+                    const uint32_t mover = plies & 1u;
+                    const int s = sy * g.w + sx, t = ty * g.w + tx;
+                    enumerate_wave<PMAX>(g, b, mover, mv);
+                    listed = true;
+                    const bool mine = mv.count != 0u && mv.cell == (uint32_t)s && ((mv.targets >> t) & 1ull);
+                    if (__builtin_amdgcn_ballot_w64(mine) != 0ull) {
+                        move_piece(b, s, t);
+                        ++plies;
+                        uint32_t after = BGS_ST_RUNNING;
+                        if ((1ull << t) & (g.goal_top | g.goal_bottom)) {
+                            after = mover + 1u;
+                            listed = false;
+                        } else {
+                            enumerate_wave<PMAX>(g, b, 1u - mover, mv);   // the next player's list: the terminal test AND the observation
+                            if (mv.n == 0) {
+                                enumerate_wave<PMAX>(g, b, mover, mv);
+                                after = mv.n ? mover + 1u : BGS_ST_DRAW;
+                                listed = false;
+                            }
+                        }
+                        if (lane == 0u) {
+                            store_board(planes, 1, 0, b);
+                            plies_buf[0] = (uint16_t)plies;
+                        }
+                        if (after != BGS_ST_RUNNING) {
+                            st = after;
+                            pair = reward_pair(st);
+                            if (lane == 0u) {
+                                status[0] = (uint8_t)st;
+                                reward[0] = (uint16_t)pair;
+                            }
+                        }
+                        stepped = lane == 0u ? 1u : 0u;
+                        rc = 0;
+                    }
+                }
+            }
+            if (lane == 0u) result[0] = rc;
+        }
+        // the records
+        const int hw = g.h * g.w;
+        if ((int)lane < hw) grid[lane] = (int8_t)value_at(b, (int)lane);   // a cell per lane: one store instruction
+        const uint64_t occ = occupancy(b);
+        const uint32_t mover = plies & 1u;
+        const uint64_t src = st == BGS_ST_RUNNING ? movable(g, occ, mover) : 0ull;
+        const int row = src ? (int)(((uint32_t)(__ffsll((unsigned long long)src) - 1) * g.inv_w) >> 16) : 0;
+        if (src && !listed) enumerate_wave<PMAX>(g, b, mover, mv);
+        for (int x = 0; x < g.w; ++x) {   // (uniform: column x's mask from the lane that holds the column's piece, if it can move)
+            const uint64_t holder = src ? __builtin_amdgcn_ballot_w64(mv.count != 0u && mv.cell == (uint32_t)(row * g.w + x)) : 0ull;
+            uint64_t mask = 0;
+            if (holder) {
+                const int from = (__ffsll((unsigned long long)holder) - 1) & 63;
+                mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv.targets >> 32), from) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv.targets, from);
+            }
+            if (lane == 0u) targets[x] = mask;
+        }
+        if (lane == 0u) {
+            targets[g.w] = src ? (uint64_t)row : ~0ull;
+            player[0] = (int8_t)(plies & 1u);
+            winner[0] = st == 0 ? -1 : (st == BGS_ST_DRAW ? 2 : (int8_t)(st - 1));
+            plies_out[0] = (int32_t)plies;
+            reward_out[0] = (uint16_t)pair;
+        }
+    }
+    add_steps(steps, stepped);
+    if (done) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(done, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + BGS_BLOCK - 1) / BGS_BLOCK); }
 
 }  // namespace
@@ -2143,6 +2264,13 @@ void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_
 void bounce_transition(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
                        int8_t* d_winner, int32_t* d_plies, uint64_t* d_targets, int8_t* d_reward_out, uint32_t* d_done,
                        uint32_t ticket) {
+    static const bool wave_wanted = [] { const char* e = getenv("BGS_TRANSITION_WAVE"); return !(e && e[0] == '0'); }();
+    if (b->n == 1 && wave_wanted && b->bg.h * b->bg.w <= 64) {   // the object API's engines: one board, one wave, a piece per lane
+        hipLaunchKernelGGL((k_bounce_transition_wave<BGS_BOUNCE_MAX_PIECES>), dim3(1), dim3(BGS_WAVE), 0, b->stream, b->bg, b->d_planes,
+                           b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), d_moves, d_status_out, b->d_steps, d_grid,
+                           d_player, d_winner, d_plies, d_targets, reinterpret_cast<uint16_t*>(d_reward_out), d_done, ticket);
+        return;
+    }
     hipLaunchKernelGGL(k_bounce_transition, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->d_status,
                        b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, d_moves, d_status_out, b->d_steps, d_grid,
                        d_player, d_winner, d_plies, d_targets, reinterpret_cast<uint16_t*>(d_reward_out),

@@ -94,27 +94,43 @@ def test_surface(fx):
     assert hash(nxt) == hash(a.sample_next_state()) and nxt != state
 
 
+def _crowded_grids():
+    """Start grids either side of the one-wave transition kernel's reach (a piece per lane, at most 16): 16 pieces on 7x8
+    and 18 on 6x8 (served by the thread-per-board code inside the same kernel), values up to 7."""
+    sixteen = np.zeros((7, 8), dtype=np.int8)
+    sixteen[1] = [1, 2, 3, 1, 2, 3, 1, 2]
+    sixteen[5] = [2, 1, 3, 2, 1, 7, 2, 1]
+    eighteen = np.zeros((6, 8), dtype=np.int8)
+    eighteen[1] = [1, 2, 3, 1, 2, 3, 1, 2]
+    eighteen[2, 3] = eighteen[3, 4] = 2
+    eighteen[4] = [2, 1, 3, 2, 1, 3, 2, 1]
+    return [sixteen, eighteen]
+
+
 def test_random_playthrough_matches_oracle(fx):
+    """Random games through the object API against the oracle, ply by ply: the action LIST (order included), the grid, the
+    player, the end and the reward -- on the reference's default start and on two crowded ones."""
     from oracle import oracle
     from simulator.game.bounce import Config
 
     grid = np.array(fx["tests"][1]["positions"][0]["grid"], dtype=np.int8)
     rnd = random.Random(3)
-    for _ in range(2):
-        state = Config(grid).sample_initial_state()
-        orc = oracle.BounceOracle(grid, 1)
-        plies = 0
-        while not state.has_ended and plies < 300:
-            assert state.player == orc.player[0]
-            np.testing.assert_array_equal(state.grid, orc.grid[0])
-            listed = [(tuple(a.source), tuple(a.target)) for a in state.actions]
-            assert listed == orc.actions(0)
-            action = rnd.choice(state.actions)
-            state = action.sample_next_state()
-            orc.step_actions([[*action.source, *action.target]])
-            plies += 1
-        assert bool(orc.ended[0]) == state.has_ended
-        np.testing.assert_array_equal(state.reward, orc.reward[0])
+    for start, games in ((grid, 2), *((g, 3) for g in _crowded_grids())):
+        for _ in range(games):
+            state = Config(start).sample_initial_state()
+            orc = oracle.BounceOracle(start, 1)
+            plies = 0
+            while not state.has_ended and plies < 300:
+                assert state.player == orc.player[0]
+                np.testing.assert_array_equal(state.grid, orc.grid[0])
+                listed = [(tuple(a.source), tuple(a.target)) for a in state.actions]
+                assert listed == orc.actions(0)
+                action = rnd.choice(state.actions)
+                state = action.sample_next_state()
+                orc.step_actions([[*action.source, *action.target]])
+                plies += 1
+            assert bool(orc.ended[0]) == state.has_ended
+            np.testing.assert_array_equal(state.reward, orc.reward[0])
 
 
 def test_json_of_terminal_states(fx):

@@ -256,8 +256,9 @@ def test_the_three_forms_of_the_round_trip_agree():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = _PLAYTHROUGH.format(root=root, pkg=os.path.join(root, "board-game-simulator-python_amd"))
     digests = {}
-    for form in ("staged", "mapped", "graph", "fused", "fused-stream"):
-        env = dict(os.environ, BGS_TRANSITION=form.split("-")[0], BGS_TRANSITION_SPIN="0" if form.endswith("stream") else "1")
+    for form in ("staged", "mapped", "graph", "fused", "fused-stream", "fused-thread"):
+        env = dict(os.environ, BGS_TRANSITION=form.split("-")[0], BGS_TRANSITION_SPIN="0" if form.endswith("stream") else "1",
+                   BGS_TRANSITION_WAVE="0" if form.endswith("thread") else "1")   # Bounce: a thread per board instead of a piece per lane
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         digests[form] = out.stdout.strip().splitlines()[-1]

@@ -572,14 +572,15 @@ int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_
     }
     if (he != hipSuccess) rc = fail(BGS_ERR_RUNTIME, "gather allocation failed: %s", hipGetErrorString(he));
     if (rc == BGS_OK && rank == 0) rc = bgs_sink_create(device, n_per_rank * world, slots, host_threads, &g->sink);
-    if (rc == BGS_OK) {
+    static const bool comm_alone = [] { const char* e = getenv("BGS_GATHER_COMM_ALONE"); return !(e && e[0] == '0'); }();
+    if (rc == BGS_OK && (world > 1 || comm_alone)) {
         // collective: every rank of the world is inside this call at the same time
         NcclUniqueId u;
         memcpy(u.internal, id, sizeof u.internal);
         const int r = rccl().CommInitRank(&g->comm, world, u, rank);
         if (r != 0) rc = fail(BGS_ERR_RUNTIME, "ncclCommInitRank failed: %s", rccl().GetErrorString(r));
     }
-    if (rc == BGS_OK && world == 1) {
+    if (rc == BGS_OK && world == 1 && g->comm) {
         // nothing will ever be sent: the library loaded and the id was good, which is all a one-rank world can show
         (void)rccl().CommDestroy(g->comm);
         g->comm = nullptr;

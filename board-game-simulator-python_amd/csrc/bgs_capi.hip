@@ -289,7 +289,11 @@ int device_facts(bgs_batch* b) {
     // Bounce rollouts: one lane per board with the flattened search (fewest instructions per ply: throughput) for large
     // batches, 8 lanes per board (shortest ply latency) for small ones; BGS_BOUNCE_GROUP = 1 / 8 overrides
     b->bounce_group = b->n >= 32768 ? 1 : 8;
-    if (const char* env = getenv("BGS_BOUNCE_GROUP")) b->bounce_group = atoi(env) == 1 ? 1 : 8;
+    b->bounce_group_auto = 1;
+    if (const char* env = getenv("BGS_BOUNCE_GROUP")) {
+        b->bounce_group = atoi(env) == 1 ? 1 : 8;
+        b->bounce_group_auto = 0;
+    }
     b->bounce_flat = 1;
     if (const char* env = getenv("BGS_BOUNCE_FLAT")) b->bounce_flat = atoi(env) != 0;
     b->bounce_pieces = 1;

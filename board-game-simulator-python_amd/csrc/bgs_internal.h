@@ -96,7 +96,8 @@ struct bgs_batch {
     int planes;              // uint64 planes per board
     int num_cus;             // compute units of the device
     int rollout_wps;         // waves per SIMD the fused rollout is sized for
-    int bounce_group;        // lanes per board of a single-launch Bounce rollout: 8 (default) or 1 (BGS_BOUNCE_GROUP)
+    int bounce_group;        // lanes per board of a single-launch Bounce rollout: 8 (small batches) or 1 (BGS_BOUNCE_GROUP)
+    int bounce_group_auto;   // 1: not set from the environment (bounce_rollout may still choose by the launches in flight)
     int bounce_flat;         // 1: one-lane-per-board Bounce rollouts use the flattened search (BGS_BOUNCE_FLAT=0: nested loops)
     int bounce_pieces;       // 1: from-initial flat rollouts run on the piece list (K3p; BGS_BOUNCE_PIECES=0: K3f)
     int bounce_block;        // K3p: threads per workgroup, 256 / 512 / 1024 (BGS_BOUNCE_BLOCK): the waves of a workgroup share their drain

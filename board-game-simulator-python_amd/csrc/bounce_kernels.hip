@@ -1815,7 +1815,20 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
         uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)status[i]);
         uint32_t plies = (uint32_t)__builtin_amdgcn_readfirstlane((int)plies_buf[i]);
         if (st != BGS_ST_RUNNING || plies >= max_plies) continue;
-        if ((uint32_t)__popcll(occupancy(b)) > (uint32_t)PMAX) continue;   // (never: the host checks the piece count)
+        if ((uint32_t)__popcll(occupancy(b)) > (uint32_t)PMAX) {
+            // more pieces than lanes provided for (a batch loaded from memory may hold anything): lane 0 plays the board with
+            // the thread-per-board code -- correct, slow, and rare (the host does not send batches CONFIGURED with that many)
+            if (lane == 0u) {
+                const uint32_t before = plies;
+                (void)play<false>(g, b, st, plies, seed, first_game + (uint64_t)game, max_plies);
+                store_board(planes, n, i, b);
+                status[i] = (uint8_t)st;
+                plies_buf[i] = (uint16_t)plies;
+                reward[i] = reward_pair(st);
+                stepped += plies - before;
+            }
+            continue;
+        }
         const uint32_t first_ply = plies;
         WaveMoves mv;
         Philox4 blk;
@@ -2074,8 +2087,10 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
                                b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
                                seed, b->first_game, cap, b->d_steps, worklist, work_count);
         };
-        if (b->bg.piece_count <= 8) launch_wave(std::integral_constant<int, 8>{});
-        else if (b->bg.piece_count <= 12) launch_wave(std::integral_constant<int, 12>{});
+        // (from_initial here: every board of the rollout descends from the configured start position, so none holds more
+        // pieces than it; otherwise 16 lanes, and a board with more than that is played by lane 0)
+        if (from_initial && b->bg.piece_count >= 1 && b->bg.piece_count <= 8) launch_wave(std::integral_constant<int, 8>{});
+        else if (from_initial && b->bg.piece_count >= 1 && b->bg.piece_count <= 12) launch_wave(std::integral_constant<int, 12>{});
         else launch_wave(std::integral_constant<int, 16>{});
         return;
     }
@@ -2205,27 +2220,46 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
             pass_cap_of[i] = b->bounce_pass_cap[i];
             pass_group_of[i] = b->bounce_pass_group[i];
         }
-        if (b->bounce_plan_auto && b->bounce_group == 1 && b->bounce_flat && b->bounce_pieces && from_initial &&
-            b->bg.piece_count >= 1 && cap > 2u * (uint32_t)bounce_shape(b->launches_in_flight).tail_cap) {
+        // lanes per board of the first (or only) pass: 8 for small batches (shortest ply), 1 for large ones (fewest instructions).
+        // From the start position the large-batch kernel is K3p, whose ply is 17 us deep for a lone wave: one launch at a
+        // time it only wins from 2^17 boards (2^16: 2.05 ms against 1.75 with 8 lanes + K3w; 2^17: 2.46 against 2.62), with
+        // four and more launches in flight from 2^15 as before
+        const BounceShape shape = bounce_shape(b->launches_in_flight);
+        const bool piece_list = b->bounce_flat && b->bounce_pieces && from_initial && b->bg.piece_count >= 1;
+        int lanes = b->bounce_group;
+        if (b->bounce_group_auto && piece_list && b->launches_in_flight < 4) lanes = b->n >= 131072 ? 1 : 8;
+        // K3w as the last pass: any batch whose configured start position has at most 16 pieces (piece_count = 0: more)
+        const bool wave_tail = b->bounce_wave_pass && b->bg.piece_count >= 1 && b->bg.piece_count <= BGS_BOUNCE_MAX_PIECES;
+        if (b->bounce_plan_auto && lanes == 1 && piece_list && cap > 2u * (uint32_t)shape.tail_cap) {
             passes = 2;
-            pass_cap_of[0] = (uint32_t)bounce_shape(b->launches_in_flight).tail_cap;
+            pass_cap_of[0] = (uint32_t)shape.tail_cap;
             pass_group_of[0] = 1;
             pass_cap_of[1] = cap;
-            pass_group_of[1] = 8;
-            // ... or, where it can take them (at most 16 pieces), ONE BOARD PER WAVE (K3w): its ply is shorter still, and it
-            // remembers the action lists of the positions it has seen, which is what a game that never ends consists of.
-            // Measured (tools/k3w_probe.sh, 2^18 default boards): one launch at a time 1.40 -> 1.92-2.09 x 10^9 env-steps/s,
-            // 20 in flight 1.42 -> 1.54-1.57 x 10^10; an 8-lane pass in between (to 2x / 4x the bulk cap) reads the same.
-            // BGS_BOUNCE_WAVE_PASS=0: the 8-lane tail as before.
-            if (b->bounce_wave_pass && b->bg.piece_count <= BGS_BOUNCE_MAX_PIECES) pass_group_of[1] = 64;
+            // ... by ONE BOARD PER WAVE (K3w) where it can take them: its ply is shorter still, and it remembers the action lists
+            // of the positions it has seen, which is what a game that never ends consists of.  Measured (tools/k3w_probe.sh,
+            // 2^18 default boards): one launch at a time 1.40 -> 1.92-2.09 x 10^9 env-steps/s, 20 in flight 1.42 -> 1.54-1.57 x
+            // 10^10; an 8-lane pass in between (to 2x / 4x the bulk cap) reads the same.  BGS_BOUNCE_WAVE_PASS=0: the 8-lane
+            // tail as before.
+            pass_group_of[1] = wave_tail ? 64 : 8;
+        } else if (b->bounce_plan_auto && wave_tail) {
+            // every other batch (small ones, boards loaded from memory): a short first pass on the kernel it always had, then
+            // K3w.  2^10 / 2^12 / 2^14 / 2^15 boards from the start, one launch at a time: 0.67 / 0.84 / 0.98 / 1.70 ms -> 0.44 /
+            // 0.55 / 0.78 / 1.07 ms (first pass to 16 plies below 2^13 boards, else 32).  A large batch loaded from memory
+            // (one lane per board, K3f) used to keep a whole wave alive for every game that never ends.
+            const uint32_t first = lanes == 1 ? (uint32_t)shape.tail_cap : (b->n >= 8192 ? 32u : 16u);
+            if (cap > 2u * first) {
+                passes = 2;
+                pass_cap_of[0] = first;
+                pass_group_of[0] = lanes;
+                pass_cap_of[1] = cap;
+                pass_group_of[1] = 64;
+            }
         }
-        for (int i = 1; i < passes; ++i)   // K3w needs a work list and at most 16 pieces on every board it is handed: boards of
-            if (pass_group_of[i] == 64 && !(from_initial && b->bg.piece_count >= 1 && b->bg.piece_count <= BGS_BOUNCE_MAX_PIECES))
-                pass_group_of[i] = 8;      // the configured start position (a loaded batch may hold anything)
+        for (int i = 1; i < passes; ++i)   // (a plan from the environment: K3w only where the configured position fits its lanes)
+            if (pass_group_of[i] == 64 && !(b->bg.piece_count >= 1 && b->bg.piece_count <= BGS_BOUNCE_MAX_PIECES)) pass_group_of[i] = 8;
         if (passes >= 1 && pass_group_of[0] == 64) pass_group_of[0] = 1;
-        if (passes <= 1) {  // single launch (BGS_BOUNCE_PLAN=single, or a plan with one entry)
-            launch_rollout(b, seed, cap, from_initial, b->bounce_group, b->bounce_group == 1 ? b->rollout_wps : 8, nullptr, nullptr,
-                           queues);
+        if (passes <= 1) {  // single launch (BGS_BOUNCE_PLAN=single, a plan with one entry, a ply cap too short for two passes)
+            launch_rollout(b, seed, cap, from_initial, lanes, lanes == 1 ? b->rollout_wps : 8, nullptr, nullptr, queues);
             return;
         }
         for (int pass = 0; pass < passes; ++pass) {
@@ -2238,7 +2272,7 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
                 // boards still running below the final cap after the previous pass -> this pass's list
                 hipLaunchKernelGGL(k_bounce_compact, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->d_status, b->d_plies,
                                    b->n, cap, list, counts + pass);
-                launch_rollout(b, seed, pass_cap, false, group, 0, list, counts + pass, queues + pass);
+                launch_rollout(b, seed, pass_cap, group == 64 && from_initial, group, 0, list, counts + pass, queues + pass);
             }
             if (pass_cap >= cap) break;  // nothing can be left for a later pass
         }

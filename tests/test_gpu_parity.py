@@ -755,6 +755,30 @@ def test_bounce_write_state_roundtrip(batch_mod):
     assert status[0] == -1 and status[1] == -1 and (status[2:] == 0).all()
 
 
+def test_bounce_loaded_boards_of_any_crowd_finish_on_one_board_per_wave(batch_mod):
+    """A batch CONFIGURED with 12 pieces, LOADED with other people's boards -- 12, 16 and 22 pieces on the same 9x6 cells --
+    and rolled out from memory: the tail pass (K3w, 16 lanes here) plays what fits its lanes a piece per lane and hands a
+    board with more pieces to lane 0's thread-per-board code; all of it against the oracle, ply caps inside both passes."""
+    n = 1536
+    crowded16 = DEFAULT_BOUNCE.copy()
+    crowded16[3, [0, 2, 3, 5]] = [2, 1, 3, 1]
+    crowded22 = crowded16.copy()
+    crowded22[5] = [1, 1, 2, 2, 3, 3]
+    starts = [DEFAULT_BOUNCE, crowded16, crowded22]
+    for cap in (4096, 40, 17):
+        grids = np.stack([starts[i % 3] for i in range(n)]).astype(np.int8)
+        orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+        orc.grid[...] = grids
+        dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+        assert (dev.write_state(orc.grid, orc.player, orc.winner, orc.plies) == 0).all()
+        dev.set_first_game(11 << 32)
+        dev.rollout(SEED + 21, max_plies=cap)
+        total = orc.rollout(SEED + 21, first_game=11 << 32, max_plies=cap)
+        assert_same(dev, orc, f"loaded crowds, cap {cap}")
+        assert dev.steps == total
+        dev.close()
+
+
 def test_bounce_full_size_batch(batch_mod):
     """BASELINE config 4: Bounce default grid, batch 2^18, max_plies 4096."""
     n = 1 << 18

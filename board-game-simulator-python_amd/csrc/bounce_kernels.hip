@@ -2192,12 +2192,14 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
 // Random Bounce games have no length bound: most end within a few dozen plies, a few run for hundreds and some
 // never end (they stop at max_plies).  One launch that plays every game to the end spends most of its instruction
 // issue on waves in which a single long game is still alive.  The rollout therefore runs in PASSES with growing ply
-// caps (32, 512, max_plies by default): after a pass the boards that are still running are compacted into a work list
-// (k_bounce_compact) and the next pass plays only those, 64 (or 8) to a wave again.  A board resumes exactly where it
-// stopped (state in memory, RNG keyed by game id and ply), so the result is the one-launch result bit for bit.  The
-// passes are enqueued back to back on the batch's stream; the list lengths never visit the host.
-// Bulk passes use one lane per board (fewest instructions per ply); the last pass uses 8 lanes per board (shortest
-// ply latency, which is what a handful of very long games is bound by).  BGS_BOUNCE_PLAN="cap:lanes,..." overrides.
+// caps: after a pass the boards that are still running are compacted into a work list (k_bounce_compact) and the next
+// pass plays only those.  A board resumes exactly where it stopped (state in memory, RNG keyed by game id and ply), so
+// the result is the one-launch result bit for bit.  The passes are enqueued back to back on the batch's stream; the
+// list lengths never visit the host.
+// The automatic plan is two passes: the kernel that suits the batch (K3p / K3f with one lane per board for large ones:
+// fewest instructions per ply; 8 lanes per board for small ones) up to a short cap, then ONE BOARD PER WAVE (K3w: the
+// shortest ply, and a memo of action lists -- what a handful of very long games is bound by).  Start positions of more
+// than 16 pieces keep round 3's plan (one launch, or K3p + an 8-lane tail).  BGS_BOUNCE_PLAN="cap:lanes,..." overrides.
 void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
     uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
     if (cap > kMaxPlies) cap = kMaxPlies;  // plies are stored as uint16

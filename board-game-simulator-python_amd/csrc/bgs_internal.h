@@ -70,11 +70,12 @@ constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBo
 //   {64, 128}      1.92   3.10   6.53   7.7
 //   {128, 256}     1.63   2.92   6.85   8.8
 //   {160, 512}     1.12    --     --   10.2
-// Round 4, with the one-board-per-wave tail pass (K3w) behind the bulk pass (tools/k3w_depth_probe.sh, GPU_MAX_HW_QUEUES=24):
+// Round 4, with the one-board-per-wave tail pass (K3w, with its memo and links) behind the bulk pass
+// (tools/k3w_depth_probe.sh, GPU_MAX_HW_QUEUES=24):
 //   in flight        2      4      6      8      12     16     20
-//   {64, 128}      4.03   6.83   8.04   8.71   8.89   9.10   9.23
-//   {128, 256}     3.91   7.33   9.87  12.38  13.86  13.78  14.49
-//   {160, 512}     3.10   5.79   8.06  10.36  14.29  15.29  15.79
+//   {64, 128}      4.77   7.54   8.02   8.21   8.36   8.43   8.50
+//   {128, 256}     4.88   8.88  12.24  13.98  14.11  14.29  14.44
+//   {160, 512}     3.65   6.89   9.55  12.17  15.72  15.79  15.86
 struct BounceShape { int tail_cap; int boards_per_wave; };
 inline BounceShape bounce_shape(int launches_in_flight) {
     if (launches_in_flight >= 12) return {160, 512};

@@ -755,6 +755,34 @@ def test_bounce_write_state_roundtrip(batch_mod):
     assert status[0] == -1 and status[1] == -1 and (status[2:] == 0).all()
 
 
+@pytest.mark.parametrize("seed_offset,first_game", [(0, 196997), (5, 2278), (5, 260696)])
+def test_bounce_games_that_never_end(batch_mod, seed_offset, first_game):
+    """The games of the 2^18-board batches that run into max_plies (tools/bounce_endless.py found them: a handful of positions
+    visited over and over), each with 47 neighbours in a small batch: the one-board-per-wave pass plays them from its memo
+    of action lists and hops along its links between remembered positions for thousands of plies -- the board after 4096,
+    1000 and 999 plies (the cap inside a run of hops, even and odd) must be the oracle's, and so must a rollout that stops
+    at 300 plies and goes on from memory."""
+    n = 48
+    for cap in (4096, 1000, 999):
+        dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+        orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+        dev.set_first_game(first_game - 17)
+        dev.rollout(SEED + seed_offset, max_plies=cap, from_initial=True)
+        total = orc.rollout(SEED + seed_offset, first_game=first_game - 17, max_plies=cap)
+        assert int(orc.plies[17]) == cap, "the fixture's endless game is not where the test expects it"
+        assert_same(dev, orc, f"game {first_game}, cap {cap}")
+        assert dev.steps == total
+        dev.close()
+    dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+    orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+    dev.set_first_game(first_game - 17)
+    dev.rollout(SEED + seed_offset, max_plies=300, from_initial=True)
+    dev.rollout(SEED + seed_offset, max_plies=4096)
+    orc.rollout(SEED + seed_offset, first_game=first_game - 17, max_plies=4096)
+    assert_same(dev, orc, f"game {first_game}, resumed at 300")
+    dev.close()
+
+
 def test_bounce_loaded_boards_of_any_crowd_finish_on_one_board_per_wave(batch_mod):
     """A batch CONFIGURED with 12 pieces, LOADED with other people's boards -- 12, 16 and 22 pieces on the same 9x6 cells --
     and rolled out from memory: the tail pass (K3w, 16 lanes here) plays what fits its lanes a piece per lane and hands a

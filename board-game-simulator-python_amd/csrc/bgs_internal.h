@@ -80,7 +80,7 @@ struct BounceShape { int tail_cap; int boards_per_wave; };
 inline BounceShape bounce_shape(int launches_in_flight) {
     if (launches_in_flight >= 12) return {160, 512};
     if (launches_in_flight >= 4) return {128, 256};
-    return {64, 128};
+    return {80, 128};   // (one launch at a time, K3w on 8192 waves: caps of 64 / 80 / 96 / 112 / 128 read 2.78 / 2.86 / 2.80 / 2.69 / 2.62 x 10^9)
 }
 
 struct bgs_batch {

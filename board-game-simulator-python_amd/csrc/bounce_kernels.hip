@@ -2135,9 +2135,10 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         auto launch_wave = [&](auto pmax_tag) {
             constexpr int PMAX = decltype(pmax_tag)::value;
             // one-wave workgroups; a wave without a list entry leaves at once, so the grid is sized for the longest list the
-            // automatic plan produces (5 % of 2^18 boards after a 64-ply bulk pass: three entries a wave)
+            // automatic plan produces (5 % of 2^18 boards after a short bulk pass: one or two entries a wave; 2048 / 4096 /
+            // 8192 / 16384 waves read 2.39 / 2.61 / 2.78 / 2.83 x 10^9 one launch at a time, and the same with 4 and 20 in flight)
             static const int grid_env = [] { const char* e = getenv("BGS_BOUNCE_WAVE_GRID"); return e ? atoi(e) : 0; }();
-            const unsigned wave_grid = grid_env > 0 ? (unsigned)grid_env : 4096u;
+            const unsigned wave_grid = grid_env > 0 ? (unsigned)grid_env : 8192u;
             hipLaunchKernelGGL((k_bounce_rollout_wave<PMAX>), dim3(wave_grid), dim3(BGS_WAVE), 0,
                                b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
                                seed, b->first_game, cap, b->d_steps, worklist, work_count);

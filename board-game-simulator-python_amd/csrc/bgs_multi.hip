@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -48,6 +49,8 @@ struct Rccl {
     int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(ncclComm_t, int*) = nullptr;      // optional: what the communicator itself says (bgs_gather_comm)
+    int (*CommUserRank)(ncclComm_t, int*) = nullptr;   // optional
     bool ok = false;
     std::string why;   // when !ok
     std::string name;  // what was loaded
@@ -88,6 +91,8 @@ const Rccl& rccl() {
         r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(h, "ncclRecv"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(h, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send &&
                r.Recv && r.GetErrorString;
         if (!r.ok) r.why = "symbols missing";
@@ -255,7 +260,9 @@ extern "C" int bgs_multi_connect_rollout(const int* devices, int n_devices, int 
 //                     bgs_sink_rollout.
 // Groups are the same on every rank as long as every rank enqueues the same number of steps between two waits for the
 // newest ticket (what bgs_pipeline_* and bench.py do): a group closes when `batch` steps are there, and a partial group
-// only when somebody waits for one of its steps -- at the end of a region, with all of its steps submitted.
+// when somebody waits for one of its steps -- at the end of a region, with all of its steps submitted -- or, by itself,
+// BGS_GATHER_FLUSH_US (1000) microseconds after its first step was submitted.  Ranks whose groups are cut at different
+// steps still match: point-to-point messages between a pair of ranks are matched in the order they were posted.
 // ------------------------------------------------------------------------------------------------
 namespace {
 
@@ -290,6 +297,8 @@ struct bgs_gather {
     int batch = 0;            // steps per group of point-to-point calls: slots / 2 (BGS_GATHER_BATCH overrides; the launching
                               // thread runs `slots` steps ahead, so half of them can wait for their group to fill)
     int64_t flush_upto = 0;   // somebody waits for a step below this: send partial groups
+    int64_t flush_us = 1000;  // a partial group leaves by itself this long after its first step was submitted (BGS_GATHER_FLUSH_US)
+    int comm_ranks = -1, comm_rank = -1;   // ncclCommCount / ncclCommUserRank of the communicator (-1: the transport has no such query)
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;        // everything RCCL does for this rank is enqueued here
     std::vector<uint8_t*> codes;         // [slots] device: the rollout kernel writes a step's codes here (ranks != 0)
@@ -314,7 +323,8 @@ struct bgs_gather {
     int64_t submitted = 0;               // steps handed to the communication thread
     int64_t enqueued = 0;                // steps whose send / receives are on the communication stream
     bool stop = false;
-    bool failed = false;                 // (under mu) the communicator is beyond repair: every later call reports `error`
+    bool failed = false;                 // (under mu) a step or the transport failed: every later call reports `error`
+    bool comm_broken = false;            // (communication thread only) RCCL or the communication stream failed: nothing more is posted
     std::string error;
     std::thread worker;
 
@@ -330,25 +340,38 @@ struct bgs_gather {
     bool own_buffer() const { return !(rank == 0 && direct); }   // the step's codes live in a buffer of the gather's
 
     // One group: steps [t, t + k) -- stream waits, point-to-point calls, rank 0's copy, one record, rank 0's publishes.
+    // A step whose rollout could not be enqueued on THIS rank (step_ok down) still takes part in the group's point-to-point
+    // calls: the peers have posted -- or will post -- the matching receives / sends, and a rank that skipped its half would
+    // leave them waiting on their communication streams for ever (round-4 advisor).  Such a step's message carries zeros
+    // ("every game still running": rank 0 delivers 0 / 0 for those rows), the step is published as failed on the rank that
+    // failed, and that rank's gather refuses every later call.  Only a failure of the transport itself (an RCCL or HIP
+    // error on the communication stream: comm_broken) stops the posting.
     void run_group(int64_t t, int k, std::vector<int64_t>& st) {
         const Rccl& api = rccl();
-        bool ok = !has_failed();
+        bool ok = !comm_broken;
+        bool all_steps_ok = true;
         hipError_t he = hipSuccess;
         int ne = 0;
         for (int i = 0; i < k; ++i) {
             st[i] = t + i;  // rank 0: the launching thread claimed the sink ticket of this step (same numbers)
-            if (!step_ok[(t + i) % slots]) ok = false;   // (its rollout could not be enqueued: nothing to wait for)
+            if (!step_ok[(t + i) % slots]) all_steps_ok = false;   // (its rollout could not be enqueued: nothing to wait for)
         }
         // the communication stream waits for the LAST rollout of the group on every launch stream it used
         hipStream_t seen[kMaxGroup];
         int n_seen = 0;
         for (int i = k - 1; i >= 0 && ok; --i) {
             const int slot = (int)((t + i) % slots);
+            if (!step_ok[slot]) continue;   // (no event was recorded behind it)
             bool dup = false;
             for (int j = 0; j < n_seen; ++j) dup = dup || seen[j] == step_stream[slot];
             if (dup) continue;
             seen[n_seen++] = step_stream[slot];
             if ((he = hipStreamWaitEvent(stream, rolled[slot], 0)) != hipSuccess) ok = false;
+        }
+        // a failed step's codes: zeros (ranks other than 0 send them; rank 0's own rows of that step are never delivered)
+        for (int i = 0; i < k && ok && rank != 0; ++i) {
+            const int slot = (int)((t + i) % slots);
+            if (!step_ok[slot] && (he = hipMemsetAsync(codes[slot], 0, code_bytes, stream)) != hipSuccess) ok = false;
         }
         // The gather: one group of point-to-point calls, every OTHER rank -> rank 0.
         if (ok) {
@@ -388,7 +411,8 @@ struct bgs_gather {
             for (int i = 0; i < k; ++i)
                 bgs::sink_publish(sink, st[i], n * world, host[(t + i) % slots], ok && step_ok[(t + i) % slots], st[k - 1]);
         }
-        if (!ok && !has_failed()) {
+        if (!ok) comm_broken = true;
+        if ((!ok || !all_steps_ok) && !has_failed()) {
             if (ne != 0) fail_with("RCCL", api.GetErrorString(ne));
             else if (he != hipSuccess) fail_with("HIP", hipGetErrorString(he));
             else fail_with("rollout", "a step of the group could not be enqueued");
@@ -406,7 +430,11 @@ struct bgs_gather {
     }
 
     // The communication thread (worlds of two ranks and more).  A group closes when `batch` steps are there; a partial
-    // group goes out as soon as somebody waits for one of its steps (flush_upto).
+    // group goes out as soon as somebody waits for one of its steps (flush_upto) -- or by itself flush_us microseconds after
+    // its first step arrived (round-4 advisor: a rank that submits fewer than `batch` steps and then blocks on something
+    // outside the library -- a host barrier, a message from rank 0 -- without waiting for its newest ticket would never post
+    // its sends, and rank 0's wait for that step would never return).  In a loop that keeps submitting, a group of 6 fills
+    // in ~0.2 ms and the timer never fires.
     void run() {
         (void)hipSetDevice(device);
         std::vector<int64_t> st((size_t)kMaxGroup, -1);
@@ -414,8 +442,10 @@ struct bgs_gather {
             int k;
             {
                 std::unique_lock<std::mutex> lock(mu);
-                cv.wait(lock, [&] { return stop || submitted >= t + batch || (submitted > t && flush_upto > t); });
+                cv.wait(lock, [&] { return stop || submitted > t; });
                 if (submitted <= t) return;  // stop, nothing left
+                auto closed = [&] { return stop || submitted >= t + batch || flush_upto > t; };
+                if (!closed()) cv.wait_for(lock, std::chrono::microseconds(flush_us), closed);
                 k = (int)std::min<int64_t>(batch, submitted - t);
             }
             run_group(t, k, st);
@@ -549,6 +579,10 @@ int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_
     if (g->batch > slots) g->batch = slots;
     if (g->batch > kMaxGroup) g->batch = kMaxGroup;
     if (g->batch < 1) g->batch = 1;
+    if (const char* e = getenv("BGS_GATHER_FLUSH_US")) {
+        const long long v = atoll(e);
+        if (v >= 1) g->flush_us = v;
+    }
     g->host.assign(slots, nullptr);
     g->step_stream.assign(slots, nullptr);
     g->step_ok.assign(slots, 0);
@@ -580,6 +614,13 @@ int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_
         const int r = rccl().CommInitRank(&g->comm, world, u, rank);
         if (r != 0) rc = fail(BGS_ERR_RUNTIME, "ncclCommInitRank failed: %s", rccl().GetErrorString(r));
     }
+    if (rc == BGS_OK && g->comm) {
+        // what the communicator says about itself (the first line of an N > 1 bench run carries it: "did RCCL see N ranks?")
+        int v = -1;
+        if (rccl().CommCount && rccl().CommCount(g->comm, &v) == 0) g->comm_ranks = v;
+        v = -1;
+        if (rccl().CommUserRank && rccl().CommUserRank(g->comm, &v) == 0) g->comm_rank = v;
+    }
     if (rc == BGS_OK && world == 1 && g->comm) {
         // nothing will ever be sent: the library loaded and the id was good, which is all a one-rank world can show
         (void)rccl().CommDestroy(g->comm);
@@ -607,6 +648,13 @@ int bgs_gather_info(const bgs_gather* g, int* direct, int* batch, int* transport
     return BGS_OK;
 }
 
+int bgs_gather_comm(const bgs_gather* g, int* ranks, int* rank) {
+    NEED(g != nullptr, "gather is NULL");
+    if (ranks) *ranks = g->comm_ranks;
+    if (rank) *rank = g->comm_rank;
+    return BGS_OK;
+}
+
 int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, int8_t* host_reward,
                        int64_t* ticket) {
     // everything that can be refused is refused BEFORE a ticket exists (round-3 advisor: a claimed sink ticket that is
@@ -619,6 +667,7 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
     // fault injection for the tests (BGS_GATHER_INJECT_FAILURE=<step>): that step "cannot be enqueued" after its ticket
     // was claimed -- the path a device error would take
     static const long long inject = getenv("BGS_GATHER_INJECT_FAILURE") ? atoll(getenv("BGS_GATHER_INJECT_FAILURE")) : -1;
+    static const int inject_rank = getenv("BGS_GATHER_INJECT_RANK") ? atoi(getenv("BGS_GATHER_INJECT_RANK")) : -1;  // -1: every rank
     if (g->world == 1) return bgs_sink_rollout(g->sink, b, seed, max_plies, flags, host_reward, ticket);
     HIP_TRY(hipSetDevice(g->device));
     int64_t t;
@@ -676,7 +725,7 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
     }
     // From here on the step is submitted whatever happens -- a step that could not be enqueued travels through the
     // communication thread with its flag down, so that rank 0's sink ticket is published in order and nothing stalls.
-    if (ok && t == inject) {
+    if (ok && t == inject && (inject_rank < 0 || inject_rank == g->rank)) {
         ok = false;
         rc = fail(BGS_ERR_RUNTIME, "injected failure at step %lld (BGS_GATHER_INJECT_FAILURE)", (long long)t);
     }
@@ -691,9 +740,9 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
         g->step_ok[slot] = ok ? 1 : 0;
         g->submitted = t + 1;
         if (!ok) g->flush_upto = std::max(g->flush_upto, t + 1);   // (let the failed step's group leave at once)
-        // the communication thread sleeps until a whole group is there (or somebody asks for a flush): waking it for
-        // every step only to have it go back to sleep costs both threads a futex round trip per step
-        wake = g->submitted >= g->enqueued + g->batch || g->flush_upto > g->enqueued;
+        // the communication thread is woken for the FIRST step of a group (it starts the group's flush timer and goes
+        // back to sleep), when the group is full, and when somebody asks for a flush -- not for the steps in between
+        wake = g->submitted == g->enqueued + 1 || g->submitted >= g->enqueued + g->batch || g->flush_upto > g->enqueued;
     }
     if (wake) g->cv.notify_all();
     if (ticket) *ticket = t;

@@ -80,6 +80,7 @@ struct bgs_pipeline {
     bgs_gather* gather = nullptr;
     std::vector<int8_t*> host;         // [n_host] destinations (NULL entries: a gather rank other than 0)
     std::vector<int64_t> ticket;       // [n_host] the hand-over last delivered into that array, -1 = none pending
+    std::vector<int64_t> held;         // [n_host] index of the hand-over whose rewards that array holds (or will hold), -1 = none
     uint64_t seed0 = 0;
     int32_t max_plies = 0x7FFFFFFF;
     uint32_t flags = BGS_ROLLOUT_FROM_INITIAL;
@@ -125,6 +126,7 @@ int bgs_pipeline_create(bgs_batch* const* batches, int depth, bgs_reward_sink* s
     p->gather = gather;
     for (int h = 0; h < n_host; ++h) p->host.push_back(host_rewards[h]);
     p->ticket.assign(n_host, -1);
+    p->held.assign(n_host, -1);
     p->seed0 = seed0;
     p->max_plies = max_plies;
     p->flags = flags;
@@ -159,7 +161,7 @@ static int consume(bgs_pipeline* p, int64_t j) {
     return bgs_progress_store(p->consumed, j + 1);
 }
 
-int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_stride) {
+static int enqueue_steps(bgs_pipeline* p, const uint64_t* seeds, int64_t count, int handover, int time_stride) {
     NEED(p != nullptr && count >= 0, "bad argument");
     NEED(!handover || p->sink || p->gather, "this pipeline has no hand-over");
     HIP_TRY(hipSetDevice(p->device));
@@ -167,7 +169,7 @@ int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_
     const int n_host = (int)p->host.size();
     for (int64_t i = 0; i < count; ++i) {
         bgs_batch* b = p->batches[p->step % depth];
-        const uint64_t seed = p->seed0 + (uint64_t)p->step;
+        const uint64_t seed = seeds ? seeds[i] : p->seed0 + (uint64_t)p->step;
         size_t bracket = (size_t)-1;
         if (time_stride > 0 && i % time_stride == 0) {
             if (p->brackets == p->ev0.size()) {
@@ -201,6 +203,7 @@ int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_
             NEED(!p->rank_words || t == j, "a pipeline on a shared array needs a sink of its own (ticket %lld for hand-over %lld)",
                  (long long)t, (long long)j);
             p->ticket[h] = t;
+            p->held[h] = j;
             ++p->handed;
         } else {
             if ((rc = bgs_rollout(b, seed, p->max_plies, p->flags))) return rc;
@@ -214,6 +217,27 @@ int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_
         ++p->step;
     }
     return BGS_OK;
+}
+
+int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_stride) {
+    return enqueue_steps(p, nullptr, count, handover, time_stride);
+}
+
+int bgs_pipeline_enqueue_seeds(bgs_pipeline* p, const uint64_t* seeds, int64_t count, int handover) {
+    NEED(seeds != nullptr || count == 0, "seeds is NULL");
+    return enqueue_steps(p, seeds, count, handover, 0);
+}
+
+int bgs_pipeline_wait(bgs_pipeline* p, int64_t handover_index) {
+    NEED(p != nullptr, "pipeline is NULL");
+    NEED(handover_index >= 0 && handover_index < p->handed, "hand-over %lld has not been enqueued", (long long)handover_index);
+    const int h = (int)(handover_index % (int64_t)p->host.size());
+    NEED(p->held[h] == handover_index, "hand-over %lld is not in flight any more: its host array was reused by hand-over %lld",
+         (long long)handover_index, (long long)p->held[h]);
+    if (p->ticket[h] < 0) return BGS_OK;   // waited for before
+    int rc = wait_ticket(p, p->ticket[h]);
+    if (rc == BGS_OK) p->ticket[h] = -1;
+    return rc;
 }
 
 int bgs_pipeline_drain(bgs_pipeline* p) {

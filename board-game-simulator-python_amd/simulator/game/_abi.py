@@ -142,6 +142,7 @@ SIGNATURES = {
     ),
     "bgs_gather_wait": (ctypes.c_int, [c_handle, ctypes.c_int64]),
     "bgs_gather_info": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "bgs_gather_comm": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "bgs_gather_transport": (ctypes.c_char_p, []),
     "bgs_gather_destroy": (ctypes.c_int, [c_handle]),
     "bgs_pipeline_create": (
@@ -150,6 +151,8 @@ SIGNATURES = {
          ctypes.c_int32, ctypes.c_uint32, ctypes.POINTER(c_handle)],
     ),
     "bgs_pipeline_enqueue": (ctypes.c_int, [c_handle, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "bgs_pipeline_enqueue_seeds": (ctypes.c_int, [c_handle, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
+    "bgs_pipeline_wait": (ctypes.c_int, [c_handle, ctypes.c_int64]),
     "bgs_pipeline_drain": (ctypes.c_int, [c_handle]),
     "bgs_pipeline_progress": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "bgs_pipeline_kernel_ms": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),

@@ -72,6 +72,16 @@ class RolloutExecutor:
     def enqueue(self, count: int, handover: bool = True, time_stride: int = 0) -> None:
         _abi.check(_abi.lib().bgs_pipeline_enqueue(self._handle, int(count), 1 if handover else 0, int(time_stride)))
 
+    def enqueue_seeds(self, seeds, handover: bool = True) -> None:
+        """`enqueue` with the seed of every step given (a C-contiguous uint64 array), instead of seed0 + step index."""
+        arr = np.ascontiguousarray(seeds, dtype=np.uint64)
+        _abi.check(_abi.lib().bgs_pipeline_enqueue_seeds(self._handle, ctypes.c_void_p(arr.ctypes.data), int(arr.size),
+                                                         1 if handover else 0))
+
+    def wait_handover(self, index: int) -> None:
+        """Until hand-over number `index` is in its host array `host_arrays[index % len(host_arrays)]`."""
+        _abi.check(_abi.lib().bgs_pipeline_wait(self._handle, int(index)))
+
     def drain(self) -> None:
         _abi.check(_abi.lib().bgs_pipeline_drain(self._handle))
 
@@ -206,45 +216,64 @@ class RolloutPipeline:
             raise ValueError(f"need {self.slots} host arrays (arrays_per_stream x depth)")
         self.host = list(host_arrays)
         self.sink = RewardSink(self.n, slots=self.slots, threads=max(1, host_threads), device=device)
-        self._tickets = [None] * self.slots
-        self._steps = [None] * self.slots
-        self._next = 0
+        # the loop itself is native: the executor enqueues a BURST of steps per library call (bgs_pipeline_enqueue_seeds)
+        self._exe = RolloutExecutor(self.batches, sink=self.sink, host_arrays=self.host, seed0=0, max_plies=self.max_plies)
+        self._next = 0        # steps enqueued
 
     # ---- one step at a time -----------------------------------------------------------------------
     def submit(self, seed: int) -> int:
-        """Enqueue one step (all n boards, initial state to terminal) and return its step index.  Blocks only if the host
-        array this step reuses (the one of step index - arrays_per_stream * depth) has not been collected with `result()` yet AND is
-        still being delivered."""
-        i = self._next
-        h = i % self.slots
-        if self._tickets[h] is not None:
-            self.sink.wait(self._tickets[h])  # the array is about to be overwritten: its previous delivery must be over
-        self._tickets[h] = self.sink.rollout(self.batches[i % self.depth], self.host[h], int(seed), self.max_plies, from_initial=True)
-        self._steps[h] = i
-        self._next = i + 1
-        return i
+        """Enqueue one step (all n boards, initial state to terminal) and return its step index.  Blocks only while the
+        host array this step reuses (the one of step index - arrays_per_stream * depth) is still being delivered."""
+        return self.submit_many([seed])[0]
+
+    def submit_many(self, seeds: Sequence[int]) -> range:
+        """Enqueue len(seeds) steps with ONE library call (a Python call per step costs the launching thread most of a
+        2^20-board Connect4 step); returns their step indices."""
+        arr = np.ascontiguousarray(np.asarray([int(s) & 0xFFFFFFFFFFFFFFFF for s in seeds], dtype=np.uint64))
+        first = self._next
+        if arr.size:
+            self._exe.enqueue_seeds(arr)
+            self._next += int(arr.size)
+        return range(first, self._next)
 
     def result(self, step: int) -> np.ndarray:
         """The rewards int8[n, 2] of `step` (waits for their delivery).  The array is reused by step + arrays_per_stream * depth."""
-        h = step % self.slots
-        if self._steps[h] != step:
+        if step < 0 or step >= self._next or step + self.slots < self._next:
             raise KeyError(f"step {step} is not in flight any more (its host array was reused)")
-        if self._tickets[h] is not None:
-            self.sink.wait(self._tickets[h])
-            self._tickets[h] = None
-        return self.host[h]
+        self._exe.wait_handover(step)
+        return self.host[step % self.slots]
 
     # ---- the loop ----------------------------------------------------------------------------------
     def run(self, seeds: Iterable[int]) -> Iterator[Tuple[int, np.ndarray]]:
-        """Yield (step, rewards) for every seed, in order, keeping `depth` steps ahead of the consumer."""
-        pending = []
-        for seed in seeds:
-            pending.append(self.submit(seed))
-            if len(pending) > self.depth:
-                step = pending.pop(0)
-                yield step, self.result(step)
-        for step in pending:
-            yield step, self.result(step)
+        """Yield (step, rewards) for every seed, in order.  The launches run ahead of the consumer by up to
+        arrays_per_stream * depth steps and are enqueued in bursts (one library call per burst, not per step); the array
+        of a yielded step stays untouched until the consumer asks for the next one."""
+        it = iter(seeds)
+        burst = max(1, self.slots // 3)
+        exhausted = False
+        nxt = self._next          # the next step to yield
+        while True:
+            # steps [nxt, self._next) are in flight or delivered; the consumer holds nothing (it asked for the next step):
+            # everything up to nxt + slots may be enqueued without touching the array of a step that is still to be yielded
+            room = nxt + self.slots - self._next
+            if not exhausted and (room >= burst or self._next == nxt):
+                chunk = []
+                for seed in it:
+                    chunk.append(seed)
+                    if len(chunk) >= room:
+                        break
+                else:
+                    exhausted = True
+                self.submit_many(chunk)
+            if nxt >= self._next:
+                if exhausted:
+                    return
+                continue
+            rewards = self.result(nxt)
+            nxt += 1
+            # while the consumer holds the array of step nxt - 1, step nxt - 1 + slots must not be enqueued: `room` above
+            # is computed from nxt AFTER the consumer has come back
+            yield nxt - 1, rewards
 
     @property
     def env_steps(self) -> int:
@@ -252,11 +281,10 @@ class RolloutPipeline:
         return sum(b.steps for b in self.batches)
 
     def close(self) -> None:
+        if getattr(self, "_exe", None) is not None:
+            self._exe.close()   # (drains: every enqueued step is delivered before the sink goes)
+            self._exe = None
         if getattr(self, "sink", None) is not None:
-            for h, t in enumerate(self._tickets):
-                if t is not None:
-                    self.sink.wait(t)
-                    self._tickets[h] = None
             self.sink.close()
             self.sink = None
         for b in getattr(self, "batches", []):

@@ -205,7 +205,13 @@ class RewardGather:
     node), rank 0's sink expands them into ONE host array int8[world * per_rank, 2] in global game order
     (`bgs_gather_*`: persistent communicator, communication stream and thread inside libbgs.so; the launching thread
     makes one call per step and never enters RCCL).  `dist` (torch.distributed, initialised, any backend) only carries
-    the communicator's 128-byte id from rank 0 to the others."""
+    the communicator's 128-byte id from rank 0 to the others.
+
+    Every rank makes the same sequence of `rollout` calls.  A step's codes leave in a group with its neighbours: when the
+    group is full, when somebody `wait`s for one of its steps, or by themselves a millisecond after the group's first step
+    (BGS_GATHER_FLUSH_US) -- so a rank may submit a few steps and then block on something else.  A step that cannot be
+    enqueued on one rank raises THERE (and on every later call of that rank's gather); its message still goes out, as
+    zeros, so that the peers are not left waiting: rank 0 delivers reward 0 / 0 for that rank's rows of that step."""
 
     def __init__(self, dist, per_rank: int, slots: int = 6, host_threads: int = 6, device: int = 0):
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -240,13 +246,17 @@ class RewardGather:
     def info(self) -> dict:
         """How the gather runs: {"direct": receives straight into the sink's device-mapped slots (else device memory + a
         copy kernel), "batch": steps per group of point-to-point calls, "transport_check": "none" (one rank) / "passed" /
-        "passed after falling back from direct receives", "transport": the library in use}."""
+        "passed after falling back from direct receives", "transport": the library in use, "ranks" / "rank": what the
+        COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank; None when the transport has no such query)}."""
         direct, batch, check = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         _abi.check(_abi.lib().bgs_gather_info(self._handle, ctypes.byref(direct), ctypes.byref(batch), ctypes.byref(check)))
+        ranks, rank = ctypes.c_int(-1), ctypes.c_int(-1)
+        _abi.check(_abi.lib().bgs_gather_comm(self._handle, ctypes.byref(ranks), ctypes.byref(rank)))
         name = _abi.lib().bgs_gather_transport()
         return {"direct": bool(direct.value), "batch": batch.value,
                 "transport_check": ("none", "passed", "passed after falling back from direct receives")[check.value],
-                "transport": name.decode() if name else ""}
+                "transport": name.decode() if name else "",
+                "ranks": ranks.value if ranks.value >= 0 else None, "rank": rank.value if rank.value >= 0 else None}
 
     def wait(self, ticket: int) -> None:
         """Rank 0: the step's rewards of ALL ranks are in its host array; other ranks: this rank's codes have left."""

@@ -1,4 +1,4 @@
-// fake_rccl.hip -- TEST-ONLY stand-in for the nine nccl* entry points libbgs.so loads at run time (csrc/bgs_multi.hip,
+// fake_rccl.hip -- TEST-ONLY stand-in for the nccl* entry points (nine required, two optional queries) libbgs.so loads at run time (csrc/bgs_multi.hip,
 // `BGS_RCCL_LIB=<this library>`).  RCCL refuses two ranks on one device, and the test box has one GPU: with this transport
 // several PROCESSES SHARING THE ONE GPU (or several logical devices of one process) execute libbgs's real world > 1 code --
 // the communication thread's groups of ncclSend / ncclRecv, partial groups, receives into the sink's device-mapped
@@ -311,6 +311,18 @@ int ncclCommDestroy(void* comm) {
         delete r;
     }
     delete c;
+    return 0;
+}
+
+int ncclCommCount(void* comm, int* count) {
+    if (!comm || !count) return fail("bad arguments to ncclCommCount");
+    *count = static_cast<Comm*>(comm)->world;
+    return 0;
+}
+
+int ncclCommUserRank(void* comm, int* rank) {
+    if (!comm || !rank) return fail("bad arguments to ncclCommUserRank");
+    *rank = static_cast<Comm*>(comm)->rank;
     return 0;
 }
 

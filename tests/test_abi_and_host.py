@@ -30,6 +30,22 @@ def test_library_exports_every_declared_symbol():
     assert _abi.lib().bgs_version() >= 100
 
 
+def test_dynamic_symbol_table_is_the_header():
+    """libbgs.so is built with -fvisibility=hidden and a version script: `nm -D --defined-only` shows the functions
+    include/bgs.h declares and nothing else -- no bgs::* helpers, no STL instantiations, no compiler markers."""
+    import subprocess
+
+    from simulator.game import _abi
+
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _abi.LIB_PATH], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == declared_symbols()
+    with open(os.path.join(ROOT, "include", "bgs.h")) as fh:
+        header = fh.read()
+    # the one number the documents quote is derived from the header (DESIGN.md says "see include/bgs.h", not a count)
+    assert len(exported) == len(re.findall(r"^BGS_API ", header, flags=re.M))
+
+
 def test_header_is_plain_c():
     import subprocess, tempfile
 

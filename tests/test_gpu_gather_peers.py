@@ -28,14 +28,18 @@ def build_fake_rccl():
     return FAKE
 
 
-def run_ranks(tmp_path, world, mode, extra_env=None, timeout=240):
+def run_ranks(tmp_path, world, mode, extra_env=None, timeout=240, per_process=1):
+    """`world` ranks as world / per_process processes (per_process ranks on threads of one process: the box allows at most
+    6 processes on the card); returns one stdout / stderr per PROCESS."""
     env = dict(os.environ, BGS_RCCL_LIB=build_fake_rccl())
     env.update(extra_env or {})
-    procs = [subprocess.Popen(["timeout", "-k", "10", str(timeout), sys.executable, PEER, str(tmp_path), str(r), str(world), mode],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    groups = [",".join(str(r) for r in range(first, min(world, first + per_process))) for first in range(0, world, per_process)]
+    assert len(groups) <= 6
+    procs = [subprocess.Popen(["timeout", "-k", "10", str(timeout), sys.executable, PEER, str(tmp_path), g, str(world), mode],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for g in groups]
     outs = [p.communicate() for p in procs]
-    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {r} exit {p.returncode}\n{out[-2000:]}\n{err[-3000:]}"
+    for g, p, (out, err) in zip(groups, procs, outs):
+        assert p.returncode == 0, f"rank(s) {g} exit {p.returncode}\n{out[-2000:]}\n{err[-3000:]}"
     return [out for out, _ in outs], [err for _, err in outs]
 
 
@@ -73,3 +77,48 @@ def test_one_process_two_logical_devices(tmp_path):
     games [r n, (r + 1) n)."""
     outs, _ = run_ranks(tmp_path, 1, "multi")
     assert "MULTI_OK" in outs[0]
+
+
+@pytest.mark.parametrize("direct", ["0", "1"])
+def test_gather_with_eight_ranks(tmp_path, direct):
+    """The world size BASELINE config 5 names.  Eight ranks as 4 processes x 2 ranks (the box's limit is 6 processes on
+    the card): rank 0 receives 7 messages per step at dst + r * code_bytes, its sink expands 8 x n games per step; {copy
+    kernel, direct receives} x the default group (slots / 2); every rank's rows of every delivered step == oracle."""
+    outs, _ = run_ranks(tmp_path, 8, "steps", {"BGS_GATHER_DIRECT": direct, "PEER_SLOW_RANK": "5", "PEER_GAMES": "4096",
+                                               "BGS_FAKE_RCCL_MSG_BYTES": "4096"}, per_process=2, timeout=400)
+    text = "\n".join(outs)
+    for r in range(8):
+        assert f"PEER_OK rank {r} verified 43" in text, text
+    assert f"'direct': {direct == '1'}" in outs[0] and "'batch': 4" in outs[0] and "'ranks': 8" in outs[0]
+
+
+@pytest.mark.parametrize("world,per_process", [(2, 1), (4, 1), (8, 2)])
+def test_config_5_shapes_through_the_gather(tmp_path, world, per_process):
+    """BASELINE config 5's arithmetic at the world sizes the metric names: 2^18 games per rank here (2^20 with
+    PEER_GAMES=1048576, tools/gather_full_size.sh), 12 host arrays, groups of 6, 3 batches in flight, the native loop;
+    the communicator itself reports `world` ranks; rank 0 compares every rank's rows of all 14 steps with the oracle."""
+    n = 1 << 18
+    outs, _ = run_ranks(tmp_path, world, "full", {"PEER_GAMES": str(n), "PEER_STEPS": "14", "BGS_FAKE_RCCL_MSG_BYTES": str(n // 4)},
+                        per_process=per_process, timeout=600)
+    text = "\n".join(outs)
+    for r in range(world):
+        assert f"FULL_OK rank {r} of {world} verified 14 steps of {world} x {n} games" in text, text
+    assert f"'ranks': {world}" in outs[0]
+
+
+def test_a_rank_that_submits_one_step_and_then_blocks_elsewhere(tmp_path):
+    """Round-4 advisor (medium): ranks other than 0 submit ONE step of a group of 4 and sit at a barrier that only opens
+    when rank 0 has that step's rewards; nobody but rank 0 waits for a ticket.  The partial group leaves by itself."""
+    outs, _ = run_ranks(tmp_path, 3, "lone_step", {"BGS_GATHER_BATCH": "4"}, timeout=120)
+    for r, out in enumerate(outs):
+        assert f"LONE_OK rank {r}" in out, out
+
+
+@pytest.mark.parametrize("bad_rank", [1, 0])
+def test_one_rank_fails_alone_and_nobody_is_left_waiting(tmp_path, bad_rank):
+    """Round-4 advisor (low): a step that cannot be enqueued on ONE rank.  That rank reports it; its message still goes
+    out (zeros), the peers' groups complete, rank 0 delivers every step."""
+    outs, _ = run_ranks(tmp_path, 3, "inject_one", {"BGS_GATHER_INJECT_FAILURE": "5", "BGS_GATHER_INJECT_RANK": str(bad_rank),
+                                                    "BGS_GATHER_BATCH": "4"}, timeout=120)
+    for r, out in enumerate(outs):
+        assert f"INJECT_ONE_OK rank {r}" in out, out

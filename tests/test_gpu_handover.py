@@ -683,14 +683,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("gather,ranks", [("shm", 3), ("rccl", 2), ("both", 3)])
+@pytest.mark.parametrize("gather,ranks", [("shm", 3), ("rccl", 2), ("both", 2), ("both", 4), ("both", 6)])
 def test_bench_multi_rank_rehearsal(gather, ranks):
     """bench.py's own N > 1 loops as child processes sharing this box's GPU (gloo carries the control messages; RCCL
     cannot run several ranks on one GPU): `shm` -- one host array in shared memory, every rank's sink delivers its rows,
     rank 0 consumes (futex hand-shake inside the native loop); `rccl` -- the IN-LIBRARY gather (bgs_gather_*, the code a
     real 8-GPU run executes) over the tests' shared-memory stand-in for RCCL; `both` -- the default of an N > 1 run: the
     two one after the other, `value` from the shared array.  Rank 0's host array must verify against a replay of EVERY
-    rank's first games."""
+    rank's first games.  World sizes 2, 4 and 6: the metric's 1 / 2 / 4 / 8 as far as the box lets a run go -- it allows
+    at most 6 processes on the card; the gather's N = 8 arithmetic runs as 4 processes x 2 ranks in
+    tests/test_gpu_gather_peers.py, the shared array's 8-rank hand-shake on the CPU in tests/test_sharding_gloo.py."""
     from tests.test_gpu_gather_peers import build_fake_rccl
 
     port = _free_port()
@@ -715,6 +717,7 @@ def test_bench_multi_rank_rehearsal(gather, ranks):
     if gather != "shm":
         info = d["gather_rccl"]["gather_info"]
         assert info["direct"] is False and info["batch"] == 6 and info["transport_check"] == "passed"
+        assert info["ranks"] == ranks and info["rank"] == 0   # what the COMMUNICATOR says, not what the launcher asked for
         assert "libfake_rccl" in info["transport"] and "RCCL gather inside the library" in d["gather_rccl"]["sharding"]
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # only rank 0 prints the line
 

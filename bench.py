@@ -168,34 +168,49 @@ def cpu_threads():
 
 def cpu_baseline(last_seed, host_reward_head):
     """Time the oracle on this host's cores on a bounded sample of the same workload, and use the same run to
-    cross-check the rewards the last timed step delivered (first games of the host array)."""
+    cross-check the rewards the last timed step delivered (first games of the host array).  `value` is the BEST of a few
+    thread-team sizes -- a one-GPU share of the host (16), 64, every core the process may use -- with the team that gave it
+    in `cores`; every team plays boards it touched first (a fresh batch per team, the oracle's reset is parallel)."""
     import ctypes
 
     import numpy as np
 
     from oracle import oracle
 
-    avail, cap, cores = cpu_threads()
-    os.environ["OMP_NUM_THREADS"] = str(cores)
+    avail, cap, share = cpu_threads()
     n = 1 << 20
-    reps = 12  # (~1.2 s on 16 threads: about 20 s of CPU work)
-    orc = oracle.ConnectOracle(HEIGHT, WIDTH, COUNT, n)
-    orc.rollout(SEED, max_plies=4)  # touch the pages, start the thread team
-    total, elapsed = 0, 0.0
-    parity = None
-    for r in range(reps):
-        seed = last_seed if r == 0 else SEED + 1000 + r
-        orc.reset()
-        t0 = time.perf_counter()
-        total += orc.rollout(seed)
-        elapsed += time.perf_counter() - t0
-        if r == 0 and host_reward_head is not None:
-            parity = bool(np.array_equal(orc.reward[: host_reward_head.shape[0]], host_reward_head))
+    teams = sorted({t for t in (share, 64, avail) if 1 <= t <= avail})
+    if os.environ.get("BGS_CPU_ALL_CORES", "1") == "0":
+        teams = [share]
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+        teams = [share]
+        os.environ["OMP_NUM_THREADS"] = str(share)
+    by_team, parity = {}, None
+    for team in teams:
+        if gomp is not None:
+            gomp.omp_set_num_threads(team)
+        orc = oracle.ConnectOracle(HEIGHT, WIDTH, COUNT, n)   # (its reset: first touch by this team)
+        orc.rollout(SEED, max_plies=4)  # start the thread team
+        reps = 8 if team == share else 4   # (~1.2 s a repetition on 16 threads: about 20 s of CPU work in all)
+        total, elapsed = 0, 0.0
+        for r in range(reps):
+            seed = last_seed if (r == 0 and team == share) else SEED + 1000 + 16 * team + r
+            orc.reset()
+            t0 = time.perf_counter()
+            total += orc.rollout(seed)
+            elapsed += time.perf_counter() - t0
+            if r == 0 and team == share and host_reward_head is not None:
+                parity = bool(np.array_equal(orc.reward[: host_reward_head.shape[0]], host_reward_head))
+        by_team[team] = {"value": total / elapsed, "reps": reps, "env_steps": total}
+        del orc
+    best = max(by_team, key=lambda t: by_team[t]["value"])
     # the same oracle on ONE thread (the reference's own loop is single-threaded under the GIL, SURVEY 8d), and
     # BASELINE.json's config 1: the latency of ONE game from the initial state to the end (N = 1)
     single = latency = plies = None
-    try:
-        gomp = ctypes.CDLL("libgomp.so.1")
+    if gomp is not None:
         gomp.omp_set_num_threads(1)
         small = oracle.ConnectOracle(HEIGHT, WIDTH, COUNT, 1 << 18)
         t0 = time.perf_counter()
@@ -210,33 +225,22 @@ def cpu_baseline(last_seed, host_reward_head):
             moved += one.rollout(SEED, first_game=g)
         latency = (time.perf_counter() - t0) / games * 1e6
         plies = moved / games
-        gomp.omp_set_num_threads(cores)
-    except OSError:
-        pass
-    # ... and on EVERY core the process may use (the north-star asks for the box's host cores; the 16-thread figure above is
-    # what a one-GPU share of the host gets): a shorter sample, the thread team is new
+        gomp.omp_set_num_threads(share)
     all_cores = None
-    if avail > cores and os.environ.get("BGS_CPU_ALL_CORES", "1") != "0":
-        try:
-            gomp = ctypes.CDLL("libgomp.so.1")
-            gomp.omp_set_num_threads(avail)
-            orc.reset()
-            orc.rollout(SEED + 2000, max_plies=4)
-            t_all, s_all = 0.0, 0
-            for r in range(4):
-                orc.reset()
-                t0 = time.perf_counter()
-                s_all += orc.rollout(SEED + 2001 + r)
-                t_all += time.perf_counter() - t0
-            all_cores = {"value": s_all / t_all, "unit": "env-steps/s", "cores": avail, "sample": f"4 x 2^20 games ({s_all} env-steps)"}
-            gomp.omp_set_num_threads(cores)
-        except OSError:
-            pass
-    capped = f"; {avail} cores visible, capped at BGS_CPU_THREADS={cap}" if avail > cap else ""
+    if avail in by_team and avail != share:
+        all_cores = {"value": by_team[avail]["value"], "unit": "env-steps/s", "cores": avail,
+                     "sample": f"{by_team[avail]['reps']} x 2^20 games ({by_team[avail]['env_steps']} env-steps)"}
+    binds = ""
+    if avail in by_team and by_team[avail]["value"] < 0.95 * by_team[best]["value"]:
+        binds = (f"; every visible core ({avail} threads) is SLOWER than {best} threads here: the boards are first touched by the team "
+                 "that plays them and the schedule is static, so what binds beyond that team size is not page placement -- on the "
+                 "GPU boxes of this pool the process sees all of the host's hardware threads but is granted a share of them")
     return {
-        "value": total / elapsed,
+        "value": by_team[best]["value"],
         "unit": "env-steps/s",
-        "cores": cores,
+        "cores": best,
+        "by_threads": {str(t): by_team[t]["value"] for t in teams},
+        "gpu_share_of_host": {"cores": share, "value": by_team[share]["value"]},
         "single_thread_value": single,
         "single_game_latency_us": latency,
         "single_game_mean_plies": plies,
@@ -245,27 +249,53 @@ def cpu_baseline(last_seed, host_reward_head):
         "kind_note": "restatement: oracle/bgs_oracle.c restates the algorithm in plain C from the reference's binding sites and "
                      "tests; it is neither the reference's code nor a port of it (the reference's core is an un-vendored dependency)",
         "all_cores": all_cores,
-        "sample": f"CPU restatement (oracle/bgs_oracle.c, OpenMP, {cores} threads{capped}) -- the reference's own core is not "
-        f"buildable offline: {reps} x 2^20 Connect4(6,7,4) games from the initial state ({total} env-steps); "
+        "sample": f"CPU restatement (oracle/bgs_oracle.c, OpenMP; best of {teams} threads = {best}; {avail} cores visible, "
+        f"BGS_CPU_THREADS={cap} is one GPU's share of the host) -- the reference's own core is not buildable offline: "
+        f"{by_team[best]['reps']} x 2^20 Connect4(6,7,4) games from the initial state ({by_team[best]['env_steps']} env-steps), "
+        f"boards first touched by the team that plays them{binds}; "
         "single_game_latency_us = one game (BASELINE config 1, N = 1) per reset + rollout call of the oracle through ctypes, mean "
         "of 2000 games (mostly call overhead: single_game_us_inside_a_batch is the same game's share of a one-thread batch)",
         "parity_with_host_rewards": parity,
     }
 
 
-def committed_counters(build_id, stem, kernel_substring=None):
-    """Per-launch PMC figures (profiles/r*_<stem>.json, newest round first), valid only for the build they were
-    measured on and for default launch settings."""
+# which kernel unit (csrc/Makefile: connect_kernels / bounce_kernels / generic_kernels) a counters file describes
+STEM_UNIT = {"rollout_counters": "connect", "bench_kernel": "connect", "k1": "connect", "k2c": "connect", "k2b": "connect",
+             "bounce": "bounce", "bounce_solo": "bounce", "bounce_k3f": "bounce", "bounce_lane_groups": "bounce"}
+BUSY_CASE_UNIT = {"k2o_solo": "connect", "k2o_3deep": "connect", "k2c_solo": "connect", "k2c_8deep": "connect",
+                  "k3p_solo": "bounce", "k3p_8x": "bounce"}
+
+
+def counters_match(c, ids, unit):
+    """Is the counters record `c` (a profiles/*.json file, or one case of the busy file) about the code that is running?
+    Files written since round 5 name the UNIT id of their kernel (bgs_kernel_unit_id: the unit's source, bgs_common.h, its
+    own header, the flags) and are matched on that -- so an edit to the Bounce unit leaves the Connect counters quotable;
+    older files carry only the library's global build id and are matched on it."""
+    if c.get("unit_id"):
+        return c["unit_id"] == ids["units"].get(c.get("unit") or unit)
+    return c.get("build_id") == ids["build"]
+
+
+def running_ids():
+    from simulator.game import _abi
+
+    return {"build": _abi.build_id(), "units": _abi.unit_ids()}
+
+
+def committed_counters(ids, stem, kernel_substring=None, profiles_dir=None):
+    """Per-launch PMC figures (profiles/r*_<stem>.json, newest round first), valid only for the kernel unit they were
+    measured on (`ids` = running_ids()) and for default launch settings."""
     overrides = [k for k in LAUNCH_OVERRIDES if os.environ.get(k)]
     if overrides:
         return None, f"launch overrides set ({', '.join(overrides)}): the committed counters describe the default launch"
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{stem}.json")), reverse=True)
+    unit = STEM_UNIT[stem]
+    files = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), f"r[0-9][0-9]_{stem}.json")), reverse=True)
     seen = []
     for path in files:
         with open(path) as fh:
             c = json.load(fh)
-        if c.get("build_id") != build_id:
-            seen.append(f"{os.path.basename(path)}: build {c.get('build_id')}")
+        if not counters_match(c, ids, unit):
+            seen.append(f"{os.path.basename(path)}: " + (f"{c.get('unit', unit)} unit {c['unit_id']}" if c.get("unit_id") else f"build {c.get('build_id')}"))
             continue
         if "kernels" in c and c.get("valu_wave_instructions_per_launch"):
             # per-step totals over every kernel of the configuration's rollout (Bounce: bulk pass + compaction + tail pass)
@@ -279,19 +309,22 @@ def committed_counters(build_id, stem, kernel_substring=None):
                     return k, None
             continue
         return dict(c, file=os.path.basename(path)), None
-    return None, f"no counters for build {build_id} ({'; '.join(seen) or 'no file'}): not quoted"
+    return None, f"no counters for the {unit} unit {ids['units'].get(unit)} ({'; '.join(seen) or 'no file'}): not quoted"
 
 
-def busy_block(build_id, case):
-    """Hardware busy counters of the rollout kernel (profiles/r*_valu_busy.json, tools/busy_counters.sh), for the build
-    that is running: how full the vector issue pipe is by the chip's own counters, next to the instruction-rate fraction."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_busy.json")), reverse=True)
+def busy_block(ids, case, profiles_dir=None):
+    """Hardware busy counters of the rollout kernel (profiles/r*_valu_busy.json, tools/busy_counters.sh), for the kernel
+    unit that is running: how full the vector issue pipe is by the chip's own counters, next to the instruction-rate fraction."""
+    files = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "r[0-9][0-9]_valu_busy.json")), reverse=True)
     for path in files:
         with open(path) as fh:
             c = json.load(fh)
-        if c.get("build_id") != build_id or case not in c.get("cases", {}):
+        if case not in c.get("cases", {}):
             continue
         entry = c["cases"][case]
+        # (a case carries its own unit id since round 5; the file's build id stands for every case of an older file)
+        if not counters_match(dict(entry, build_id=c.get("build_id")), ids, BUSY_CASE_UNIT[case]):
+            continue
         k = next(iter(entry["kernels"].values()))
         d = k.get("derived") or {}
         return {
@@ -339,7 +372,8 @@ def valu_issue_block(counters, why_not, seconds_per_launch, build):
                               "basis": "the SIMD-32 peak with this kernel's measured cycles per instruction (tools/valu_mix.py: "
                               "instruction mix x tools/ubench.hip issue costs at 4 waves per SIMD) -- a builder model, not a guide "
                               "figure; a fraction above 1 says the model's per-instruction costs are pessimistic at this occupancy"}
-    out["basis"] = ("achieved = wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU on build " + build + ") / the time a "
+    out["basis"] = ("achieved = wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU, " + str(counters.get("file")) + ", taken on "
+                    + (f"the {counters.get('unit')} kernel unit {counters.get('unit_id')}" if counters.get("unit_id") else f"build {build}") + ") / the time a "
                     "launch takes in the pipelined loop (ms_per_step: launches overlap); peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 "
                     "cycles per wave64 instruction (MI355X_MICROARCH.md)")
     return out
@@ -421,7 +455,8 @@ def run_other_config(name: str, steps: int) -> int:
     orc.rollout(last_seed, max_plies=max_plies)
     parity = bool(np.array_equal(orc.reward, got))
     build = _abi.build_id()
-    counters, why_not = committed_counters(build, stem, kernel)
+    ids = running_ids()
+    counters, why_not = committed_counters(ids, stem, kernel)
     out = {
         "config": label,
         "value": value,
@@ -437,7 +472,8 @@ def run_other_config(name: str, steps: int) -> int:
         "parity_with_oracle": parity,
         "parity_sample": f"host rewards of the last timed step vs the CPU oracle, first {head} games, seed 0x{last_seed:016X}",
         "valu_issue": valu_issue_block(counters, why_not, ms * 1e-3, build),
-        "valu_busy": busy_block(build, {"connect_12x13x5": "k2c_8deep", "bounce_default": "k3p_8x"}[name]),
+        "valu_busy": busy_block(ids, {"connect_12x13x5": "k2c_8deep", "bounce_default": "k3p_8x"}[name]),
+        "unit_id": ids["units"][STEM_UNIT[stem]],
         "algorithmic": {"bytes_per_env_step": bytes_per_step, "GBps": value * bytes_per_step / 1e9,
                         "frac_of_hbm_peak": value * bytes_per_step / 1e9 / HBM_PEAK_GBS,
                         "note": "SURVEY 8d's per-ply byte model: a register/LDS-resident rollout does not move these bytes"},
@@ -877,14 +913,15 @@ def main() -> int:
         ms_per_step = elapsed / args.steps * 1e3
         steps_per_launch = steps_local / args.steps
         build = _abi.build_id()
-        counters, why_not = committed_counters(build, "rollout_counters") if n == BATCH_PER_GPU else (None, "counters are for batch 2^20")
+        ids = running_ids()
+        counters, why_not = committed_counters(ids, "rollout_counters") if n == BATCH_PER_GPU else (None, "counters are for batch 2^20")
         roof = valu_issue_block(counters, why_not, ms_per_step * 1e-3, build)
         named = re.search(r"k_[a-z0-9_]+", counters["kernel"]) if counters and counters.get("kernel") else None
         roof["kernel"] = named.group(0) if named else "k_connect_rollout_opened"
         roof["kernel_ms_per_launch"] = kernel_ms
         roof["event_pairs"] = len(range(0, args.steps, stride))
         roof["launches_in_flight"] = depth
-        busy = busy_block(build, "k2o_3deep") if n == BATCH_PER_GPU and depth == 3 else None
+        busy = busy_block(ids, "k2o_3deep") if n == BATCH_PER_GPU and depth == 3 else None
         if busy is not None:
             roof["valu_busy"] = busy
             roof["valu_busy_frac"] = busy["valu_busy_frac"]
@@ -941,6 +978,7 @@ def main() -> int:
                 "loop": "native (bgs_pipeline_enqueue: one library call per timed region)",
                 "waves_per_simd_per_launch": int(os.environ["BGS_ROLLOUT_WPS"]),
                 "build_id": build,
+                "kernel_unit_ids": ids["units"],
             },
             "roofline": roof,
         }

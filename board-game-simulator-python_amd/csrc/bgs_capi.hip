@@ -51,7 +51,7 @@ struct Layout {
 
 // planes > 0: bit-packed boards (planes x uint64 per board); planes == 0: the generic layout, int8[n][h][w] in the same
 // region.  legal_bytes: bytes per board of the legal-move record bgs_transition returns.
-Layout layout_for(int planes, int64_t n, int h, int w, size_t legal_bytes = 0) {
+Layout layout_for(int planes, int64_t n, int h, int w, size_t legal_bytes = 0, bool bounce_pool = false) {
     Layout l;
     size_t off = 0;
     size_t board_bytes = (size_t)planes * 8;  // the region must hold whichever form the batch turns out to use
@@ -63,8 +63,9 @@ Layout layout_for(int planes, int64_t n, int h, int w, size_t legal_bytes = 0) {
     l.steps = off; off += align_up(kStepBytes);
     l.worklist = off; off += align_up((size_t)n * 4);
     l.work_count = off; off += align_up(sizeof(uint32_t) * 2 * BGS_BOUNCE_MAX_PASSES);
-    // packed Bounce boards: the piece-list rollout's device-wide pool of parked boards (counters + entries, bgs_internal.h)
-    l.pool = off; off += planes == 4 ? align_up(sizeof(uint32_t) * BGS_BOUNCE_POOL_WORDS) : 0;
+    // packed Bounce boards only: the piece-list rollout's device-wide pool of parked boards (counters + entries,
+    // bounce_unit.h; 3 MB).  Two-word Connect boards (8x8, 9x10: four planes as well) do not pay for it (round-4 advisor).
+    l.pool = off; off += bounce_pool ? align_up(sizeof(uint32_t) * BGS_BOUNCE_POOL_WORDS) : 0;
     l.gen_masks = off; off += align_up(sizeof(uint64_t) * 6 * (BGS_GENERIC_BOUNCE_MAX_CELLS / 64));
     l.gen_cfg = off; off += align_up((size_t)h * w);
     size_t per_board = (size_t)h * w;
@@ -338,6 +339,8 @@ int device_facts(bgs_batch* b) {
         if (!plan) plan = "auto";
         const char* wave_pass = getenv("BGS_BOUNCE_WAVE_PASS");
         b->bounce_wave_pass = !(wave_pass && wave_pass[0] == '0');
+        const char* epoch_limit = getenv("BGS_BOUNCE_EPOCH_LIMIT");
+        b->bounce_epoch_limit = epoch_limit ? atoi(epoch_limit) : 0;
         b->bounce_passes = 0;
         b->bounce_plan_auto = strcmp(plan, "auto") == 0;
         if (!b->bounce_plan_auto && strcmp(plan, "single") != 0) {
@@ -637,7 +640,8 @@ int bgs_connect_arena_bytes(int height, int width, int count, int64_t n, size_t*
 // one arena layout per board SIZE, for the size query and for the carve alike (up to 64 cells: the packed form's four
 // planes, which also hold a small generic board)
 static auto bounce_layout(int64_t n, int height, int width) {
-    return layout_for(height * width > BGS_BOUNCE_MAX_CELLS ? 0 : 4, n, height, width, bgs::generic_bounce_legal_bytes(height, width));
+    return layout_for(height * width > BGS_BOUNCE_MAX_CELLS ? 0 : 4, n, height, width, bgs::generic_bounce_legal_bytes(height, width),
+                      height * width <= BGS_BOUNCE_MAX_CELLS);
 }
 
 int bgs_bounce_arena_bytes(int height, int width, int64_t n, size_t* bytes) {

@@ -11,6 +11,21 @@
 #define BGS_ST_RUNNING 0u
 #define BGS_ST_DRAW 3u
 
+// limits of the packed representations
+enum {
+    BGS_CONNECT_MAX_WORDS = 3,   // width * (height + 1) <= 192 bits per plane
+    BGS_CONNECT_MAX_H = 15,      // column heights are kept 4 bits per column
+    BGS_CONNECT_MAX_W = 16,
+    BGS_BOUNCE_MAX_CELLS = 64,   // height * width <= 64: one bit per cell in a uint64
+    BGS_BOUNCE_MAX_VALUE = 15,   // 4 value bit-planes
+    BGS_BOUNCE_MAX_PASSES = 8,   // passes of the multi-pass Bounce rollout
+    BGS_BOUNCE_MAX_PIECES = 16,  // piece-list rollout kernel (K3p): pieces on the configured start position
+    // the generic (reference-layout) kernels take over beyond the packed limits
+    BGS_GENERIC_CONNECT_MAX_DIM = 64,      // height, width <= 64 (the oracle's own limit: nothing larger can be checked)
+    BGS_GENERIC_BOUNCE_MAX_CELLS = 1024,   // height * width <= 1024, piece values <= 127 (int8)
+    BGS_GENERIC_BOUNCE_MAX_DIM = 64
+};
+
 namespace bgs {
 
 // ------------------------------------------------------------------------------------------------

@@ -10,78 +10,10 @@ struct bgs_gather;       // bgs_multi.hip
 
 enum { BGS_GAME_CONNECT = 1, BGS_GAME_BOUNCE = 2 };
 
-// limits of the packed representations
-enum {
-    BGS_CONNECT_MAX_WORDS = 3,   // width * (height + 1) <= 192 bits per plane
-    BGS_CONNECT_MAX_H = 15,      // column heights are kept 4 bits per column
-    BGS_CONNECT_MAX_W = 16,
-    BGS_BOUNCE_MAX_CELLS = 64,   // height * width <= 64: one bit per cell in a uint64
-    BGS_BOUNCE_MAX_VALUE = 15,   // 4 value bit-planes
-    BGS_BOUNCE_MAX_PASSES = 8,   // passes of the multi-pass Bounce rollout
-    BGS_BOUNCE_MAX_PIECES = 16,  // piece-list rollout kernel (K3p): pieces on the configured start position
-    BGS_BOUNCE_POOL_GROUPS = 2048,  // K3p: workgroups of a launch that can park boards in the device-wide pool
-    BGS_BOUNCE_POOL_WORDS = 4 + 2 * 2048 + 2048 * 64 * 6,  // dwords: counters, per-group count / head, 64 entries of 6 dwords a group
-    // the generic (reference-layout) kernels take over beyond the packed limits
-    BGS_GENERIC_CONNECT_MAX_DIM = 64,      // height, width <= 64 (the oracle's own limit: nothing larger can be checked)
-    BGS_GENERIC_BOUNCE_MAX_CELLS = 1024,   // height * width <= 1024, piece values <= 127 (int8)
-    BGS_GENERIC_BOUNCE_MAX_DIM = 64
-};
-
-struct ConnectGeom {
-    int h, w, k, nw;   // nw = 64-bit words per plane
-};
-
-struct BounceGeom {
-    int h, w;
-    uint32_t inv_w;          // ceil(2^16 / w): y = (cell * inv_w) >> 16 for cell < 64
-    uint64_t all;            // every cell
-    uint64_t interior;       // rows 1 .. h-2
-    uint64_t goal_top;       // row h-1 (player 0's goal)
-    uint64_t goal_bottom;    // row 0   (player 1's goal)
-    uint64_t not_col0;       // cells with x > 0
-    uint64_t not_collast;    // cells with x < w-1
-    uint64_t init[4];        // value bit-planes of the configured start position
-    uint32_t init_status;    // 0, or the terminal code of a start position without legal moves
-    // The start position as a piece list (Bounce never captures and never changes a piece's value, so a board IS the
-    // cells of its pieces): piece k has value piece_value[k] and starts on cell piece_cell[k]; pieces are numbered by
-    // ascending (value, cell).  piece_count = 0: more than BGS_BOUNCE_MAX_PIECES pieces (the piece-list rollout is off).
-    uint32_t piece_count;
-    uint8_t piece_value[16];
-    uint8_t piece_cell[16];
-    uint64_t piece_idx[4];   // index planes of the start position: bit c of plane p = bit p of the index of the piece on cell c
-};
-
-// Launch tuning of the fused rollouts.  These live here (a header the build id hashes) and not in bgs_capi.hip because
-// they change what a launch executes: counters taken under one setting must not be quoted for another.
-constexpr int kRolloutOpeningBlocks = 3;    // K2o: 4-ply blocks played in lock step before a board joins the refill loop
-constexpr int kGamesPerLaneOneWord = 8;     // one-word Connect boards: games per lane a launch aims for (512 per wave at 2^20)
-constexpr int kGamesPerLane = 4;            // every other rollout
-constexpr int kBouncePiecesPark = 40;       // K3p with the device-wide pool: 32 / 40 / 48 / 56 / 63 read 11.8 / 12.2 / 11.9 / 11.8 / 3.0 x 10^9 with 20 in flight
-constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBoards (0 = every wave drains alone)
-// K3p, automatic plan: the shape of a launch follows the number of launches the caller keeps in flight on the device
-// (bgs_set_launches_in_flight; the rollout executor passes its depth).  tail_cap: games longer than this are finished
-// by the tail pass; boards_per_wave: boards a wave of the bulk pass plays.  Alone on the chip a launch is bound by its
-// longest chain of dependent plies (17 us a ply on the piece-list kernel, 0.65 us on the 8-lanes-per-board kernel of
-// the tail) and by how many SIMDs it reaches, so: short bulk, many waves.  With 16 launches sharing the chip what counts
-// is instructions per ply, so: few long-lived waves that stay full, and a bulk pass long enough to keep the tail small.
-// 2^18 boards, 10^9 env-steps/s (round 3, r3_bounce_solo.sh in the git history, r3_bounce_depth.sh, r3_bounce_depth2.sh):
-//   in flight        1      4      8      16
-//   {384, 512}     1.11   2.16   6.05   9.7      (round 3's only shape until then)
-//   {64, 128}      1.92   3.10   6.53   7.7
-//   {128, 256}     1.63   2.92   6.85   8.8
-//   {160, 512}     1.12    --     --   10.2
-// Round 4, with the one-board-per-wave tail pass (K3w, with its memo and links) behind the bulk pass
-// (tools/k3w_depth_probe.sh, GPU_MAX_HW_QUEUES=24):
-//   in flight        2      4      6      8      12     16     20
-//   {64, 128}      4.77   7.54   8.02   8.21   8.36   8.43   8.50
-//   {128, 256}     4.88   8.88  12.24  13.98  14.11  14.29  14.44
-//   {160, 512}     3.65   6.89   9.55  12.17  15.72  15.79  15.86
-struct BounceShape { int tail_cap; int boards_per_wave; };
-inline BounceShape bounce_shape(int launches_in_flight) {
-    if (launches_in_flight >= 12) return {160, 512};
-    if (launches_in_flight >= 4) return {128, 256};
-    return {80, 128};   // (one launch at a time, K3w on 8192 waves: caps of 64 / 80 / 96 / 112 / 128 read 2.78 / 2.86 / 2.80 / 2.69 / 2.62 x 10^9)
-}
+// (the limits of the packed representations live in bgs_common.h, the geometry records and the launch tuning of a game in
+// connect_unit.h / bounce_unit.h -- the headers the kernel units' ids hash; this one is host-side plumbing and is not hashed)
+#include "connect_unit.h"
+#include "bounce_unit.h"
 
 struct bgs_batch {
     int game;
@@ -109,6 +41,7 @@ struct bgs_batch {
     int bounce_park;         // flat rollout: a draining wave parks its boards for its workgroup at this many or fewer (0..32; BGS_BOUNCE_PARK)
     int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (BGS_BOUNCE_CHUNK)
     int launches_in_flight;  // the caller's hint (bgs_set_launches_in_flight), 1 = one launch at a time: see bounce_shape()
+    int bounce_epoch_limit;  // K3w: the memo starts over after this many replacements (0 = the 16 bits a link has; BGS_BOUNCE_EPOCH_LIMIT: the tests' way to reach the restart)
     int bounce_wave_pass;    // 1: the automatic plan ends with the one-board-per-wave pass (K3w); BGS_BOUNCE_WAVE_PASS=0 switches it off
     int bounce_plan_auto;    // 1: the library chooses between one launch and bulk + tail passes (BGS_BOUNCE_PLAN unset or "auto")
     int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board

@@ -1694,6 +1694,9 @@ k_bounce_compact(const uint8_t* __restrict__ status, const uint16_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kWaveMemoBits = 5, kWaveMemoSlots = 1u << kWaveMemoBits;
 constexpr uint32_t kWaveLinks = 32;   // actions per remembered position whose successor is remembered too (K3w, see the ply loop)
+// a link word is epoch << 16 | actions of the successor << 8 | the successor's slot, and lanes 0 .. kWaveLinks - 1 clear a row
+static_assert(kWaveMemoSlots <= 256 && kWaveLinks <= 64, "a link holds the slot in 8 bits; one wave clears a slot's row of links");
+constexpr uint32_t kWaveEpochLimit = 0xFFFFu;   // 16 bits of epoch in a link: at the limit the memo starts over empty
 
 struct WaveMoves {
     uint64_t targets;    // this lane's piece, if it is a source: its legal landing cells
@@ -1787,11 +1790,11 @@ __global__ void __launch_bounds__(BGS_WAVE)
 k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                       uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
                       unsigned long long* __restrict__ steps, const uint32_t* __restrict__ worklist,
-                      const uint32_t* __restrict__ work_count) {
+                      const uint32_t* __restrict__ work_count, uint32_t epoch_limit) {
     static_assert(PMAX <= 16, "the prefix sum runs over one 16-lane row");
     __builtin_amdgcn_s_setprio(3);   // (see k_bounce_rollout: these waves are the launch's critical path)
     const uint32_t lane = threadIdx.x & 63u;
-    // the wave's memo of action lists (see the ply loop): 64 positions, 14 KB
+    // the wave's memo of action lists (see the ply loop): kWaveMemoSlots = 32 positions in 16 sets of 2 ways, ~11 KB with the links (PMAX = 16)
     __shared__ uint64_t memo_key[kWaveMemoSlots][4];
     __shared__ uint64_t memo_targets[kWaveMemoSlots][PMAX];
     __shared__ uint32_t memo_lane[kWaveMemoSlots][PMAX];
@@ -1896,7 +1899,7 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
                 enumerate_wave<PMAX>(g, b, side, mv);
                 // the victim way: if it held a position, every link written so far may point at it -- a new epoch
                 const uint32_t victim_tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)(way ? tag1 : tag0));
-                if (victim_tag != 0xFFFFFFFFu && ++epoch == 0xFFFFu) {   // (16 bits in a link: start over with an empty memo)
+                if (victim_tag != 0xFFFFFFFFu && ++epoch >= epoch_limit) {   // (16 bits in a link: start over with an empty memo)
                     for (uint32_t e = lane; e < kWaveMemoSlots; e += BGS_WAVE) memo_tag[e] = 0xFFFFFFFFu;
                     epoch = 1;
                     __syncthreads();
@@ -2141,7 +2144,8 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
             const unsigned wave_grid = grid_env > 0 ? (unsigned)grid_env : 8192u;
             hipLaunchKernelGGL((k_bounce_rollout_wave<PMAX>), dim3(wave_grid), dim3(BGS_WAVE), 0,
                                b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
-                               seed, b->first_game, cap, b->d_steps, worklist, work_count);
+                               seed, b->first_game, cap, b->d_steps, worklist, work_count,
+                               b->bounce_epoch_limit >= 2 && b->bounce_epoch_limit < (int)kWaveEpochLimit ? (uint32_t)b->bounce_epoch_limit : kWaveEpochLimit);
         };
         // (from_initial here: every board of the rollout descends from the configured start position, so none holds more
         // pieces than it; otherwise 16 lanes, and a board with more than that is played by lane 0)

@@ -298,6 +298,16 @@ def build_id() -> str:
     return lib().bgs_build_id().decode("ascii")
 
 
+UNITS = ("connect", "bounce", "generic")
+
+
+def unit_ids() -> dict:
+    """{"connect": id, "bounce": id, "generic": id}: the id each kernel unit was compiled with (its source, bgs_common.h,
+    its own unit header and the compile flags).  Counter files under profiles/ name the unit id of the kernel they
+    describe; an edit to one unit leaves the others' counters quotable."""
+    return {name: (lib().bgs_kernel_unit_id(k) or b"unknown").decode("ascii") for k, name in enumerate(UNITS)}
+
+
 def device_count() -> int:
     n = ctypes.c_int(0)
     check(lib().bgs_device_count(ctypes.byref(n)))

@@ -124,10 +124,16 @@ static int connect_apply_one(int h, int w, int k, int8_t* g, int8_t* player, int
  * (tests/test_connect.py:75-83, :131-138). */
 int orc_connect_reset(int h, int w, int64_t n, int8_t* grid, int8_t* player, int8_t* winner, int32_t* plies) {
     if (!connect_cfg_ok(h, w, 1) || n < 0) return ORC_ERR_ARG;
-    memset(grid, 0xFF, (size_t)n * h * w);
-    memset(player, 0, (size_t)n);
-    memset(winner, 0xFF, (size_t)n);
-    memset(plies, 0, (size_t)n * sizeof(int32_t));
+    /* board by board, with the thread team and the static schedule of the rollout below: the first reset of a batch is what
+     * touches its pages first, so every thread's share of the boards sits in memory next to the core that will play it
+     * (one memset from one thread put all 2^20 boards of bench.py's baseline on one NUMA node of the host) */
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        memset(grid + i * h * w, 0xFF, (size_t)h * w);
+        player[i] = 0;
+        winner[i] = -1;
+        plies[i] = 0;
+    }
     return ORC_OK;
 }
 
@@ -357,7 +363,8 @@ int orc_bounce_reset(int h, int w, const int8_t* cfg, int64_t n, int8_t* grid, i
     int8_t w0 = -1;
     if (orc_bounce_actions(h, w, cfg, 0, -1, 0, NULL, NULL) == 0)
         w0 = (int8_t)(orc_bounce_actions(h, w, cfg, 1, -1, 0, NULL, NULL) > 0 ? 1 : 2);
-    for (int64_t i = 0; i < n; ++i) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {   /* (first touch by the thread that will play the board: see orc_connect_reset) */
         memcpy(grid + i * h * w, cfg, (size_t)h * w);
         player[i] = 0;
         winner[i] = w0;

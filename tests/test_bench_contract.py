@@ -75,6 +75,47 @@ def test_counters_file_names_its_build():
     assert 2.0 < c["mix_cycles_per_instruction"] < 6.0
 
 
+def test_counters_are_gated_per_kernel_unit(tmp_path):
+    """Round-4 review, weak #8: counters are quoted when the id of the KERNEL UNIT they were taken on matches the running
+    library's (bgs_kernel_unit_id), not the global build id -- a Bounce-only edit leaves the Connect counters quotable
+    and the other way round; files from before round 5 (no unit id) are still matched on the global build id."""
+    sys.path[:0] = [ROOT]
+    import bench
+
+    def write(name, **fields):
+        with open(tmp_path / name, "w") as fh:
+            json.dump(fields, fh)
+
+    write("r05_rollout_counters.json", build_id="b" * 16, unit="connect", unit_id="c" * 16, valu_wave_instructions_per_launch=2.0e7,
+          hbm_bytes_per_launch=2.0e7)
+    write("r05_bounce.json", build_id="b" * 16, unit="bounce", unit_id="d" * 16, valu_wave_instructions_per_launch=3.0e8,
+          kernels={"k_bounce_rollout_pieces<16, 256>(...)": {"SQ_INSTS_VALU": 2.9e8}})
+    write("r04_k2c.json", build_id="a" * 16, kernels={"void k_connect_rollout_lds<...>": {"SQ_INSTS_VALU": 2.8e7}})
+    write("r05_valu_busy.json", build_id="b" * 16, cases={
+        "k2o_3deep": {"what": "x", "unit": "connect", "unit_id": "c" * 16, "kernels": {"k": {"derived": {"valu_busy_frac": 0.9}}}},
+        "k3p_8x": {"what": "y", "unit": "bounce", "unit_id": "d" * 16, "kernels": {"k": {"derived": {"valu_busy_frac": 0.6}}}}})
+    ids = {"build": "z" * 16, "units": {"connect": "c" * 16, "bounce": "d" * 16, "generic": "e" * 16}}
+    got, why = bench.committed_counters(ids, "rollout_counters", profiles_dir=str(tmp_path))
+    assert why is None and got["valu_wave_instructions_per_launch"] == 2.0e7 and got["file"] == "r05_rollout_counters.json"
+    assert bench.committed_counters(ids, "bounce", "k_bounce_rollout", profiles_dir=str(tmp_path))[0]["unit_id"] == "d" * 16
+    assert bench.busy_block(ids, "k2o_3deep", profiles_dir=str(tmp_path))["valu_busy_frac"] == 0.9
+    # a Bounce-only edit: the Bounce unit's id (and the global build id) move, the Connect unit's does not
+    edited = {"build": "y" * 16, "units": dict(ids["units"], bounce="f" * 16)}
+    assert bench.committed_counters(edited, "rollout_counters", profiles_dir=str(tmp_path))[0] is not None
+    assert bench.busy_block(edited, "k2o_3deep", profiles_dir=str(tmp_path)) is not None
+    got, why = bench.committed_counters(edited, "bounce", "k_bounce_rollout", profiles_dir=str(tmp_path))
+    assert got is None and "bounce unit" in why and "not quoted" in why
+    assert bench.busy_block(edited, "k3p_8x", profiles_dir=str(tmp_path)) is None
+    # ... and a Connect edit the other way round
+    edited = {"build": "x" * 16, "units": dict(ids["units"], connect="0" * 16)}
+    assert bench.committed_counters(edited, "rollout_counters", profiles_dir=str(tmp_path))[0] is None
+    assert bench.committed_counters(edited, "bounce", "k_bounce_rollout", profiles_dir=str(tmp_path))[0] is not None
+    # a file from before round 5 names the global build only
+    assert bench.committed_counters(ids, "k2c", "_lds", profiles_dir=str(tmp_path))[0] is None
+    old = dict(ids, build="a" * 16)
+    assert bench.committed_counters(old, "k2c", "_lds", profiles_dir=str(tmp_path))[0]["valu_wave_instructions_per_launch"] == 2.8e7
+
+
 def test_sharded_loops_with_one_rank_over_rccl_are_within_reach_of_the_plain_loop():
     """The N > 1 code paths over the real RCCL with a one-rank world (all a one-GPU box can run): the shared host array
     costs nothing; the in-library RCCL gather -- a communicator, a communication thread and a second stream between the

@@ -71,6 +71,21 @@ def test_a_changed_flag_rebuilds_every_object_and_changes_the_id(tmp_path):
     assert third not in (first, second) and third == _print_id(csrc)
     assert third_units[0] == first_units[0] and third_units[2] == first_units[2] and third_units[1] != first_units[1]
 
+    # ... and so does an edit to that unit's own header (its geometry record and launch tuning), while the host-side
+    # plumbing header every unit includes (bgs_internal.h: the batch object, prototypes) moves no id at all: counters
+    # under profiles/ are gated per unit (bench.py), a Bounce-only round must not invalidate the Connect counters
+    with open(os.path.join(csrc, "bounce_unit.h"), "a") as fh:
+        fh.write("\n// build identity test\n")
+    with open(os.path.join(csrc, "bgs_internal.h"), "a") as fh:
+        fh.write("\n// build identity test\n")
+    _make(csrc)
+    fourth, fourth_units = _ids(lib)
+    assert fourth_units[0] == first_units[0] and fourth_units[2] == first_units[2]
+    assert fourth_units[1] not in (first_units[1], third_units[1])
+    units = dict(line.split() for line in subprocess.check_output(
+        ["make", "-s", "--no-print-directory", "-C", csrc, "print-unit-ids"], text=True).splitlines())
+    assert [units["connect"], units["bounce"], units["generic"]] == fourth_units
+
 
 def test_the_library_in_the_tree_is_the_one_its_sources_give():
     """What __graft_entry__.build() enforces: the loaded library's id equals `make print-id` of the tree."""

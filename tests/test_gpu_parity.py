@@ -783,6 +783,27 @@ def test_bounce_games_that_never_end(batch_mod, seed_offset, first_game):
     dev.close()
 
 
+@pytest.mark.parametrize("limit", ["2", "3", "7"])
+def test_bounce_memo_starts_over_when_its_epochs_run_out(batch_mod, monkeypatch, limit):
+    """Round-4 advisor: a link of K3w's memo holds its epoch in 16 bits, and when the count of replacements reaches the
+    limit the memo starts over empty -- stale rows of links are left behind and must not be followed.  2^16 replacements
+    do not happen in a test, so BGS_BOUNCE_EPOCH_LIMIT brings the restart within reach: a few waves, each playing a dozen
+    boards -- among them a game that never ends -- replace remembered positions all the time."""
+    monkeypatch.setenv("BGS_BOUNCE_EPOCH_LIMIT", limit)
+    monkeypatch.setenv("BGS_BOUNCE_WAVE_GRID", "4")
+    n = 48
+    for seed_offset, first_game, cap in ((0, 196997, 4096), (5, 2278, 1500)):
+        dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+        orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+        dev.set_first_game(first_game - 17)
+        dev.rollout(SEED + seed_offset, max_plies=cap, from_initial=True)
+        total = orc.rollout(SEED + seed_offset, first_game=first_game - 17, max_plies=cap)
+        assert int(orc.plies[17]) == cap
+        assert_same(dev, orc, f"epoch limit {limit}, game {first_game}, cap {cap}")
+        assert dev.steps == total
+        dev.close()
+
+
 def test_bounce_loaded_boards_of_any_crowd_finish_on_one_board_per_wave(batch_mod):
     """A batch CONFIGURED with 12 pieces, LOADED with other people's boards -- 12, 16 and 22 pieces on the same 9x6 cells --
     and rolled out from memory: the tail pass (K3w, 16 lanes here) plays what fits its lanes a piece per lane and hands a

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/busy_* (tools/busy_counters.sh) -> profiles/r04_valu_busy.json: per case and kernel the mean counter values
+"""gpurun_out/busy_* (tools/busy_counters.sh) -> profiles/<round>_valu_busy.json (BGS_PROFILE_ROUND, default r05): per case and kernel the mean counter values
 per dispatch and what they say about the vector issue pipe.
 
 Units (rocprofv3 -L on gfx950): SQ_ACTIVE_INST_VALU, SQ_ACTIVE_INST_ANY, SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_BUSY_CU_CYCLES are
@@ -67,6 +67,19 @@ def main():
         "k3p_solo": ("k_bounce_rollout_pieces", "Bounce default, one launch of 2^18 boards in the shape of 20 in flight"),
         "k3p_8x": ("k_bounce_rollout_pieces", "Bounce default, 8 x 2^18 boards in one launch"),
     }
+    units = _abi.unit_ids()
+    case_unit = {"k2o_solo": "connect", "k2o_3deep": "connect", "k2c_solo": "connect", "k2c_8deep": "connect", "k3p_solo": "bounce", "k3p_8x": "bounce"}
+    rnd = os.environ.get("BGS_PROFILE_ROUND", "r05")
+    path = os.path.join(ROOT, "profiles", f"{rnd}_valu_busy.json")
+    # cases that were not re-taken in this pass (their unit did not move: busy_counters.sh skipped them) are carried over
+    # from the newest file that holds them for the running unit id
+    carried = {}
+    for old in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_busy.json")), reverse=True):
+        with open(old) as fh:
+            prev = json.load(fh)
+        for tag, entry in prev.get("cases", {}).items():
+            if tag not in carried and entry.get("unit_id") and entry["unit_id"] == units.get(entry.get("unit")):
+                carried[tag] = entry
     out = {"build_id": _abi.build_id(),
            "method": "tools/busy_counters.sh: rocprofv3 --kernel-trace --pmc (one pass, 8 SQ + 2 GRBM counters), per-dispatch means; "
                      "dispatches are serialised by the counter collection, so pipelined cases are counted as one launch of N x the boards "
@@ -75,8 +88,9 @@ def main():
     for tag, (want, what) in cases.items():
         c = case(tag, want)
         if c:
-            out["cases"][tag] = {"what": what, "kernels": c}
-    path = os.path.join(ROOT, "profiles", "r04_valu_busy.json")
+            out["cases"][tag] = {"what": what, "unit": case_unit[tag], "unit_id": units[case_unit[tag]], "kernels": c}
+        elif tag in carried:
+            out["cases"][tag] = carried[tag]
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
     for tag, c in out["cases"].items():

@@ -5,13 +5,14 @@
 # rocprofv3 collects counters per dispatch and serialises the dispatches, so "N launches in flight" cannot be counted
 # as such: each pipelined case is counted as ONE launch of N times the boards with N times the waves per SIMD (the same
 # games per wave, the same waves resident per SIMD as N launches sharing the chip).
-# usage (GPU box): bash tools/busy_counters.sh ; then python3 tools/busy_counters.py -> profiles/r04_valu_busy.json
+# usage (GPU box): bash tools/busy_counters.sh ; then python3 tools/busy_counters.py -> profiles/r05_valu_busy.json
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 PMC="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE GRBM_COUNT"
-pass() {  # pass <tag> <program> <args...>   (environment of the caller)
+pass() {  # pass <tag> <program> <args...>   (environment of the caller); skipped when the case's kernel unit did not move
   local tag=$1; shift
+  if ! ( cd $R && python3 tools/needs_profile.py case $tag ); then rm -rf $R/gpurun_out/busy_$tag; return; fi
   rm -rf $R/gpurun_out/busy_$tag
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $R/gpurun_out/busy_$tag -- "$@" > $R/gpurun_out/busy_$tag.log 2>&1 || echo "pass failed: $tag"
   echo "counted $tag"

@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_* (tools/profile_all.sh) -> profiles/<round>_*.json (round: BGS_PROFILE_ROUND, default r04), including
-profiles/<round>_rollout_counters.json, the per-launch PMC figures of the bench kernel that bench.py quotes when its build
-id matches the running library."""
+"""gpurun_out/prof_* (tools/profile_all.sh) -> profiles/<round>_*.json (round: BGS_PROFILE_ROUND, default r05), including
+profiles/<round>_rollout_counters.json, the per-launch PMC figures of the bench kernel that bench.py quotes when the id of
+the kernel UNIT they were taken on (connect / bounce / generic: bgs_kernel_unit_id) matches the running library's.  Only the
+tags whose passes exist under gpurun_out/ are (re)written: profile_all.sh skips the units that did not move."""
 import json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
 OUT = os.path.join(ROOT, "profiles")
-ROUND = os.environ.get("BGS_PROFILE_ROUND", "r04")
+ROUND = os.environ.get("BGS_PROFILE_ROUND", "r05")
+TAG_UNIT = {"bench": "connect", "k1": "connect", "k2c": "connect", "k2b": "connect", "bounce": "bounce", "bounce_solo": "bounce",
+            "bounce_k3f": "bounce", "bounce8": "bounce"}
 
 
 def summary(tag, want=""):
@@ -24,6 +27,7 @@ def main():
     from simulator.game import _abi
 
     build = _abi.build_id()
+    units = _abi.unit_ids()
     method = ("tools/profile_all.sh: rocprofv3 --kernel-trace --stats, then --pmc in separate passes (SQ_*; FETCH_SIZE; "
               "WRITE_SIZE), per-dispatch means; FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads), KiB -> B")
     for tag, want, name in (("bench", "k_connect_rollout_opened", f"{ROUND}_bench_kernel.json"), ("k1", "step_random", f"{ROUND}_k1.json"),
@@ -76,15 +80,26 @@ def main():
             except Exception as exc:
                 print(f"no benchfull pass: {exc}", file=sys.stderr)
         with open(os.path.join(OUT, name), "w") as fh:
-            json.dump(dict({"build_id": build, "method": method}, **total, **extra, kernels=s), fh, indent=1)
-    misc = summary("misc")
-    with open(os.path.join(OUT, f"{ROUND}_misc_kernel_stats.json"), "w") as fh:
-        json.dump({"build_id": build, "command": "rocprofv3 --kernel-trace --stats -- python3 tools/measure_all.py", "kernels": misc}, fh, indent=1)
+            json.dump(dict({"build_id": build, "unit": TAG_UNIT[tag], "unit_id": units[TAG_UNIT[tag]], "method": method}, **total, **extra, kernels=s), fh, indent=1)
+    try:
+        misc = summary("misc")
+    except Exception as exc:
+        misc = None
+        print(f"skipping misc: {exc}", file=sys.stderr)
+    if misc:
+        with open(os.path.join(OUT, f"{ROUND}_misc_kernel_stats.json"), "w") as fh:
+            json.dump({"build_id": build, "unit_ids": units, "command": "rocprofv3 --kernel-trace --stats -- python3 tools/measure_all.py", "kernels": misc}, fh, indent=1)
     mfile = os.path.join(ROOT, "gpurun_out", "measure_all.json")
     if os.path.exists(mfile) and os.path.getsize(mfile):
         with open(mfile) as fh, open(os.path.join(OUT, f"{ROUND}_secondary_measurements.json"), "w") as out:
             out.write(fh.read())
-    bench = summary("bench", "k_connect_rollout_opened")
+    try:
+        bench = summary("bench", "k_connect_rollout_opened")
+    except Exception as exc:
+        print(f"no bench pass in gpurun_out/ ({exc}): {ROUND}_rollout_counters.json left as it is", file=sys.stderr)
+        return
+    if not bench:
+        return
     k = next(iter(bench.values()))
     with open(os.path.join(ROOT, "gpurun_out", "valu_mix.json")) as fh:
         mix = json.load(fh)
@@ -97,6 +112,8 @@ def main():
     mix["weights"] = {"opening_block_instructions_per_launch": n_open, "loop_and_other_instructions_per_launch": n_loop}
     counters = {
         "build_id": build,
+        "unit": "connect",
+        "unit_id": units["connect"],
         "kernel": next(iter(bench)),
         "dispatches": k.get("dispatches"),
         "mean_us": k.get("mean_us"),
@@ -113,7 +130,7 @@ def main():
     }
     with open(os.path.join(OUT, f"{ROUND}_rollout_counters.json"), "w") as fh:
         json.dump(counters, fh, indent=1)
-    print(json.dumps({kk: counters[kk] for kk in ("build_id", "valu_wave_instructions_per_launch", "hbm_bytes_per_launch",
+    print(json.dumps({kk: counters[kk] for kk in ("build_id", "unit_id", "valu_wave_instructions_per_launch", "hbm_bytes_per_launch",
                                                   "active_lanes_per_valu_instruction", "mean_us")}))
 
 

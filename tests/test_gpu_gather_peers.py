@@ -34,7 +34,7 @@ def run_ranks(tmp_path, world, mode, extra_env=None, timeout=240, per_process=1)
     env = dict(os.environ, BGS_RCCL_LIB=build_fake_rccl())
     env.update(extra_env or {})
     groups = [",".join(str(r) for r in range(first, min(world, first + per_process))) for first in range(0, world, per_process)]
-    assert len(groups) <= 6
+    assert len(groups) <= 5   # (the box allows 6 processes on the card, and the test process is one of them)
     procs = [subprocess.Popen(["timeout", "-k", "10", str(timeout), sys.executable, PEER, str(tmp_path), g, str(world), mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for g in groups]
     outs = [p.communicate() for p in procs]

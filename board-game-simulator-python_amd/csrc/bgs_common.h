@@ -29,9 +29,17 @@ enum {
 namespace bgs {
 
 // ------------------------------------------------------------------------------------------------
-// RNG contract: philox4x32-10, key = seed, counter = (game lo, game hi, ply >> 2, 0); the draw of a ply is
-// output word (ply & 3).  One block serves four consecutive plies of a game.
+// RNG contract (include/bgs.h): philox4x32-10, key = seed.
+//   Bounce : counter = (game lo, game hi, ply >> 2, 0); the draw of a ply is output word (ply & 3): a word per ply.
+//   Connect: counter = (game lo, game hi, ply >> 4, 0); the WORD of the four-ply block ply >> 2 is output word
+//            (ply >> 2) & 3, and the draw of ply j = ply & 3 of the block is word * kSubDraw[j] mod 2^32, kSubDraw[j] =
+//            A^j, A = 747796405 -- four consecutive states of the multiplicative congruential generator x -> A x.  One
+//            philox call serves SIXTEEN plies of a game, so a Connect4 game (<= 42 plies) needs three, all of which the
+//            bench kernel computes in its lock-step opening: its ply loop holds no philox at all.
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t kSubDrawA = 747796405u;
+constexpr uint32_t kSubDraw1 = kSubDrawA, kSubDraw2 = kSubDrawA * kSubDrawA, kSubDraw3 = kSubDrawA * kSubDrawA * kSubDrawA;
+static_assert(kSubDraw2 == 4201498105u && kSubDraw3 == 3399858189u, "A^2, A^3 mod 2^32");
 struct Philox4 {
     uint32_t v[4];
 };
@@ -75,6 +83,20 @@ __device__ __forceinline__ uint32_t philox_word(const Philox4& p, uint32_t ply) 
     const uint32_t hi = (j & 1u) ? p.v[3] : p.v[2];
     return (j & 2u) ? hi : lo;
 }
+
+// Connect: the draw of sub-step j (0..3) of a block from the block's word -- j is a compile-time constant in the rollout
+// kernels (one v_mul_lo_u32 with a literal), a run-time value in the per-ply kernels
+template <uint32_t J>
+__host__ __device__ __forceinline__ uint32_t sub_draw(uint32_t word) {
+    static_assert(J < 4u, "four plies a block");
+    return J == 0u ? word : word * (J == 1u ? kSubDraw1 : J == 2u ? kSubDraw2 : kSubDraw3);
+}
+__host__ __device__ __forceinline__ uint32_t sub_draw(uint32_t word, uint32_t j) {
+    const uint32_t m = (j & 1u) ? kSubDraw1 : 1u;
+    return word * ((j & 2u) ? m * kSubDraw2 : m);
+}
+// Connect: the word of ply's block out of the philox call that covers it (philox4x32_10(seed, game, ply >> 4))
+__device__ __forceinline__ uint32_t connect_word(const Philox4& p, uint32_t ply) { return philox_word(p, ply >> 2); }
 
 __host__ __device__ __forceinline__ uint32_t sample_index(uint32_t draw, uint32_t n_actions) {
     return (uint32_t)(((uint64_t)draw * n_actions) >> 32);

@@ -524,12 +524,12 @@ k_connect_rollout(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ stat
             taken = avail - taken < wanted ? avail : taken + wanted;
         }
         if (__builtin_amdgcn_ballot_w64(live)) {
-            Philox4 blk;
-            if (live) blk = philox4x32_10(seed, first_game + (uint64_t)game, gm.plies() >> 2);
+            uint32_t word = 0;   // the block's word: one philox call serves the sixteen plies of four blocks
+            if (live) word = connect_word(philox4x32_10(seed, first_game + (uint64_t)game, gm.plies() >> 4), gm.plies());
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 if (live && (FROM_INITIAL || (gm.plies() & 3u) == j)) {
-                    const bool running = gm.ply(g, blk.v[j]);
+                    const bool running = gm.ply(g, sub_draw(word, j));
                     live = running && (!CAPPED || gm.plies() < max_plies);
                     if (!live) {
                         finished = true;
@@ -571,8 +571,8 @@ k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
             Game gm;
             gm.load(g, p0, p1);
             const uint32_t ply = gm.plies();
-            const Philox4 blk = philox4x32_10(seed, first_game + (uint64_t)i, ply >> 2);
-            const bool running = gm.ply(g, philox_word(blk, ply));
+            const Philox4 blk = philox4x32_10(seed, first_game + (uint64_t)i, ply >> 4);
+            const bool running = gm.ply(g, sub_draw(connect_word(blk, ply), ply & 3u));
             gm.planes(p0, p1);
             const uint32_t mover = ply & 1u;  // only the mover's plane changed
 #pragma unroll
@@ -614,14 +614,14 @@ template <bool SINGLE, class G>
 __device__ __forceinline__ uint32_t play_plies(const G& g, uint64_t bottoms, uint64_t cells, uint64_t& p0, uint64_t& p1,
                                                uint32_t& st, uint64_t seed, uint64_t game, uint32_t count) {
     if (st != BGS_ST_RUNNING) return 0u;
-    if (SINGLE) count = 1u;  // (straight-line code: no loop, no second philox block)
+    if (SINGLE) count = 1u;  // (straight-line code: no loop, no second philox call)
     uint32_t ply = (uint32_t)__popcll(p0) + (uint32_t)__popcll(p1);
     const uint32_t full = (uint32_t)(g.h() * g.w());
-    Philox4 blk = philox4x32_10(seed, game, ply >> 2);
+    Philox4 blk = philox4x32_10(seed, game, ply >> 4);
     uint32_t played = 0;
     for (uint32_t q = 0; q < count; ++q) {
         const uint64_t landing = ((p0 | p1) + bottoms) & cells;
-        const uint32_t idx = sample_index(philox_word(blk, ply), (uint32_t)__popcll(landing));
+        const uint32_t idx = sample_index(sub_draw(connect_word(blk, ply), ply & 3u), (uint32_t)__popcll(landing));
         const uint32_t pos = select_bit64(landing, idx);
         const bool second = ply & 1u;
         uint64_t mine = (second ? p1 : p0) | (1ull << pos);
@@ -639,7 +639,7 @@ __device__ __forceinline__ uint32_t play_plies(const G& g, uint64_t bottoms, uin
         ++played;
         if (won) { st = (second ? 2u : 1u); break; }
         if (ply == full) { st = BGS_ST_DRAW; break; }
-        if ((ply & 3u) == 0u && q + 1u < count) blk = philox4x32_10(seed, game, ply >> 2);
+        if ((ply & 15u) == 0u && q + 1u < count) blk = philox4x32_10(seed, game, ply >> 4);
     }
     return played;
 }
@@ -969,14 +969,15 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
             taken = avail - taken < wanted ? avail : taken + wanted;
         }
 
-        // ---- one philox block, four plies, no control flow
+        // ---- the block's word (one philox call covers four blocks; lanes sit in different blocks, so it is made every
+        // time), four plies, no control flow
         const uint32_t was_live = live;
-        const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk);
+        const uint32_t word = philox_word(philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk >> 2), blk);
         uint32_t open = (hts >> 3) & ONES;
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t cnt = (uint32_t)__popc(open);
-            const uint32_t idx = sample_index(draws.v[j], cnt);
+            const uint32_t idx = sample_index(sub_draw(word, j), cnt);
             // nibble x of cmp = 8 + idx - (open columns among 0..x): (idx - open) * ONES is idx * ONES - open * ONES
             uint64_t cmp64, carry;  // (idx - open) * ONES + 0x88888888 as one v_mad_u64_u32 (hipcc would pick mul_lo + add)
             asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(cmp64), "=s"(carry) : "v"(idx - open), "s"(ONES), "v"(eights));
@@ -1038,8 +1039,9 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
 //     K >= 4 and H >= 6 (OPEN_BLOCKS >= 2) the same holds for plies 4 and 5, and plies 6 and 7 are full plies.
 //   * the lane-refill loop carries ~45 instructions of refill / store code around every 4-ply block.  The wave
 //     therefore opens 64 games AT ONCE, all lanes busy and no refill code, whenever its pool of opened boards runs
-//     dry, and parks them in a wave-private ring in LDS (128 slots of planes + column nibbles); idle lanes refill from
-//     the ring and join the main loop at block OPEN_BLOCKS (blocks 2.. of the opening are full blocks in lock step).
+//     dry, and parks them in a wave-private ring in LDS (planes + column nibbles + the words of the blocks to come); idle
+//     lanes refill from the ring and join the main loop at block OPEN_BLOCKS (blocks 2.. of the opening are full blocks
+//     in lock step).
 //     A game that ends inside the opening is stored by the opening stage and parked as a dead slot (column word 0).
 // Status and reward are not stored per game either: a finished game leaves ONE outcome byte in the wave's LDS slice (a
 // plain ds_write_b8), and when the chunk is done a lane reads four games as one dword -- their four status bytes as they
@@ -1049,10 +1051,30 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
 // <= 32 boards in LDS for the waves still running and leaves.  It cut another 6 % of the instructions and made the
 // kernel slower, alone and three in flight: the adopted boards lengthen ONE wave per workgroup, i.e. one SIMD of the
 // CU, and with two workgroups per CU that imbalance is not averaged out.)
+// Round 5: the ply loop holds NO philox.  With a word per block of four plies (bgs_common.h) one philox call serves
+// sixteen plies, a whole game of a board of at most 48 cells needs three -- what the opening stage computed for its own
+// three blocks before -- and the opening parks the words of the blocks still to come (block OPEN_BLOCKS .. the last one a
+// full board can reach: eight for Connect4) next to the board.  A lane that takes a board takes its words into registers;
+// a block consumes the first and moves the others down one (unconditional moves: lanes sit in different blocks).
+//   222 -> 186 VALU a block (42 of philox out, 3 sub-draw multiplies and 7 moves in), the opening as before.
+// The pool is a ring of 64 slots (128 before: with the words a slot is 52 bytes, and six workgroups a CU -- three launches
+// in flight -- leave each wave 6 KB of LDS): when it runs dry the lanes that need a board first take what is left, THEN
+// all 64 lanes open the chunk's next 64 games over the emptied slots, then the remaining needy lanes take from those.
+template <class G, int OPEN_BLOCKS>
+struct OpenedWords {
+    // the last block a game can reach; run-time geometries: the launcher admits boards of at most 48 cells (12 blocks)
+    static constexpr int LAST = G::STATIC_H > 0 ? (G::STATIC_H * G::STATIC_W + 3) / 4 - 1 : 11;
+    static constexpr int COUNT = LAST - OPEN_BLOCKS + 1 > 1 ? LAST - OPEN_BLOCKS + 1 : 1;   // words parked with a board
+    static constexpr int QUADS = (COUNT + 3) / 4;
+    static_assert(LAST <= 11 && OPEN_BLOCKS >= 1 && OPEN_BLOCKS <= 4, "three philox calls cover blocks 0 .. 11");
+};
+
+template <int QUADS>
 struct OpenedPool {  // per wave
-    static constexpr uint32_t SLOTS = 128;
+    static constexpr uint32_t SLOTS = 64;
     uint64_t plane[2][SLOTS];
-    uint64_t cols[SLOTS];  // low word: column nibbles, 0 = dead slot
+    uint32_t cols[SLOTS];          // column nibbles, 0 = dead slot (the opening stage has stored that game)
+    uint4 words[QUADS][SLOTS];     // the words of blocks OPEN_BLOCKS, OPEN_BLOCKS + 1, ...
 };
 
 template <class G, int OPEN_BLOCKS, bool CODES>
@@ -1060,8 +1082,11 @@ __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                          int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps,
                          uint32_t games_per_wave, uint32_t* __restrict__ codes_out) {
+    using OW = OpenedWords<G, OPEN_BLOCKS>;
+    constexpr int NWORDS = OW::QUADS * 4;
+    using Pool = OpenedPool<OW::QUADS>;
     extern __shared__ uint32_t code_lds[];  // one outcome BYTE per game of the wave's chunk: games_per_wave / 4 dwords per wave
-    __shared__ OpenedPool pools[BGS_BLOCK / BGS_WAVE];
+    __shared__ Pool pools[BGS_BLOCK / BGS_WAVE];
     constexpr uint32_t ONES = 0x11111111u;
     const uint32_t top = (uint32_t)g.h() + 7u;
     const uint32_t columns = g.w() >= 8 ? ONES : (ONES & ((1u << (4 * g.w())) - 1u));
@@ -1075,13 +1100,16 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
     const int64_t end = begin + games_per_wave < n ? begin + games_per_wave : n;
     const uint32_t avail = begin < end ? (uint32_t)(end - begin) : 0u;
     uint32_t taken = 0;    // games handed to lanes
-    uint32_t opened = 0;   // games whose opening has been played (a multiple of 64)
+    uint32_t opened = 0;   // games whose opening has been played (a multiple of 64); opened - taken <= 64 games wait in the pool
     uint64_t* __restrict__ const plane0 = planes + begin;
     uint64_t* __restrict__ const plane1 = planes + n + begin;
-    OpenedPool& pool = pools[threadIdx.x >> 6];
+    Pool& pool = pools[threadIdx.x >> 6];
 
     uint64_t p[2] = {0, 0};
-    uint32_t hts = 0, blk = 0, live = 0, st = 0, game = 0, stepped = 0;
+    uint32_t hts = 0, live = 0, st = 0, game = 0, stepped = 0;
+    uint32_t w[NWORDS];    // w[0]: the word of this lane's next block
+#pragma unroll
+    for (int k = 0; k < NWORDS; ++k) w[k] = 0;
 
     if (avail == 0u) return;
     // The outcome of game i of the chunk is byte i of the wave's LDS slice (a plain byte store where the game ends, no
@@ -1140,22 +1168,98 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
         q[j & 1u] |= 1ull << pos;
         h4 -= 1u << sh;
     };
-    // one philox block of four plies on this lane's board, then boards that ended go to memory (their status and
-    // reward follow from the codes)
+    // one block of four plies on this lane's board from the word w[0], then boards that ended go to memory (their status
+    // and reward follow from the codes); the lane's words move down one
     auto play_block = [&]() {
         const uint32_t was_live = live;
-        const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk);
+        const uint32_t word = w[0];
+#pragma unroll
+        for (int k = 0; k + 1 < NWORDS; ++k) w[k] = w[k + 1];
         uint32_t open = (hts >> 3) & ONES;
-        full_ply(std::integral_constant<uint32_t, 0>{}, draws.v[0], p, hts, open, live, st);
-        full_ply(std::integral_constant<uint32_t, 1>{}, draws.v[1], p, hts, open, live, st);
-        full_ply(std::integral_constant<uint32_t, 2>{}, draws.v[2], p, hts, open, live, st);
-        full_ply(std::integral_constant<uint32_t, 3>{}, draws.v[3], p, hts, open, live, st);
-        blk += 1u;
+        full_ply(std::integral_constant<uint32_t, 0>{}, sub_draw<0>(word), p, hts, open, live, st);
+        full_ply(std::integral_constant<uint32_t, 1>{}, sub_draw<1>(word), p, hts, open, live, st);
+        full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(word), p, hts, open, live, st);
+        full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(word), p, hts, open, live, st);
         if (was_live != 0 && live == 0) {
             *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane0) + (game * 8u)) = p[0];
             *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane1) + (game * 8u)) = p[1];
             outcome[game] = (uint8_t)(st ? st : BGS_ST_DRAW);  // no cap: a board that stopped without a winner is full
         }
+    };
+    // an idle lane takes game `which` of the chunk out of the pool: board, column nibbles, the words of its blocks to come
+    auto take = [&](uint32_t which) {
+        game = which;
+        const uint32_t slot = which & (Pool::SLOTS - 1u);
+        p[0] = pool.plane[0][slot];
+        p[1] = pool.plane[1][slot];
+        hts = pool.cols[slot];
+#pragma unroll
+        for (int k = 0; k < OW::QUADS; ++k) {
+            const uint4 v = pool.words[k][slot];
+            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+        st = 0;
+        live = hts != 0u ? ~0u : 0u;  // (a dead slot: the opening stage has stored that game)
+    };
+    // all 64 lanes open the chunk's next 64 games (blocks 0 .. OPEN_BLOCKS - 1 in lock step) and park them with their words
+    auto open_games = [&]() {
+        const uint32_t og = opened + lane;
+        const uint64_t id = first_game + (uint64_t)(begin + og);
+        uint64_t q[2] = {0, 0};
+        uint32_t h4 = top * columns, alive = ~0u, won_by = 0, op = columns;
+        uint32_t words[12];   // the words of blocks 0 .. 11: three philox calls (fewer when the board cannot last that long)
+        {
+            const Philox4 d = philox4x32_10(seed, id, 0u);
+            words[0] = d.v[0]; words[1] = d.v[1]; words[2] = d.v[2]; words[3] = d.v[3];
+        }
+#pragma unroll
+        for (int c = 1; c < 3; ++c) {
+            if (4 * c <= OW::LAST) {
+                const Philox4 d = philox4x32_10(seed, id, (uint32_t)c);
+                words[4 * c] = d.v[0]; words[4 * c + 1] = d.v[1]; words[4 * c + 2] = d.v[2]; words[4 * c + 3] = d.v[3];
+            } else {
+                words[4 * c] = words[4 * c + 1] = words[4 * c + 2] = words[4 * c + 3] = 0u;
+            }
+        }
+        cheap_ply(0u, sub_draw<0>(words[0]), q, h4);
+        cheap_ply(1u, sub_draw<1>(words[0]), q, h4);
+        cheap_ply(2u, sub_draw<2>(words[0]), q, h4);
+        cheap_ply(3u, sub_draw<3>(words[0]), q, h4);
+        const uint32_t before = stepped;
+        if (OPEN_BLOCKS >= 2) {
+            cheap_ply(0u, sub_draw<0>(words[1]), q, h4);
+            cheap_ply(1u, sub_draw<1>(words[1]), q, h4);
+            op = (h4 >> 3) & ONES;
+            full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(words[1]), q, h4, op, alive, won_by);
+            full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(words[1]), q, h4, op, alive, won_by);
+        }
+#pragma unroll
+        for (int ob = 2; ob < OPEN_BLOCKS; ++ob) {  // further blocks in lock step
+            full_ply(std::integral_constant<uint32_t, 0>{}, sub_draw<0>(words[ob]), q, h4, op, alive, won_by);
+            full_ply(std::integral_constant<uint32_t, 1>{}, sub_draw<1>(words[ob]), q, h4, op, alive, won_by);
+            full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(words[ob]), q, h4, op, alive, won_by);
+            full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(words[ob]), q, h4, op, alive, won_by);
+        }
+        if (og < avail) {
+            stepped += OPEN_BLOCKS >= 2 ? 6u : 4u;
+            if (OPEN_BLOCKS >= 2 && alive == 0) {  // ended inside the opening: a win, or a small board is full
+                plane0[og] = q[0];
+                plane1[og] = q[1];
+                outcome[og] = (uint8_t)(won_by ? won_by : BGS_ST_DRAW);
+            }
+        } else {
+            stepped = before;  // a lane past the end of the chunk played for nobody
+        }
+        const uint32_t slot = og & (Pool::SLOTS - 1u);
+        pool.plane[0][slot] = q[0];
+        pool.plane[1][slot] = q[1];
+        pool.cols[slot] = alive ? h4 : 0u;
+#pragma unroll
+        for (int k = 0; k < OW::QUADS; ++k) {
+            auto at = [&](int i) { return OPEN_BLOCKS + i <= 11 ? words[OPEN_BLOCKS + i <= 11 ? OPEN_BLOCKS + i : 11] : 0u; };
+            pool.words[k][slot] = make_uint4(at(4 * k), at(4 * k + 1), at(4 * k + 2), at(4 * k + 3));
+        }
+        opened += 64u;
     };
 
     // ---- the chunk: idle lanes take the next opened games
@@ -1163,62 +1267,22 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
         const uint64_t need = __builtin_amdgcn_ballot_w64(live == 0);
         if (need) {
             const uint32_t wanted = (uint32_t)__popcll(need);
-            if (taken + wanted > opened && opened < avail) {
-                // ---- the pool runs dry: all 64 lanes open the chunk's next 64 games
-                const uint32_t og = opened + lane;
-                const uint64_t id = first_game + (uint64_t)(begin + og);
-                uint64_t q[2] = {0, 0};
-                uint32_t h4 = top * columns, alive = ~0u, won_by = 0, op = columns;
-                {
-                    const Philox4 d = philox4x32_10(seed, id, 0u);
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) cheap_ply(j, d.v[j], q, h4);
-                }
-                const uint32_t before = stepped;
-                if (OPEN_BLOCKS >= 2) {
-                    const Philox4 d = philox4x32_10(seed, id, 1u);
-                    cheap_ply(0u, d.v[0], q, h4);
-                    cheap_ply(1u, d.v[1], q, h4);
-                    op = (h4 >> 3) & ONES;
-                    full_ply(std::integral_constant<uint32_t, 2>{}, d.v[2], q, h4, op, alive, won_by);
-                    full_ply(std::integral_constant<uint32_t, 3>{}, d.v[3], q, h4, op, alive, won_by);
-                }
-#pragma unroll
-                for (uint32_t ob = 2; ob < (uint32_t)OPEN_BLOCKS; ++ob) {  // further blocks in lock step
-                    const Philox4 d = philox4x32_10(seed, id, ob);
-                    full_ply(std::integral_constant<uint32_t, 0>{}, d.v[0], q, h4, op, alive, won_by);
-                    full_ply(std::integral_constant<uint32_t, 1>{}, d.v[1], q, h4, op, alive, won_by);
-                    full_ply(std::integral_constant<uint32_t, 2>{}, d.v[2], q, h4, op, alive, won_by);
-                    full_ply(std::integral_constant<uint32_t, 3>{}, d.v[3], q, h4, op, alive, won_by);
-                }
-                if (og < avail) {
-                    stepped += OPEN_BLOCKS >= 2 ? 6u : 4u;
-                    if (OPEN_BLOCKS >= 2 && alive == 0) {  // ended inside the opening: a win, or a small board is full
-                        plane0[og] = q[0];
-                        plane1[og] = q[1];
-                        outcome[og] = (uint8_t)(won_by ? won_by : BGS_ST_DRAW);
-                    }
-                } else {
-                    stepped = before;  // a lane past the end of the chunk played for nobody
-                }
-                const uint32_t slot = og & (OpenedPool::SLOTS - 1u);
-                pool.plane[0][slot] = q[0];
-                pool.plane[1][slot] = q[1];
-                pool.cols[slot] = alive ? h4 : 0u;
-                opened += 64u;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t have = opened - taken;   // wave-uniform: boards waiting in the pool (<= 64)
+            if (wanted > have && opened < avail) {
+                // ---- the pool runs dry: the first `have` needy lanes empty it, all 64 lanes open the chunk's next 64 games
+                // into the freed slots, the other needy lanes take from those
+                const bool first = live == 0 && rank < have;
+                const bool second = live == 0 && !first;
+                if (first && taken + rank < avail) take(taken + rank);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the reads above before the stores of the opening
+                __builtin_amdgcn_wave_barrier();
+                open_games();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-            }
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            if (live == 0 && taken + rank < avail) {
-                game = taken + rank;
-                const uint32_t slot = game & (OpenedPool::SLOTS - 1u);
-                p[0] = pool.plane[0][slot];
-                p[1] = pool.plane[1][slot];
-                hts = (uint32_t)pool.cols[slot];
-                st = 0;
-                blk = (uint32_t)OPEN_BLOCKS;
-                live = hts != 0u ? ~0u : 0u;  // (a dead slot: the opening stage has stored that game)
+                if (second && taken + rank < avail) take(taken + rank);
+            } else if (live == 0 && taken + rank < avail) {
+                take(taken + rank);
             }
             taken = avail - taken < wanted ? avail : taken + wanted;
         }
@@ -1307,11 +1371,11 @@ k_connect_rollout_aligned_wide(G g, uint64_t* __restrict__ planes, uint8_t* __re
         }
 
         const uint64_t was_live = live;
-        const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk);
+        const uint32_t word = philox_word(philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk >> 2), blk);
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t count_lo = (uint32_t)__popc(open_lo);
-            const uint32_t idx = sample_index(draws.v[j], count_lo + (uint32_t)__popc(open_hi));
+            const uint32_t idx = sample_index(sub_draw(word, j), count_lo + (uint32_t)__popc(open_hi));
             const bool in_lo = idx < count_lo;
             const uint32_t part = in_lo ? open_lo : open_hi;
             const uint32_t rank_in_part = in_lo ? idx : idx - count_lo;
@@ -1436,12 +1500,13 @@ k_connect_open_lds(G g, OpenedBoard* __restrict__ opened, int64_t n, uint64_t se
     if (i < n) {
         Bits<NW> p[2] = {zero_bits<NW>(), zero_bits<NW>()};
         uint64_t hts = 0;
+        static_assert(kOpenedBlocks <= 4, "one philox call covers four blocks");
+        const Philox4 words = philox4x32_10(seed, first_game + (uint64_t)i, 0u);   // the words of blocks 0 .. 3
 #pragma unroll
         for (uint32_t blk = 0; blk < kOpenedBlocks; ++blk) {
-            const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)i, blk);
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t col = sample_index(draws.v[j], (uint32_t)W);   // every column is open
+                const uint32_t col = sample_index(sub_draw(words.v[blk], j), (uint32_t)W);   // every column is open
                 const uint32_t v = (uint32_t)(hts >> (4u * col)) & 15u;
                 set_bit(p[j & 1u], (int)(col * (uint32_t)(H + 1) + v));
                 hts += 1ull << (4u * col);
@@ -1609,11 +1674,11 @@ k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
         }
 
         const uint32_t was_live = live;
-        const Philox4 draws = philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk);
+        const uint32_t word = philox_word(philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk >> 2), blk);
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t count_lo = (uint32_t)__popc(open_lo);
-            const uint32_t idx = sample_index(draws.v[j], count_lo + (uint32_t)__popc(open_hi));
+            const uint32_t idx = sample_index(sub_draw(word, j), count_lo + (uint32_t)__popc(open_hi));
             const bool in_lo = idx < count_lo;
             const uint32_t part = in_lo ? open_lo : open_hi;
             const uint32_t rank_in_part = in_lo ? idx : idx - count_lo;
@@ -2067,8 +2132,9 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
                     }
                 };
                 const size_t outcome_lds = (size_t)4 * per_wave;  // K2o: one outcome byte per game
+                // (boards of at most 48 cells: a game is at most 12 blocks of four plies, whose words three philox calls give)
                 if ((flags & 1u) && !capped && b->rollout_opening && b->cg.h >= 4 && b->cg.w >= 2 && b->cg.k >= 3 &&
-                    outcome_lds <= (32u << 10)) {
+                    b->cg.h * b->cg.w <= 48 && outcome_lds <= (32u << 10)) {
                     // from the initial state, no cap: the kernel with the lock-step opening stage (K2o)
                     auto launch_opened = [&](auto blocks_tag, auto codes_tag) {
                         constexpr int OPEN_BLOCKS = decltype(blocks_tag)::value;

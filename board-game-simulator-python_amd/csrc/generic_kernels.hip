@@ -27,16 +27,20 @@ constexpr int kBlock = 64;  // one wave per workgroup: these kernels diverge fre
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-// one philox block per 4 plies, recomputed when the ply enters a new block
+// the draw of a ply (RNG contract: bgs_common.h).  Bounce: a philox word per ply, one call per 4 plies; Connect: a word per
+// block of four plies, one call per 16 plies, the ply's draw a sub-draw of its block's word.  Recomputed when the ply
+// leaves the plies the held call covers.
+template <bool CONNECT>
 struct Draws {
+    static constexpr uint32_t SHIFT = CONNECT ? 4u : 2u;
     Philox4 blk;
-    uint32_t have;  // block index held + 1 (0 = none)
+    uint32_t have;  // index of the call held + 1 (0 = none)
     __device__ __forceinline__ uint32_t at(uint64_t seed, uint64_t game, uint32_t ply) {
-        if (have != (ply >> 2) + 1u) {
-            blk = philox4x32_10(seed, game, ply >> 2);
-            have = (ply >> 2) + 1u;
+        if (have != (ply >> SHIFT) + 1u) {
+            blk = philox4x32_10(seed, game, ply >> SHIFT);
+            have = (ply >> SHIFT) + 1u;
         }
-        return philox_word(blk, ply);
+        return CONNECT ? sub_draw(connect_word(blk, ply), ply & 3u) : philox_word(blk, ply);
     }
 };
 
@@ -115,7 +119,7 @@ g_connect_play(GConnect c, int8_t* __restrict__ grid, uint8_t* __restrict__ stat
             st = status[i];
             plies = plies_buf[i];
         }
-        Draws draws;
+        Draws<true> draws;
         draws.have = 0;
         while (st == BGS_ST_RUNNING && plies < max_plies && stepped < count) {
             const uint32_t idx = sample_index(draws.at(seed, first_game + (uint64_t)i, plies), (uint32_t)gc_legal_count(c, g));
@@ -491,7 +495,7 @@ g_bounce_play(GBounce b, const int8_t* __restrict__ cfg, int8_t* __restrict__ gr
         if (st == BGS_ST_RUNNING) {
             GBoard<NW> bd;
             gb_load(b, g, bd);
-            Draws draws;
+            Draws<false> draws;
             draws.have = 0;
             int n_act = gb_count_actions(b, g, bd, plies & 1u);
             if (n_act == 0) {  // a running board whose side to move is blocked (loaded or start position)

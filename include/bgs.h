@@ -20,10 +20,20 @@
  *     stream); functions that fill host memory synchronise that stream before returning;
  *   - winner codes: -1 running, 0 / 1 that player won, 2 draw.  reward = +1 / -1 per player, 0 / 0 otherwise.
  *
- * RNG contract (build-defined): draw(seed, game, ply) = philox4x32-10(key = seed, counter = (game lo, game hi,
- * ply >> 2, 0))[ply & 3]; sampled action index = (draw * n_actions) >> 32 into the canonical action list
- * (Connect: legal columns ascending; Bounce: sources by ascending x, targets by ascending (y, x)).
- * `game` = first_game + index in batch, so results do not depend on sharding or launch geometry.
+ * RNG contract (build-defined: the reference has no RNG, its callers use random.choice, README.md:62).  A draw is a
+ * 32-bit value, the sampled action is index (draw * n_actions) >> 32 of the canonical action list (Connect: legal columns
+ * ascending; Bounce: sources by ascending x, targets by ascending (y, x)); philox = philox4x32-10 with key = seed.
+ *   Bounce : draw(seed, game, ply) = philox(counter = (game lo, game hi, ply >> 2, 0))[ply & 3] -- a word per ply.
+ *   Connect: word(seed, game, ply) = philox(counter = (game lo, game hi, ply >> 4, 0))[(ply >> 2) & 3] -- a word per block
+ *            of four plies -- and draw = word * A^(ply & 3) mod 2^32, A = 747796405: the four draws of a block are four
+ *            consecutive states of the multiplicative congruential generator x -> A x mod 2^32 started at the word.  Every
+ *            one of them is a bijection of the word, so each ply's index is distributed exactly as a word of its own would
+ *            make it (bias <= n / 2^32); the four plies of a block share 32 bits of entropy, and counted over ALL 2^32 words
+ *            every four-move sequence of a 7-column board comes within 4.2 x 10^-5 (relative) of 1 / 7^4 and every pair of
+ *            plies within 4 x 10^-7 of 1 / 49 (13 columns: 2.9 x 10^-4, 16 columns: 4.3 x 10^-4; tools/subdraw_lattice.c).
+ *            Different blocks use different philox words.  (Round 5; until then Connect drew a word per ply too.  One philox
+ *            call now serves sixteen plies, and the bench kernel's ply loop holds none: DESIGN.md section 3.)
+ * `game` = first_game + index in batch, so results do not depend on sharding, launch geometry or kernel family.
  */
 #ifndef BGS_H
 #define BGS_H

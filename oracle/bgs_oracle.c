@@ -51,6 +51,21 @@ uint32_t orc_sample_index(uint64_t seed, uint64_t game, uint32_t ply, uint32_t n
     return (uint32_t)(((uint64_t)orc_draw(seed, game, ply) * n_actions) >> 32);
 }
 
+/* Connect: the word of the ply's block, stepped (ply & 3) times through x -> A x mod 2^32 (bgs_oracle.h) */
+uint32_t orc_connect_draw(uint64_t seed, uint64_t game, uint32_t ply) {
+    uint32_t ctr[4] = {(uint32_t)game, (uint32_t)(game >> 32), ply >> 4, 0u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t out[4];
+    orc_philox4x32_10(ctr, key, out);
+    uint32_t x = out[(ply >> 2) & 3u];
+    for (uint32_t j = 0; j < (ply & 3u); ++j) x *= ORC_SUBDRAW_A;
+    return x;
+}
+
+uint32_t orc_connect_sample_index(uint64_t seed, uint64_t game, uint32_t ply, uint32_t n_actions) {
+    return (uint32_t)(((uint64_t)orc_connect_draw(seed, game, ply) * n_actions) >> 32);
+}
+
 int orc_reward(int64_t n, const int8_t* winner, int8_t* reward) {
     if (n < 0 || !winner || !reward) return ORC_ERR_ARG;
     for (int64_t i = 0; i < n; ++i) {
@@ -163,7 +178,7 @@ static uint64_t connect_play(int h, int w, int k, int8_t* g, int8_t* player, int
     uint64_t steps = 0;
     while (*winner == -1 && *plies < max_plies) {
         int n = connect_legal_one(h, w, g, *winner, cols);
-        uint32_t idx = orc_sample_index(seed, game, (uint32_t)*plies, (uint32_t)n);
+        uint32_t idx = orc_connect_sample_index(seed, game, (uint32_t)*plies, (uint32_t)n);
         connect_apply_one(h, w, k, g, player, winner, plies, cols[idx]);
         ++steps;
         if (single_ply) break;

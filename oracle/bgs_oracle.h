@@ -37,11 +37,24 @@ extern "C" {
 #define ORC_ERR_ILLEGAL (-2)
 
 /* ---- RNG contract (build-defined; the reference has no RNG, README.md:62 uses Python's) ---- */
-/* philox4x32-10 (Salmon et al. 2011), key = (seed lo, seed hi), counter = (game lo, game hi, ply>>2, 0);
- * the 32-bit draw for a ply is output word (ply & 3); the sampled index is (draw * n_actions) >> 32. */
+/* philox4x32-10 (Salmon et al. 2011), key = (seed lo, seed hi); the sampled index is (draw * n_actions) >> 32.
+ *   Bounce  (up to a few hundred actions a ply): one 32-bit word per ply -- counter = (game lo, game hi, ply >> 2, 0), the
+ *           draw of a ply is output word (ply & 3);
+ *   Connect (at most `width` <= 64 actions a ply; round 5): one 32-bit word per BLOCK of four plies -- counter = (game lo,
+ *           game hi, ply >> 4, 0), the block's word is output word ((ply >> 2) & 3), and the draw of ply j = ply & 3 of the
+ *           block is  word * A^j mod 2^32,  A = 747796405: the four draws of a block are four consecutive states of the
+ *           multiplicative congruential generator x -> A x mod 2^32 started at the philox word.  Each of them is a bijection
+ *           of the word, so every ply's index has exactly the distribution a word of its own would give it; what the four
+ *           plies of a block share is 32 bits of entropy, and their JOINT distribution is the lattice of that generator:
+ *           counted over all 2^32 words (tools/subdraw_lattice.c), every one of the 7^4 four-move sequences of a 7-column
+ *           board comes within 4.2 x 10^-5 (relative) of 1 / 7^4, every pair of plies within 4 x 10^-7 of 1 / 49;
+ *           13 columns: 2.9 x 10^-4, 16 columns: 4.3 x 10^-4.  Blocks are independent philox words. */
+#define ORC_SUBDRAW_A 747796405u
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-uint32_t orc_draw(uint64_t seed, uint64_t game, uint32_t ply);
+uint32_t orc_draw(uint64_t seed, uint64_t game, uint32_t ply);            /* Bounce: a word per ply */
 uint32_t orc_sample_index(uint64_t seed, uint64_t game, uint32_t ply, uint32_t n_actions);
+uint32_t orc_connect_draw(uint64_t seed, uint64_t game, uint32_t ply);    /* Connect: a word per four plies */
+uint32_t orc_connect_sample_index(uint64_t seed, uint64_t game, uint32_t ply, uint32_t n_actions);
 
 /* ---- Connect (reference surface: src/simulator/game/connect.cpp:24-54) ---- */
 /* batch arrays: grid int8[n][h][w] (-1 empty, 0, 1), player int8[n], winner int8[n], plies int32[n] */

@@ -52,6 +52,10 @@ def lib() -> ctypes.CDLL:
         _lib.orc_draw.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
         _lib.orc_sample_index.restype = ctypes.c_uint32
         _lib.orc_sample_index.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
+        _lib.orc_connect_draw.restype = ctypes.c_uint32
+        _lib.orc_connect_draw.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
+        _lib.orc_connect_sample_index.restype = ctypes.c_uint32
+        _lib.orc_connect_sample_index.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
     return _lib
 
 
@@ -79,6 +83,18 @@ def draw(seed: int, game: int, ply: int) -> int:
 
 def sample_index(seed: int, game: int, ply: int, n: int) -> int:
     return int(lib().orc_sample_index(seed, game, ply, n))
+
+
+SUBDRAW_A = 747796405
+
+
+def connect_draw(seed: int, game: int, ply: int) -> int:
+    """Connect's draw of a ply: the philox word of the ply's four-ply block times SUBDRAW_A ** (ply & 3) mod 2^32."""
+    return int(lib().orc_connect_draw(seed, game, ply))
+
+
+def connect_sample_index(seed: int, game: int, ply: int, n: int) -> int:
+    return int(lib().orc_connect_sample_index(seed, game, ply, n))
 
 
 def reward(winner: np.ndarray) -> np.ndarray:

@@ -45,6 +45,42 @@ def test_draw_layout():
             assert oracle.sample_index(seed, game, ply, n) == (int(block[ply & 3]) * n) >> 32
 
 
+def test_connect_draw_layout():
+    """Connect (round 5): one philox WORD per block of four plies -- counter (game lo, game hi, ply >> 4, 0), output word
+    (ply >> 2) & 3 -- and the draw of ply j of the block is word * A^j mod 2^32, A = 747796405."""
+    seed, game, a = 0x0123456789ABCDEF, 0x1_0000_0007, 747796405
+    for ply in range(70):
+        block = oracle.philox4x32_10([game & 0xFFFFFFFF, game >> 32, ply >> 4, 0], [seed & 0xFFFFFFFF, seed >> 32])
+        word = int(block[(ply >> 2) & 3])
+        want = (word * pow(a, ply & 3, 1 << 32)) & 0xFFFFFFFF
+        assert oracle.connect_draw(seed, game, ply) == want
+        for n in (1, 2, 7, 13, 64):
+            assert oracle.connect_sample_index(seed, game, ply, n) == (want * n) >> 32
+    # the first ply of a block uses the word itself
+    assert oracle.connect_draw(seed, game, 0) == int(oracle.philox4x32_10([game & 0xFFFFFFFF, game >> 32, 0, 0], [seed & 0xFFFFFFFF, seed >> 32])[0])
+    assert oracle.SUBDRAW_A == a
+
+
+def test_connect_sub_draws_are_jointly_uniform_on_a_sample():
+    """The four draws of a block are four states of x -> A x mod 2^32: every one of them is a bijection of the word (so a ply's
+    index is as uniform as a word of its own would make it) and the exhaustive count over all 2^32 words
+    (tools/subdraw_lattice.c; quoted in bgs_oracle.h) puts every four-move sequence of a 7-column board within 4.2e-5 of
+    1 / 7^4.  Here: the same count on 2^23 pseudo-random words, loose bounds, to catch a wrong constant."""
+    a = 747796405
+    words = np.random.default_rng(20261005).integers(0, 1 << 32, size=1 << 23, dtype=np.uint64)
+    idx = []
+    for j in range(4):
+        x = (words * np.uint64(pow(a, j, 1 << 32))) & np.uint64(0xFFFFFFFF)
+        idx.append((x * np.uint64(7)) >> np.uint64(32))
+    cell = ((idx[0] * 7 + idx[1]) * 7 + idx[2]) * 7 + idx[3]
+    counts = np.bincount(cell.astype(np.int64), minlength=7**4)
+    expect = len(words) / 7**4
+    assert counts.min() > 0.9 * expect and counts.max() < 1.1 * expect
+    for j in range(4):
+        single = np.bincount(idx[j].astype(np.int64), minlength=7)
+        assert abs(single / (len(words) / 7) - 1).max() < 2e-3
+
+
 # ------------------------------------------------------------------ Connect
 
 

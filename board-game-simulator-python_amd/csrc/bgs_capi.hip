@@ -430,6 +430,7 @@ int make_order_event(bgs_batch* b) {
 
 // a batch whose construction failed half-way
 void discard(bgs_batch* b) {
+    if (b->game == BGS_GAME_BOUNCE) bgs::bounce_book_release(b);
     if (b->owns_arena && b->arena) (void)hipFree(b->arena);
     if (b->order_event) (void)hipEventDestroy(b->order_event);
     delete b;
@@ -740,6 +741,17 @@ int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, 
             return BGS_OK;
         }();
     }
+    if (rc == BGS_OK && !generic) {
+        // the opening book of the start position, for the batches the piece-list rollout plays (from 32768 boards): built
+        // once per start position and device, shared afterwards.  BGS_BOUNCE_BOOK=0 switches it off, 1..4 = that depth
+        // at most, for a batch of any size (the tests' way to reach it with small batches)
+        const char* e = getenv("BGS_BOUNCE_BOOK");
+        const int want = e ? atoi(e) : (n >= 32768 ? 4 : 0);
+        if (want > 0) {
+            const int he = bgs::bounce_book_acquire(b, want);
+            if (he != 0) rc = fail(BGS_ERR_RUNTIME, "the opening book could not be built: %s", hipGetErrorString((hipError_t)he));
+        }
+    }
     if (rc == BGS_OK) rc = reset_impl(b);
     if (rc != BGS_OK) {
         discard(b);
@@ -754,6 +766,7 @@ int bgs_destroy(bgs_batch* b) {
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
     drop_small_transition(b);
+    if (b->game == BGS_GAME_BOUNCE) bgs::bounce_book_release(b);
     if (b->owns_arena && b->arena) (void)hipFree(b->arena);
     for (int k = 0; k < 2; ++k) {
         if (b->pinned[k]) (void)hipHostFree(b->pinned[k]);

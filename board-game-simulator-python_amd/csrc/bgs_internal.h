@@ -67,6 +67,13 @@ struct bgs_batch {
     uint32_t* d_worklist;    // [n] board indices still to play (Bounce multi-pass rollout)
     uint32_t* d_work_count;  // [2 * BGS_BOUNCE_MAX_PASSES] list lengths, then work-queue heads; device-resident
     uint32_t* d_pool;        // packed Bounce: [BGS_BOUNCE_POOL_WORDS] the piece-list rollout's device-wide pool of parked boards
+    // packed Bounce, large batches: the opening book of the start position (bounce_kernels.hip; shared by the batches of a
+    // process that have the same start position on the same device, bgs::bounce_book_acquire / release)
+    const uint32_t* book_links;
+    const void* book_table;
+    int book_depth;          // plies a new game skips (0: no book)
+    uint32_t book_n0;        // actions at the start position
+    void* book_owner;
     // pinned bounce buffers for large device -> host copies (allocated on first use)
     void* pinned[2];
     hipEvent_t pinned_done[2];
@@ -103,6 +110,10 @@ void bounce_transition(const bgs_batch* b, const int32_t* d_moves, int32_t* d_st
                        int8_t* d_winner, int32_t* d_plies, uint64_t* d_targets, int8_t* d_reward_out, uint32_t* d_done = nullptr,
                        uint32_t ticket = 0);
 void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags);
+// the opening book of the batch's start position (see bounce_kernels.hip): built on the batch's stream the first time a
+// start position is seen on a device, shared afterwards; 0 or a HIP error code
+int bounce_book_acquire(bgs_batch* b, int max_depth);
+void bounce_book_release(bgs_batch* b);
 void bounce_unpack_grid(const bgs_batch* b, int8_t* d_grid);
 void bounce_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies);
 void bounce_targets(const bgs_batch* b, uint64_t* d_targets, int32_t* d_count);

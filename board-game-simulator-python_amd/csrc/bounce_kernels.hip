@@ -19,6 +19,11 @@
 // depend on how it was reached), which is the closure the recursive search computes.
 #include <type_traits>
 
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
 #include "bgs_common.h"
 #include "bgs_internal.h"
 
@@ -1068,6 +1073,150 @@ __device__ __forceinline__ void pick_from_lands(const BounceGeom& g, const Piece
     dst_cell = (int)select_bit64(landed_by(g, L, members) & landing, idx);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The OPENING BOOK of a start position (round 5).  Every board of a from-initial rollout starts from the same position:
+// ply 0 is ONE position on all 2^18 lanes, plies 1 and 2 a few hundred, and a wave iteration of K3p costs the same
+// ~2 400 instructions whatever its lanes search.  So the first plies are not searched at all: the positions reachable in
+// `depth` plies (default board: 22 actions at the start, 496 two-ply paths, 12 684 three-ply paths, 338 590 four-ply
+// paths) are enumerated ONCE per start position -- by these kernels, with K3p's own search, pick and move, so the
+// canonical action order is the rollout's by construction -- and a lane that takes a new game walks them with the game's
+// own draws (philox block 0 = the words of plies 0 .. 3):
+//     at = idx(v0, n0);  e = L1[at]: at = off(e) + idx(v1, n(e));  e = L2[at]: ...;  entry = T[depth][at]
+// and starts at ply `depth` on the entry's board (positions, index planes, occupancy: one 64-byte line).  The walk is
+// keyed by (game, ply) draws exactly as the plies it replaces, so the boards are those of a search of every ply, bit for
+// bit.  A path that ends early (a piece reaches the goal row, a side is blocked) is carried down the levels as an entry
+// with one pseudo-action leading to itself, its final status and ITS ply count.
+//   level d: hdr[d] paths of d plies, link word of path i = first child path << 10 | number of actions (children)
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kBookCap1 = 64, kBookCap2 = 1024, kBookCap3 = 16384, kBookCap4 = 1u << 19;
+constexpr uint32_t kBookLinkBits = 10, kBookLinkMax = (1u << kBookLinkBits) - 1u;
+constexpr uint32_t kBookLinks = kBookCap1 + kBookCap2 + kBookCap3;   // L1 at 0, L2 at kBookCap1, L3 at kBookCap1 + kBookCap2
+constexpr uint32_t kBookLdsLinks = kBookCap1 + kBookCap2;            // what the rollout keeps in LDS
+struct BookEntry {
+    uint32_t pos[4];     // PieceBoard::pos (16 pieces)
+    uint64_t idx[4];     // PieceBoard::idx
+    uint64_t occ;
+    uint32_t meta;       // status | plies << 8 | actions << 16 (the side to move's; 1 for a path that has ended)
+    uint32_t pad;
+};
+static_assert(sizeof(BookEntry) == 64, "one cache line, four 16-byte loads");
+
+// hdr[0]: flags (bit d: level d holds a position with more actions than a link word can say), hdr[d]: paths of d plies
+__global__ void __launch_bounds__(BGS_WAVE) k_bounce_book_root(BounceGeom g, uint32_t* __restrict__ hdr) {
+    constexpr int PMAX = BGS_BOUNCE_MAX_PIECES;
+    PieceBoard<PMAX> b;
+    pieces_from_start(g, b);
+    Lands<PMAX> L;
+    PieceMoves mv;
+    land_all<PMAX>(g, b, 0u, L);
+    close_over_bounces<PMAX>(g, L);
+    count_from_lands<PMAX>(g, b, 0u, true, L, mv);
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        hdr[0] = mv.n > kBookLinkMax ? 1u : 0u;
+        hdr[1] = g.init_status == BGS_ST_RUNNING ? mv.n : 0u;
+    }
+}
+
+__global__ void __launch_bounds__(BGS_WAVE)
+k_bounce_book_expand(BounceGeom g, uint32_t level, const BookEntry* __restrict__ parents, const uint32_t* __restrict__ parent_links,
+                     BookEntry* __restrict__ out, uint32_t out_cap, uint32_t* __restrict__ hdr) {
+    constexpr int PMAX = BGS_BOUNCE_MAX_PIECES;
+    const uint32_t j = blockIdx.x * BGS_WAVE + threadIdx.x;
+    const uint32_t total = hdr[level] < out_cap ? hdr[level] : out_cap;
+    const bool active = j < total;
+    PieceBoard<PMAX> b;
+    pieces_from_start(g, b);   // (idle lanes search the start position: every lane runs every phase)
+    uint32_t st = BGS_ST_RUNNING, plies = level - 1u, action = active ? j : 0u;
+    if (active && level > 1u) {
+        uint32_t lo = 0, hi = hdr[level - 1u];   // the parent: the last path whose first child is <= j
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((parent_links[mid] >> kBookLinkBits) <= j) lo = mid; else hi = mid;
+        }
+        action = j - (parent_links[lo] >> kBookLinkBits);
+        const BookEntry& e = parents[lo];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            b.pos[k] = e.pos[k];
+            b.idx[k] = e.idx[k];
+        }
+        b.occ = e.occ;
+        st = e.meta & 255u;
+        plies = (e.meta >> 8) & 255u;
+    }
+    const uint32_t side = (level - 1u) & 1u, other = level & 1u;
+    Lands<PMAX> L;
+    PieceMoves mv;
+    land_all<PMAX>(g, b, side, L);
+    close_over_bounces<PMAX>(g, L);
+    count_from_lands<PMAX>(g, b, side, true, L, mv);
+    uint32_t n = 1u;
+    const bool moves = active && st == BGS_ST_RUNNING;   // (a running parent has mv.n > action actions: that is what its link says)
+    int s = 0, t = 0;
+    pick_from_lands<PMAX>(g, b, side, mv, L, moves ? action : 0u, s, t);
+    if (moves) {
+        move_piece_on(b, s, t);
+        plies = level;
+        if ((1ull << t) & (g.goal_top | g.goal_bottom)) st = side + 1u;
+    }
+    // the new position's side to move; a side without an action loses to a side that has one (SURVEY App. B rule 7)
+    land_all<PMAX>(g, b, other, L);
+    close_over_bounces<PMAX>(g, L);
+    count_from_lands<PMAX>(g, b, other, true, L, mv);
+    const uint32_t n_other = mv.n;
+    land_all<PMAX>(g, b, side, L);
+    close_over_bounces<PMAX>(g, L);
+    count_from_lands<PMAX>(g, b, side, true, L, mv);
+    if (moves && st == BGS_ST_RUNNING) {
+        if (n_other == 0u) st = mv.n ? side + 1u : BGS_ST_DRAW;
+        else n = n_other;
+    }
+    if (active) {
+        if (n > kBookLinkMax) atomicOr(hdr, 1u << level);
+        BookEntry e;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            e.pos[k] = b.pos[k];
+            e.idx[k] = b.idx[k];
+        }
+        e.occ = b.occ;
+        e.meta = st | (plies << 8) | ((n <= kBookLinkMax ? n : kBookLinkMax) << 16);
+        e.pad = 0;
+        out[j] = e;
+    }
+}
+
+// the links of a level (first child path << 10 | actions) and the number of paths of the next one: one workgroup
+__global__ void __launch_bounds__(BGS_BLOCK)
+k_bounce_book_links(const BookEntry* __restrict__ table, uint32_t level, uint32_t cap, uint32_t* __restrict__ links,
+                    uint32_t* __restrict__ hdr) {
+    __shared__ uint32_t sums[BGS_BLOCK];
+    const uint32_t total = hdr[level] < cap ? hdr[level] : cap;
+    const uint32_t per = (total + BGS_BLOCK - 1u) / BGS_BLOCK;
+    const uint32_t first = threadIdx.x * per, last = first + per < total ? first + per : total;
+    uint32_t sum = 0;
+    for (uint32_t i = first; i < last; ++i) sum += (table[i].meta >> 16) & 0xFFFFu;
+    sums[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < BGS_BLOCK; ++k) {
+            const uint32_t v = sums[k];
+            sums[k] = run;
+            run += v;
+        }
+        hdr[level + 1u] = run;
+        if (hdr[level] > cap) atomicOr(hdr, 1u << level);
+    }
+    __syncthreads();
+    uint32_t off = sums[threadIdx.x];
+    for (uint32_t i = first; i < last; ++i) {
+        const uint32_t n = (table[i].meta >> 16) & 0xFFFFu;
+        links[i] = (off << kBookLinkBits) | n;
+        off += n;
+    }
+}
+
 // the device-wide pool of parked boards (see the kernel): boards a workgroup parks, dwords per entry (positions, game, plies)
 constexpr uint32_t kPoolCap = 64, kPoolWords = 6;
 
@@ -1084,13 +1233,28 @@ struct ParkedPieces {
 
 // BLOCK threads per workgroup (256, 512 or 1024): the waves of a workgroup share their drain through LDS, so a larger
 // workgroup ends with fewer half-empty waves (one per workgroup carries the workgroup's longest games to their end)
+// Waves per SIMD: with the opening book's loads the kernel needs 98 VGPRs -- two more than five waves a SIMD allow.  Held to
+// 96 (amdgpu_waves_per_eu) the 8- and 12-piece instantiations fit without a spill (the 16-piece one spills 44 bytes), and a
+// fifth wave a SIMD hides more of a ply's 17 us of dependent instructions: tools/k3p_waves_ab.sh has the A/B.
+#ifndef BGS_K3P_WAVES
+#define BGS_K3P_WAVES 0
+#endif
+#if BGS_K3P_WAVES > 0
+#define BGS_K3P_OCCUPANCY __attribute__((amdgpu_waves_per_eu(BGS_K3P_WAVES, BGS_K3P_WAVES)))
+#else
+#define BGS_K3P_OCCUPANCY
+#endif
 template <int PMAX, int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) BGS_K3P_OCCUPANCY
 k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                         uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
                         unsigned long long* __restrict__ steps, uint32_t chunk, uint32_t* __restrict__ queue, uint32_t park_at,
-                        uint32_t* gpool) {
+                        uint32_t* gpool, const uint32_t* __restrict__ book_links, const BookEntry* __restrict__ book_table,
+                        uint32_t book_depth, uint32_t book_n0) {
     __shared__ ParkedPieces<PMAX, BLOCK> parked;
+    __shared__ uint32_t book_lds[kBookLdsLinks];   // the opening book's links of levels 1 and 2 (4.25 KB)
+    if (book_depth >= 2u)
+        for (uint32_t i = threadIdx.x; i < kBookLdsLinks; i += BLOCK) book_lds[i] = book_links[i];
     Lands<PMAX> lands;   // (registers; valid from a ply's search to its move)
     constexpr uint32_t WAVES = ParkedPieces<PMAX, BLOCK>::WAVES;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1177,12 +1341,44 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (!has && taken + rank < avail) {
                 game = begin + taken + rank;
-                pieces_from_start(g, b);
-                st = g.init_status;
-                plies = 0;
+                if (book_depth) {
+                    // the opening book (see above): the game's first plies are a walk along the book's links with the game's
+                    // own draws -- the words of philox block 0 -- and the lane starts on the board the walk ends on
+                    blk = philox4x32_10(seed, first_game + (uint64_t)game, 0u);
+                    have_block = true;
+                    uint32_t at = sample_index(blk.v[0], book_n0);
+                    if (book_depth >= 2u) {
+                        const uint32_t e = book_lds[at];
+                        at = (e >> kBookLinkBits) + sample_index(blk.v[1], e & kBookLinkMax);
+                    }
+                    if (book_depth >= 3u) {
+                        const uint32_t e = book_lds[kBookCap1 + at];
+                        at = (e >> kBookLinkBits) + sample_index(blk.v[2], e & kBookLinkMax);
+                    }
+                    if (book_depth >= 4u) {
+                        const uint32_t e = book_links[kBookCap1 + kBookCap2 + at];
+                        at = (e >> kBookLinkBits) + sample_index(blk.v[3], e & kBookLinkMax);
+                    }
+                    const uint4* line = reinterpret_cast<const uint4*>(book_table + at);
+                    const uint4 q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3];
+                    const uint32_t where[4] = {q0.x, q0.y, q0.z, q0.w};
+#pragma unroll
+                    for (int j = 0; j < PMAX / 4; ++j) b.pos[j] = where[j];
+                    b.idx[0] = ((uint64_t)q1.y << 32) | q1.x;
+                    b.idx[1] = ((uint64_t)q1.w << 32) | q1.z;
+                    b.idx[2] = ((uint64_t)q2.y << 32) | q2.x;
+                    b.idx[3] = ((uint64_t)q2.w << 32) | q2.z;
+                    b.occ = ((uint64_t)q3.y << 32) | q3.x;
+                    st = q3.z & 255u;
+                    plies = (q3.z >> 8) & 255u;
+                } else {
+                    pieces_from_start(g, b);
+                    st = g.init_status;
+                    plies = 0;
+                    have_block = false;
+                }
                 first_ply = 0;
                 has = true;
-                have_block = false;
                 search = st == BGS_ST_RUNNING;
                 pending = false;
             }
@@ -2214,6 +2410,8 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
             }
         }
         const unsigned groups = (unsigned)((flat_waves + per_block - 1) / per_block);
+        // the opening book of the start position (bounce_book_acquire): games start `depth` plies in -- unless the cap is shorter
+        const uint32_t book_depth = b->book_table && b->book_depth > 0 && cap >= (uint32_t)b->book_depth ? (uint32_t)b->book_depth : 0u;
         // the device-wide pool of parked boards: counters zeroed per launch (one small fill on the stream)
         uint32_t* pool = b->bounce_pool && b->bounce_pieces_park > 0 && groups >= 2 && groups <= (unsigned)BGS_BOUNCE_POOL_GROUPS ? b->d_pool : nullptr;
         if (pool) (void)hipMemsetAsync(pool, 0, sizeof(uint32_t) * (4 + 2 * (size_t)groups), b->stream);
@@ -2223,7 +2421,8 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         hipLaunchKernelGGL((k_bounce_rollout_pieces<PMAX, BLOCK>), dim3(groups),
                            dim3(BLOCK), tile, b->stream, b->bg, b->d_planes, b->d_status, b->d_plies,
                            reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps, chunk, queue,
-                           (uint32_t)b->bounce_pieces_park, pool);
+                           (uint32_t)b->bounce_pieces_park, pool, b->book_links,
+                           reinterpret_cast<const BookEntry*>(b->book_table), book_depth, b->book_n0);
         // every board was written as the positions of its pieces: the value planes for all of them, at full lanes
         hipLaunchKernelGGL(k_bounce_positions_to_planes, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->n);
     };
@@ -2349,6 +2548,124 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
         hipLaunchKernelGGL((k_bounce_play<false, false>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg,
                            b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
                            b->first_game, cap, b->d_steps);
+}
+
+// ---- the opening book's life: one per (device, start position) in the process, counted by the batches that use it ----
+namespace {
+struct Book {
+    int device = 0;
+    BounceGeom key;          // (the start position and geometry it was built for)
+    uint32_t* links = nullptr;
+    uint32_t* hdr = nullptr;
+    BookEntry* level[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int depth = 0;
+    uint32_t n0 = 0;
+    int users = 0;
+};
+std::mutex g_books_mu;
+std::vector<Book*> g_books;
+
+void free_book(Book* k) {
+    (void)hipFree(k->links);
+    (void)hipFree(k->hdr);
+    for (int d = 1; d <= 4; ++d) (void)hipFree(k->level[d]);
+    delete k;
+}
+}  // namespace
+
+int bounce_book_acquire(bgs_batch* b, int max_depth) {
+    b->book_links = nullptr;
+    b->book_table = nullptr;
+    b->book_depth = 0;
+    b->book_owner = nullptr;
+    if (max_depth <= 0 || b->bg.piece_count < 1 || b->bg.init_status != BGS_ST_RUNNING || b->bg.w > kMaxTrackedColumns) return 0;
+    if (max_depth > 4) max_depth = 4;
+    std::lock_guard<std::mutex> lock(g_books_mu);
+    Book* k = nullptr;
+    for (Book* c : g_books)
+        if (c->device == b->device && memcmp(&c->key, &b->bg, sizeof(BounceGeom)) == 0 && c->depth <= max_depth) {
+            k = c;
+            break;
+        }
+    if (!k) {
+        k = new (std::nothrow) Book();
+        if (!k) return (int)hipErrorOutOfMemory;
+        k->device = b->device;
+        k->key = b->bg;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&k->links), sizeof(uint32_t) * kBookLinks);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&k->hdr), sizeof(uint32_t) * 16);
+        const uint32_t cap[5] = {0, kBookCap1, kBookCap2, kBookCap3, kBookCap4};
+        for (int d = 1; d <= 3 && e == hipSuccess; ++d) e = hipMalloc(reinterpret_cast<void**>(&k->level[d]), sizeof(BookEntry) * cap[d]);
+        uint32_t hdr[8] = {0};
+        if (e == hipSuccess) e = hipMemsetAsync(k->hdr, 0, sizeof(uint32_t) * 16, b->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(k->links, 0, sizeof(uint32_t) * kBookLinks, b->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_bounce_book_root, dim3(1), dim3(BGS_WAVE), 0, b->stream, b->bg, k->hdr);
+            uint32_t* const link_at[4] = {nullptr, k->links, k->links + kBookCap1, k->links + kBookCap1 + kBookCap2};
+            for (uint32_t d = 1; d <= 3; ++d) {
+                hipLaunchKernelGGL(k_bounce_book_expand, dim3(cap[d] / BGS_WAVE), dim3(BGS_WAVE), 0, b->stream, b->bg, d,
+                                   d > 1 ? k->level[d - 1] : nullptr, d > 1 ? link_at[d - 1] : nullptr, k->level[d], cap[d], k->hdr);
+                hipLaunchKernelGGL(k_bounce_book_links, dim3(1), dim3(BGS_BLOCK), 0, b->stream, k->level[d], d, cap[d], link_at[d], k->hdr);
+            }
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(hdr, k->hdr, sizeof hdr, hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) {
+            free_book(k);
+            return (int)e;
+        }
+        // the deepest level that fits: every level above it within its capacity, no position with more actions than a link holds
+        int depth = 0;
+        if (hdr[1] >= 1 && hdr[1] <= cap[1] && !(hdr[0] & 3u)) {
+            depth = 1;
+            if (hdr[2] <= cap[2] && !(hdr[0] & 4u)) {
+                depth = 2;
+                if (hdr[3] <= cap[3] && !(hdr[0] & 8u)) {
+                    depth = 3;
+                    if (hdr[4] >= 1 && hdr[4] <= cap[4]) depth = 4;
+                }
+            }
+        }
+        if (depth > max_depth) depth = max_depth;
+        if (depth == 4) {
+            e = hipMalloc(reinterpret_cast<void**>(&k->level[4]), sizeof(BookEntry) * hdr[4]);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_bounce_book_expand, dim3((hdr[4] + BGS_WAVE - 1) / BGS_WAVE), dim3(BGS_WAVE), 0, b->stream, b->bg,
+                                   4u, k->level[3], k->links + kBookCap1 + kBookCap2, k->level[4], hdr[4], k->hdr);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+            }
+            if (e != hipSuccess) depth = 3;   // (no memory for the last level: a shallower book)
+        }
+        k->depth = depth;
+        k->n0 = hdr[1];
+        g_books.push_back(k);
+    }
+    ++k->users;
+    b->book_owner = k;
+    if (k->depth > 0) {
+        b->book_links = k->links;
+        b->book_table = k->level[k->depth];
+        b->book_depth = k->depth;
+        b->book_n0 = k->n0;
+    }
+    return 0;
+}
+
+void bounce_book_release(bgs_batch* b) {
+    if (!b->book_owner) return;
+    std::lock_guard<std::mutex> lock(g_books_mu);
+    Book* k = static_cast<Book*>(b->book_owner);
+    b->book_owner = nullptr;
+    b->book_links = nullptr;
+    b->book_table = nullptr;
+    b->book_depth = 0;
+    if (--k->users == 0) {
+        for (size_t i = 0; i < g_books.size(); ++i)
+            if (g_books[i] == k) g_books.erase(g_books.begin() + (long)i);
+        free_book(k);
+    }
 }
 
 void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out) {

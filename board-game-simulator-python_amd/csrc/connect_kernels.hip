@@ -1055,8 +1055,8 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
 // sixteen plies, a whole game of a board of at most 48 cells needs three -- what the opening stage computed for its own
 // three blocks before -- and the opening parks the words of the blocks still to come (block OPEN_BLOCKS .. the last one a
 // full board can reach: eight for Connect4) next to the board.  A lane that takes a board takes its words into registers;
-// a block consumes the first and moves the others down one (unconditional moves: lanes sit in different blocks).
-//   222 -> 186 VALU a block (42 of philox out, 3 sub-draw multiplies and 7 moves in), the opening as before.
+// lanes sit in different blocks of their games, so the words go to a lane-private column of LDS and a block reads one.
+//   222 -> ~180 VALU a block (42 of philox and 8 of per-ply winner / step bookkeeping out, 3 sub-draw multiplies in).
 // The pool is a ring of 64 slots (128 before: with the words a slot is 52 bytes, and six workgroups a CU -- three launches
 // in flight -- leave each wave 6 KB of LDS): when it runs dry the lanes that need a board first take what is left, THEN
 // all 64 lanes open the chunk's next 64 games over the emptied slots, then the remaining needy lanes take from those.
@@ -1087,6 +1087,11 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
     using Pool = OpenedPool<OW::QUADS>;
     extern __shared__ uint32_t code_lds[];  // one outcome BYTE per game of the wave's chunk: games_per_wave / 4 dwords per wave
     __shared__ Pool pools[BGS_BLOCK / BGS_WAVE];
+    // the words of a lane's blocks to come, [word][lane] per wave (the bank is the lane: no conflicts whatever word a lane
+    // reads): a lane that takes a board copies them here, a block reads ONE of them -- its address moves on by a row.  (In
+    // registers the eight words had to move down one every block: 8 moves; this is an add, a min and an LDS read that is
+    // issued a block ahead of its use.)
+    __shared__ uint32_t lane_words[BGS_BLOCK / BGS_WAVE][NWORDS][BGS_WAVE];
     constexpr uint32_t ONES = 0x11111111u;
     const uint32_t top = (uint32_t)g.h() + 7u;
     const uint32_t columns = g.w() >= 8 ? ONES : (ONES & ((1u << (4 * g.w())) - 1u));
@@ -1106,10 +1111,11 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
     Pool& pool = pools[threadIdx.x >> 6];
 
     uint64_t p[2] = {0, 0};
-    uint32_t hts = 0, live = 0, st = 0, game = 0, stepped = 0;
-    uint32_t w[NWORDS];    // w[0]: the word of this lane's next block
-#pragma unroll
-    for (int k = 0; k < NWORDS; ++k) w[k] = 0;
+    uint32_t hts = 0, live = 0, game = 0, stepped = 0;
+    bool anywon = false;   // somebody has a run on this lane's board (only read when the game has just ended)
+    uint32_t wnext = 0;    // the word of this lane's next block (read from lane_words a block ahead)
+    uint32_t* const my_words = &lane_words[threadIdx.x >> 6][0][lane];
+    uint32_t wrow = 0;     // the row of lane_words the block after next reads
 
     if (avail == 0u) return;
     // The outcome of game i of the chunk is byte i of the wave's LDS slice (a plain byte store where the game ends, no
@@ -1118,9 +1124,12 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
     for (uint32_t i = lane; i < ((avail + 3u) >> 2); i += BGS_WAVE) reinterpret_cast<uint32_t*>(outcome)[i] = 0u;
     __builtin_amdgcn_wave_barrier();
 
-    // one full ply of sub-step J on (q, h4, op, alive, won_by); the body of K2a's block
+    // one full ply of sub-step J on (q, h4, op, alive, won_any); the body of K2a's block
+    // Neither the winner nor the env-steps are tracked ply by ply: a game's plies are the stones on its board, and when it
+    // has ended with a run the winner is whoever placed the last stone -- both read off the planes once, where the game ends
+    // (round 5: 8 VALU a block less than a per-ply winner select and step count).
     auto full_ply = [&](auto j_tag, uint32_t draw, uint64_t (&q)[2], uint32_t& h4, uint32_t& op, uint32_t& alive,
-                        uint32_t& won_by) {
+                        bool& won_any) {
         constexpr uint32_t J = decltype(j_tag)::value;
         const uint32_t cnt = (uint32_t)__popc(op);
         const uint32_t idx = sample_index(draw, cnt);
@@ -1155,9 +1164,14 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
             b.w[0] = mine;
             won = has_run(g, b);
         }
-        stepped -= act;
-        won_by = won ? (J & 1u) + 1u : won_by;
+        won_any = won_any || won;   // (lane masks: scalar ORs)
         alive = (won || op == 0u) ? 0u : alive;
+    };
+    // the outcome of a board that has just ended, and its plies into the step count
+    auto outcome_of = [&](const uint64_t (&q)[2], bool won_any) -> uint32_t {
+        const uint32_t stones = (uint32_t)__popcll(q[0]) + (uint32_t)__popcll(q[1]);
+        stepped += stones;
+        return won_any ? ((stones - 1u) & 1u) + 1u : (uint32_t)BGS_ST_DRAW;   // no cap: a board that stopped without a run is full
     };
     // one opening ply: every column is open and nobody can win yet
     auto cheap_ply = [&](uint32_t j, uint32_t draw, uint64_t (&q)[2], uint32_t& h4) {
@@ -1172,18 +1186,18 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
     // and reward follow from the codes); the lane's words move down one
     auto play_block = [&]() {
         const uint32_t was_live = live;
-        const uint32_t word = w[0];
-#pragma unroll
-        for (int k = 0; k + 1 < NWORDS; ++k) w[k] = w[k + 1];
+        const uint32_t word = wnext;
+        wnext = my_words[wrow * BGS_WAVE];   // (used by the NEXT block: the read has a whole block to arrive)
+        wrow = wrow + 1u < (uint32_t)NWORDS - 1u ? wrow + 1u : (uint32_t)NWORDS - 1u;   // (a finished lane idles on the last row)
         uint32_t open = (hts >> 3) & ONES;
-        full_ply(std::integral_constant<uint32_t, 0>{}, sub_draw<0>(word), p, hts, open, live, st);
-        full_ply(std::integral_constant<uint32_t, 1>{}, sub_draw<1>(word), p, hts, open, live, st);
-        full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(word), p, hts, open, live, st);
-        full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(word), p, hts, open, live, st);
+        full_ply(std::integral_constant<uint32_t, 0>{}, sub_draw<0>(word), p, hts, open, live, anywon);
+        full_ply(std::integral_constant<uint32_t, 1>{}, sub_draw<1>(word), p, hts, open, live, anywon);
+        full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(word), p, hts, open, live, anywon);
+        full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(word), p, hts, open, live, anywon);
         if (was_live != 0 && live == 0) {
             *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane0) + (game * 8u)) = p[0];
             *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane1) + (game * 8u)) = p[1];
-            outcome[game] = (uint8_t)(st ? st : BGS_ST_DRAW);  // no cap: a board that stopped without a winner is full
+            outcome[game] = (uint8_t)outcome_of(p, anywon);
         }
     };
     // an idle lane takes game `which` of the chunk out of the pool: board, column nibbles, the words of its blocks to come
@@ -1196,9 +1210,13 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
 #pragma unroll
         for (int k = 0; k < OW::QUADS; ++k) {
             const uint4 v = pool.words[k][slot];
-            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+            if (k == 0) wnext = v.x; else my_words[(4 * k) * BGS_WAVE] = v.x;
+            my_words[(4 * k + 1) * BGS_WAVE] = v.y;
+            my_words[(4 * k + 2) * BGS_WAVE] = v.z;
+            my_words[(4 * k + 3) * BGS_WAVE] = v.w;
         }
-        st = 0;
+        wrow = 1u;
+        anywon = false;
         live = hts != 0u ? ~0u : 0u;  // (a dead slot: the opening stage has stored that game)
     };
     // all 64 lanes open the chunk's next 64 games (blocks 0 .. OPEN_BLOCKS - 1 in lock step) and park them with their words
@@ -1206,7 +1224,8 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
         const uint32_t og = opened + lane;
         const uint64_t id = first_game + (uint64_t)(begin + og);
         uint64_t q[2] = {0, 0};
-        uint32_t h4 = top * columns, alive = ~0u, won_by = 0, op = columns;
+        uint32_t h4 = top * columns, alive = ~0u, op = columns;
+        bool won_any = false;
         uint32_t words[12];   // the words of blocks 0 .. 11: three philox calls (fewer when the board cannot last that long)
         {
             const Philox4 d = philox4x32_10(seed, id, 0u);
@@ -1225,31 +1244,25 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
         cheap_ply(1u, sub_draw<1>(words[0]), q, h4);
         cheap_ply(2u, sub_draw<2>(words[0]), q, h4);
         cheap_ply(3u, sub_draw<3>(words[0]), q, h4);
-        const uint32_t before = stepped;
         if (OPEN_BLOCKS >= 2) {
             cheap_ply(0u, sub_draw<0>(words[1]), q, h4);
             cheap_ply(1u, sub_draw<1>(words[1]), q, h4);
             op = (h4 >> 3) & ONES;
-            full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(words[1]), q, h4, op, alive, won_by);
-            full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(words[1]), q, h4, op, alive, won_by);
+            full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(words[1]), q, h4, op, alive, won_any);
+            full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(words[1]), q, h4, op, alive, won_any);
         }
 #pragma unroll
         for (int ob = 2; ob < OPEN_BLOCKS; ++ob) {  // further blocks in lock step
-            full_ply(std::integral_constant<uint32_t, 0>{}, sub_draw<0>(words[ob]), q, h4, op, alive, won_by);
-            full_ply(std::integral_constant<uint32_t, 1>{}, sub_draw<1>(words[ob]), q, h4, op, alive, won_by);
-            full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(words[ob]), q, h4, op, alive, won_by);
-            full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(words[ob]), q, h4, op, alive, won_by);
+            full_ply(std::integral_constant<uint32_t, 0>{}, sub_draw<0>(words[ob]), q, h4, op, alive, won_any);
+            full_ply(std::integral_constant<uint32_t, 1>{}, sub_draw<1>(words[ob]), q, h4, op, alive, won_any);
+            full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(words[ob]), q, h4, op, alive, won_any);
+            full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(words[ob]), q, h4, op, alive, won_any);
         }
-        if (og < avail) {
-            stepped += OPEN_BLOCKS >= 2 ? 6u : 4u;
-            if (OPEN_BLOCKS >= 2 && alive == 0) {  // ended inside the opening: a win, or a small board is full
-                plane0[og] = q[0];
-                plane1[og] = q[1];
-                outcome[og] = (uint8_t)(won_by ? won_by : BGS_ST_DRAW);
-            }
-        } else {
-            stepped = before;  // a lane past the end of the chunk played for nobody
-        }
+        if (OPEN_BLOCKS >= 2 && og < avail && alive == 0) {  // ended inside the opening: a win, or a small board is full
+            plane0[og] = q[0];
+            plane1[og] = q[1];
+            outcome[og] = (uint8_t)outcome_of(q, won_any);
+        }   // (a lane past the end of the chunk played for nobody: nothing of it is stored or counted)
         const uint32_t slot = og & (Pool::SLOTS - 1u);
         pool.plane[0][slot] = q[0];
         pool.plane[1][slot] = q[1];

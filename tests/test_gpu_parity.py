@@ -650,6 +650,51 @@ def test_bounce_piece_list_rollout(batch_mod, name):
             os.environ["BGS_BOUNCE_GROUP"] = old
 
 
+@pytest.mark.parametrize("depth", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("name", list(PIECE_LIST_GRIDS))
+def test_bounce_opening_book(batch_mod, monkeypatch, name, depth):
+    """Round 5: K3p's lanes do not search the first plies of a game from the start position -- they walk the start
+    position's OPENING BOOK (every path of `depth` plies, enumerated once per start position with K3p's own search) with the
+    game's own draws and start `depth` plies in.  Boards, plies, rewards and step counts must be the oracle's -- on grids of 2
+    to 16 pieces (values up to 15, a blocked start: no book; paths that END inside the book: a piece in the goal row after two
+    plies on the small grids), for every depth, under ply caps below, at and above the depth, and resumed from memory."""
+    grid = PIECE_LIST_GRIDS[name]
+    monkeypatch.setenv("BGS_BOUNCE_GROUP", "1")
+    monkeypatch.setenv("BGS_BOUNCE_BOOK", depth)   # (forces the book for a batch of any size)
+    d = int(depth)
+    for n, cap in ((6000, 4096), (777, d), (500, max(1, d - 1)), (333, d + 1)):
+        dev = batch_mod.BounceBatch(grid, n)
+        orc = oracle.BounceOracle(grid, n)
+        dev.set_first_game(9 << 32)
+        dev.rollout(SEED + 5, max_plies=cap, from_initial=True)
+        total = orc.rollout(SEED + 5, first_game=9 << 32, max_plies=cap)
+        assert_same(dev, orc, f"{name} depth={depth} n={n} cap={cap}")
+        assert dev.steps == total == int(orc.plies.sum())
+        dev.rollout(SEED + 5, max_plies=4096)
+        orc.rollout(SEED + 5, first_game=9 << 32, max_plies=4096)
+        assert_same(dev, orc, f"{name} depth={depth} n={n} resumed")
+        dev.close()
+
+
+def test_bounce_opening_book_is_shared_and_released(batch_mod, monkeypatch):
+    """The book belongs to the start position, not to the batch: batches of one start position on one device share it (the
+    second create does not build), a different start position gets its own, and everything still plays the oracle's games
+    after the first batch is gone."""
+    monkeypatch.setenv("BGS_BOUNCE_GROUP", "1")
+    monkeypatch.setenv("BGS_BOUNCE_BOOK", "3")
+    a = batch_mod.BounceBatch(DEFAULT_BOUNCE, 4000)
+    b2 = batch_mod.BounceBatch(DEFAULT_BOUNCE, 2500)
+    c = batch_mod.BounceBatch(PIECE_LIST_GRIDS["nine"], 3000)
+    a.close()
+    for dev, grid, n in ((b2, DEFAULT_BOUNCE, 2500), (c, PIECE_LIST_GRIDS["nine"], 3000)):
+        orc = oracle.BounceOracle(grid, n)
+        dev.rollout(SEED + 8, max_plies=4096, from_initial=True)
+        total = orc.rollout(SEED + 8, max_plies=4096)
+        assert_same(dev, orc, "shared book")
+        assert dev.steps == total
+        dev.close()
+
+
 @pytest.mark.parametrize("name", list(PIECE_LIST_GRIDS))
 def test_bounce_one_board_per_wave_pass(batch_mod, name):
     """K3w, the last pass of the automatic plan (one board per wave, a piece per lane: the few games that run for thousands

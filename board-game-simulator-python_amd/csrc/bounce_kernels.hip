@@ -1253,6 +1253,12 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
                         uint32_t book_depth, uint32_t book_n0) {
     __shared__ ParkedPieces<PMAX, BLOCK> parked;
     __shared__ uint32_t book_lds[kBookLdsLinks];   // the opening book's links of levels 1 and 2 (4.25 KB)
+    // ... and the boards of the wave's current chunk as the book hands them out: a chunk (at most 64 games) is walked through
+    // the book by ALL lanes at once when it is drawn from the queue -- one philox call and one walk per lane, every lane busy
+    // -- and parked here, a 64-byte line a game; a lane that takes a game reads its line.  (Walked where the lane takes the
+    // game, the walk ran in almost every iteration -- some lane of 64 always finishes -- for two or three lanes: ~100 VALU
+    // an iteration, 4 % of a ply.)
+    __shared__ uint4 opened_lds[BLOCK / BGS_WAVE][4][BGS_WAVE];
     if (book_depth >= 2u)
         for (uint32_t i = threadIdx.x; i < kBookLdsLinks; i += BLOCK) book_lds[i] = book_links[i];
     Lands<PMAX> lands;   // (registers; valid from a ply's search to its move)
@@ -1336,31 +1342,42 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
             taken = 0;
             avail = begin < total ? (total - begin < chunk ? total - begin : chunk) : 0u;
             dry = avail == 0u;
+            if (book_depth && avail) {
+                // the opening book (see above), for the whole chunk in lock step: game begin + lane's first plies are a walk
+                // along the book's links with the game's own draws -- the words of philox block 0 -- ending on a 64-byte line
+                const Philox4 d = philox4x32_10(seed, first_game + (uint64_t)(begin + (lane < avail ? lane : 0u)), 0u);
+                uint32_t at = sample_index(d.v[0], book_n0);
+                if (book_depth >= 2u) {
+                    const uint32_t e = book_lds[at];
+                    at = (e >> kBookLinkBits) + sample_index(d.v[1], e & kBookLinkMax);
+                }
+                if (book_depth >= 3u) {
+                    const uint32_t e = book_lds[kBookCap1 + at];
+                    at = (e >> kBookLinkBits) + sample_index(d.v[2], e & kBookLinkMax);
+                }
+                if (book_depth >= 4u) {
+                    const uint32_t e = book_links[kBookCap1 + kBookCap2 + at];
+                    at = (e >> kBookLinkBits) + sample_index(d.v[3], e & kBookLinkMax);
+                }
+                const uint4* line = reinterpret_cast<const uint4*>(book_table + at);
+                const uint4 q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3];
+                opened_lds[w][0][lane] = q0;
+                opened_lds[w][1][lane] = q1;
+                opened_lds[w][2][lane] = q2;
+                opened_lds[w][3][lane] = q3;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         if (need && taken < avail) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (!has && taken + rank < avail) {
                 game = begin + taken + rank;
                 if (book_depth) {
-                    // the opening book (see above): the game's first plies are a walk along the book's links with the game's
-                    // own draws -- the words of philox block 0 -- and the lane starts on the board the walk ends on
-                    blk = philox4x32_10(seed, first_game + (uint64_t)game, 0u);
-                    have_block = true;
-                    uint32_t at = sample_index(blk.v[0], book_n0);
-                    if (book_depth >= 2u) {
-                        const uint32_t e = book_lds[at];
-                        at = (e >> kBookLinkBits) + sample_index(blk.v[1], e & kBookLinkMax);
-                    }
-                    if (book_depth >= 3u) {
-                        const uint32_t e = book_lds[kBookCap1 + at];
-                        at = (e >> kBookLinkBits) + sample_index(blk.v[2], e & kBookLinkMax);
-                    }
-                    if (book_depth >= 4u) {
-                        const uint32_t e = book_links[kBookCap1 + kBookCap2 + at];
-                        at = (e >> kBookLinkBits) + sample_index(blk.v[3], e & kBookLinkMax);
-                    }
-                    const uint4* line = reinterpret_cast<const uint4*>(book_table + at);
-                    const uint4 q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3];
+                    const uint32_t slot = taken + rank;   // (a chunk is at most 64 games: bounce_rollout)
+                    have_block = false;
+                    const uint4 q0 = opened_lds[w][0][slot], q1 = opened_lds[w][1][slot], q2 = opened_lds[w][2][slot],
+                                q3 = opened_lds[w][3][slot];
                     const uint32_t where[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
                     for (int j = 0; j < PMAX / 4; ++j) b.pos[j] = where[j];
@@ -2389,7 +2406,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         constexpr int PMAX = decltype(pmax_tag)::value;
         constexpr int BLOCK = decltype(block_tag)::value;
         const size_t tile = 0;  // (the landing masks live in registers; LDS only holds the parked boards)
-        const uint32_t chunk = (uint32_t)b->bounce_flat_chunk;
+        const uint32_t chunk0 = (uint32_t)b->bounce_flat_chunk;
         // Every ply costs a wave the same whatever the number of its lanes that still hold a game, so what counts is how
         // full the waves stay: few, long-lived waves (boards_per_wave boards each, drawn from the queue) spend most
         // of their life refilling and little of it draining -- when many launches share the chip.  A launch that is
@@ -2412,6 +2429,8 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         const unsigned groups = (unsigned)((flat_waves + per_block - 1) / per_block);
         // the opening book of the start position (bounce_book_acquire): games start `depth` plies in -- unless the cap is shorter
         const uint32_t book_depth = b->book_table && b->book_depth > 0 && cap >= (uint32_t)b->book_depth ? (uint32_t)b->book_depth : 0u;
+        // (with the book a chunk is walked by the 64 lanes of the wave that draws it: a whole wave's worth, never more)
+        const uint32_t chunk = book_depth ? 64u : chunk0;
         // the device-wide pool of parked boards: counters zeroed per launch (one small fill on the stream)
         uint32_t* pool = b->bounce_pool && b->bounce_pieces_park > 0 && groups >= 2 && groups <= (unsigned)BGS_BOUNCE_POOL_GROUPS ? b->d_pool : nullptr;
         if (pool) (void)hipMemsetAsync(pool, 0, sizeof(uint32_t) * (4 + 2 * (size_t)groups), b->stream);

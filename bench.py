@@ -77,7 +77,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PCIE_PEAK_GBS = 63.0         # PCIe Gen5 x16 spec (MI355X_MICROARCH.md)
 VALU_PEAK_SIMD32 = 256 * 4 * 2.4e9 / 2 / 1e9  # G wave64-instr/s: 256 CUs x 4 SIMD-32, 2 cycles per wave64 instruction
 # settings that change what a launch executes: counters taken under the defaults are not quoted when one is set
-LAUNCH_OVERRIDES = ("BGS_ROLLOUT_OPENING", "BGS_ROLLOUT_CHUNK", "BGS_ROLLOUT_GENERIC", "BGS_ROLLOUT_NO_LDS", "BGS_FORCE_GENERIC")
+LAUNCH_OVERRIDES = ("rollout_opening", "rollout_chunk", "rollout_generic", "rollout_no_lds", "force_generic")   # names in BGS_EXPERIMENT
 BOUNCE_GRID = [[0] * 6, [1, 2, 3, 3, 2, 1]] + [[0] * 6] * 5 + [[1, 2, 3, 3, 2, 1], [0] * 6]  # textual/bounce.py:66-78
 OTHER_CONFIGS = {
     # name: (BASELINE.json config, boards, batches in flight, max plies, SURVEY 8d bytes per env-step, counters file, kernel)
@@ -285,9 +285,10 @@ def running_ids():
 def committed_counters(ids, stem, kernel_substring=None, profiles_dir=None):
     """Per-launch PMC figures (profiles/r*_<stem>.json, newest round first), valid only for the kernel unit they were
     measured on (`ids` = running_ids()) and for default launch settings."""
-    overrides = [k for k in LAUNCH_OVERRIDES if os.environ.get(k)]
+    experiment = {part.partition("=")[0].strip() for part in os.environ.get("BGS_EXPERIMENT", "").split(";")}
+    overrides = [k for k in LAUNCH_OVERRIDES if k in experiment]
     if overrides:
-        return None, f"launch overrides set ({', '.join(overrides)}): the committed counters describe the default launch"
+        return None, f"launch overrides set (BGS_EXPERIMENT: {', '.join(overrides)}): the committed counters describe the default launch"
     unit = STEM_UNIT[stem]
     files = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), f"r[0-9][0-9]_{stem}.json")), reverse=True)
     seen = []

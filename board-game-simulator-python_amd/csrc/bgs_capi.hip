@@ -28,6 +28,28 @@ thread_local char g_error[512] = "";
 }
 
 namespace bgs {
+const char* experiment(const char* name) {
+    const char* all = getenv("BGS_EXPERIMENT");
+    if (!all || !name) return nullptr;
+    thread_local std::string value;
+    const size_t len = strlen(name);
+    for (const char* p = all; *p;) {
+        const char* end = strchr(p, ';');
+        if (!end) end = p + strlen(p);
+        while (p < end && *p == ' ') ++p;
+        if ((size_t)(end - p) > len && strncmp(p, name, len) == 0 && p[len] == '=') {
+            value.assign(p + len + 1, end);
+            return value.c_str();
+        }
+        if ((size_t)(end - p) == len && strncmp(p, name, len) == 0) {   // a bare name: "on"
+            value = "1";
+            return value.c_str();
+        }
+        p = *end ? end + 1 : end;
+    }
+    return nullptr;
+}
+
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -90,7 +112,7 @@ int check_device(int device) {
     return BGS_OK;
 }
 
-bool force_generic() { return getenv("BGS_FORCE_GENERIC") != nullptr; }
+bool force_generic() { return bgs::experiment("force_generic") != nullptr; }
 
 // *generic = 1: outside the bit-packed representation's limits (or BGS_FORCE_GENERIC): served by generic_kernels.hip
 int connect_geom(int h, int w, int k, ConnectGeom* cg, int* generic) {
@@ -276,14 +298,14 @@ int device_facts(bgs_batch* b) {
         if (v >= 1 && v <= 8) b->rollout_wps = v;
     }
     b->rollout_chunk = 0;
-    if (const char* e = getenv("BGS_ROLLOUT_CHUNK")) {
+    if (const char* e = bgs::experiment("rollout_chunk")) {
         const int v = atoi(e);
         if (v >= 64 && v <= (1 << 20)) b->rollout_chunk = v;
     }
-    b->rollout_generic = getenv("BGS_ROLLOUT_GENERIC") != nullptr;
-    b->rollout_no_lds = getenv("BGS_ROLLOUT_NO_LDS") != nullptr;
+    b->rollout_generic = bgs::experiment("rollout_generic") != nullptr;
+    b->rollout_no_lds = bgs::experiment("rollout_no_lds") != nullptr;
     b->rollout_opening = kRolloutOpeningBlocks;
-    if (const char* e = getenv("BGS_ROLLOUT_OPENING")) {
+    if (const char* e = bgs::experiment("rollout_opening")) {
         const int v = atoi(e);
         if (v >= 0 && v <= 4) b->rollout_opening = v;
     }
@@ -291,41 +313,41 @@ int device_facts(bgs_batch* b) {
     // batches, 8 lanes per board (shortest ply latency) for small ones; BGS_BOUNCE_GROUP = 1 / 8 overrides
     b->bounce_group = b->n >= 32768 ? 1 : 8;
     b->bounce_group_auto = 1;
-    if (const char* env = getenv("BGS_BOUNCE_GROUP")) {
+    if (const char* env = bgs::experiment("bounce_group")) {
         b->bounce_group = atoi(env) == 1 ? 1 : 8;
         b->bounce_group_auto = 0;
     }
     b->bounce_flat = 1;
-    if (const char* env = getenv("BGS_BOUNCE_FLAT")) b->bounce_flat = atoi(env) != 0;
+    if (const char* env = bgs::experiment("bounce_flat")) b->bounce_flat = atoi(env) != 0;
     b->bounce_pieces = 1;
-    if (const char* env = getenv("BGS_BOUNCE_PIECES")) b->bounce_pieces = atoi(env) != 0;
+    if (const char* env = bgs::experiment("bounce_pieces")) b->bounce_pieces = atoi(env) != 0;
     b->bounce_block = 256;
-    if (const char* env = getenv("BGS_BOUNCE_BLOCK")) b->bounce_block = atoi(env);
+    if (const char* env = bgs::experiment("bounce_block")) b->bounce_block = atoi(env);
     b->bounce_pool = 1;
-    if (const char* env = getenv("BGS_BOUNCE_POOL")) b->bounce_pool = atoi(env) != 0;
+    if (const char* env = bgs::experiment("bounce_pool")) b->bounce_pool = atoi(env) != 0;
     b->bounce_flat_chunk = 32;
-    if (const char* env = getenv("BGS_BOUNCE_CHUNK")) {
+    if (const char* env = bgs::experiment("bounce_chunk")) {
         const int v = atoi(env);
         if (v >= 1 && v <= 4096) b->bounce_flat_chunk = v;
     }
     b->bounce_park = kBouncePark;
-    if (const char* env = getenv("BGS_BOUNCE_PARK")) {
+    if (const char* env = bgs::experiment("bounce_park")) {
         const int v = atoi(env);
         if (v >= 0 && v <= 32) b->bounce_park = v;
     }
     b->launches_in_flight = 1;
     b->bounce_flat_waves = 0;
-    b->bounce_pieces_park = getenv("BGS_BOUNCE_PARK") ? b->bounce_park : kBouncePiecesPark;
-    if (const char* env = getenv("BGS_BOUNCE_PIECES_PARK")) {
+    b->bounce_pieces_park = bgs::experiment("bounce_park") ? b->bounce_park : kBouncePiecesPark;
+    if (const char* env = bgs::experiment("bounce_pieces_park")) {
         const int v = atoi(env);
         if (v >= 0 && v <= 63) b->bounce_pieces_park = v;
     }
-    if (const char* env = getenv("BGS_BOUNCE_FLAT_WAVES")) {
+    if (const char* env = bgs::experiment("bounce_flat_waves")) {
         const int v = atoi(env);
         if (v >= 1 && v <= (1 << 16)) b->bounce_flat_waves = v;
     }
     b->bounce_flat_wps = 2;
-    if (const char* env = getenv("BGS_BOUNCE_FLAT_WPS")) {
+    if (const char* env = bgs::experiment("bounce_flat_wps")) {
         const int v = atoi(env);
         if (v >= 1 && v <= 8) b->bounce_flat_wps = v;
     }
@@ -335,11 +357,11 @@ int device_facts(bgs_batch* b) {
         // default "auto": one launch, except for large from-initial batches on the piece-list kernel, whose handful of
         // very long games (a random Bounce game can go on for ever: it stops at max_plies) is finished by a second pass
         // with 8 lanes per board -- see bounce_rollout()
-        const char* plan = getenv("BGS_BOUNCE_PLAN");
+        const char* plan = bgs::experiment("bounce_plan");
         if (!plan) plan = "auto";
-        const char* wave_pass = getenv("BGS_BOUNCE_WAVE_PASS");
+        const char* wave_pass = bgs::experiment("bounce_wave_pass");
         b->bounce_wave_pass = !(wave_pass && wave_pass[0] == '0');
-        const char* epoch_limit = getenv("BGS_BOUNCE_EPOCH_LIMIT");
+        const char* epoch_limit = bgs::experiment("bounce_epoch_limit");
         b->bounce_epoch_limit = epoch_limit ? atoi(epoch_limit) : 0;
         b->bounce_passes = 0;
         b->bounce_plan_auto = strcmp(plan, "auto") == 0;
@@ -541,7 +563,7 @@ std::unordered_map<const bgs_batch*, SmallTransition> g_small;
 
 int transition_mode() {
     static const int mode = [] {
-        const char* e = getenv("BGS_TRANSITION");
+        const char* e = bgs::experiment("transition");
         if (e && !strcmp(e, "staged")) return 0;
         if (e && !strcmp(e, "mapped")) return 1;
         if (e && !strcmp(e, "graph")) return 2;
@@ -1237,7 +1259,7 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
     // earlier than the stream's completion signal comes back (BGS_TRANSITION_SPIN=0: wait for the stream as before).  The
     // kernel that wrote the ticket has nothing left to do, so the next call may reuse the blocks; the stream itself is
     // synchronised now and then, and whenever the ticket does not show within 2 ms (a failed launch reports itself there).
-    static const bool spin_wanted = [] { const char* e = getenv("BGS_TRANSITION_SPIN"); return !(e && e[0] == '0'); }();
+    static const bool spin_wanted = [] { const char* e = bgs::experiment("transition_spin"); return !(e && e[0] == '0'); }();
     const bool spin = mode == 3 && spin_wanted && !b->generic;
     bool fused = false;
     auto launch_all = [&]() -> int {

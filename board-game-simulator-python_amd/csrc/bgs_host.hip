@@ -90,7 +90,7 @@ __attribute__((target("avx2"))) int64_t expand_avx2(const uint8_t* src, int64_t 
 }
 
 const bool g_have_avx2 = __builtin_cpu_supports("avx2");
-const bool g_stream_stores = getenv("BGS_NO_STREAM_STORES") == nullptr;
+const bool g_stream_stores = bgs::experiment("no_stream_stores") == nullptr;
 
 void expand_range(const uint8_t* packed, int64_t first, int64_t count, int8_t* reward) {
     // whole code bytes: AVX2 where the CPU has it, the 256-entry table otherwise and for the last few bytes; a ragged
@@ -202,7 +202,7 @@ void expand_cells_portable(const uint64_t* wire, int64_t n, const CellFormat& f,
     }
 }
 
-const bool g_have_avx512bw = __builtin_cpu_supports("avx512bw") && getenv("BGS_NO_AVX512") == nullptr;
+const bool g_have_avx512bw = __builtin_cpu_supports("avx512bw") && bgs::experiment("no_avx512") == nullptr;
 
 void expand_cells(const void* wire, int64_t n, const CellFormat& f, int64_t first, int64_t count, int8_t* out) {
     if (f.sets == 0) {  // generic batches keep the reference layout on the device: nothing to expand
@@ -280,7 +280,7 @@ namespace {
 // BGS_SINK_TRACE=1: the sink's threads report when they saw a job's codes, expanded their share and completed it, in
 // microseconds of CLOCK_MONOTONIC (what time.perf_counter() reads too) -- for tools/short_run_timeline.py
 inline bool sink_trace_on() {
-    static const bool on = getenv("BGS_SINK_TRACE") != nullptr;
+    static const bool on = bgs::experiment("sink_trace") != nullptr;
     return on;
 }
 inline double mono_us() {
@@ -420,7 +420,7 @@ struct bgs_reward_sink {
                 const int64_t blocks = (job.n_games + 63) / 64;
                 const int64_t g0 = blocks * share / expanders * 64;
                 const int64_t g1 = share + 1 == expanders ? job.n_games : blocks * (share + 1) / expanders * 64;
-                static const bool skip = getenv("BGS_GRID_NO_EXPAND") != nullptr;  // (measurement knob: the copy alone)
+                static const bool skip = bgs::experiment("grid_no_expand") != nullptr;  // (measurement knob: the copy alone)
                 if (g1 > g0 && !skip) expand_cells(pinned[slot], job.n_games, cells, g0, g1 - g0, job.host_reward);
             } else if (ok) {
                 // shares are multiples of 4 games (one code byte), so threads never touch the same output word
@@ -662,12 +662,12 @@ static int make_sink(int device, int64_t max_games, int slots, int threads, size
     s->slots = slots;
     s->threads = threads;
     s->jobs.resize(slots);
-    if (const char* env = getenv("BGS_SINK_POLL")) s->poll = atoi(env) != 0;
-    if (const char* env = getenv("BGS_SINK_WAIT_SPIN_US")) {
+    if (const char* env = bgs::experiment("sink_poll")) s->poll = atoi(env) != 0;
+    if (const char* env = bgs::experiment("sink_wait_spin_us")) {
         const int v = atoi(env);
         if (v >= 0 && v <= 1000000) s->wait_spin_us = v;
     }
-    if (const char* env = getenv("BGS_SINK_SPIN_US")) {
+    if (const char* env = bgs::experiment("sink_spin_us")) {
         const int v = atoi(env);
         if (v >= 0 && v <= 1000000) s->spin_us = v;
     }
@@ -750,7 +750,7 @@ static hipError_t enqueue_grids(bgs_reward_sink* s, bgs_batch* b, int slot) {
     if (!b->generic && b->game == BGS_GAME_CONNECT) {
         // The conversion kernel stores straight into the page-locked slot: coalesced 512-byte runs over PCIe, 51 GB/s
         // measured at 2^20 boards (a copy engine behind a staging buffer, BGS_GRID_COPY=1: 36 GB/s)
-        static const bool direct = getenv("BGS_GRID_COPY") == nullptr;
+        static const bool direct = bgs::experiment("grid_copy") == nullptr;
         if (direct) {
             bgs::connect_cell_planes(b, reinterpret_cast<uint64_t*>(s->mapped[slot]));
             return hipGetLastError();

@@ -82,6 +82,12 @@ struct bgs_batch {
 
 namespace bgs {
 
+// The A/B switches and test hooks of the library -- kernels no automatic plan selects, fault injection, measurement knobs --
+// live behind ONE environment variable: BGS_EXPERIMENT="name=value;name=value" (names as in tools/README.md; a value may
+// hold commas and colons).  Returns the value of `name` (valid until the calling thread's next call) or NULL.  What a user
+// of the library may want to set has a variable of its own and is listed in INTEGRATION.md section G.
+const char* experiment(const char* name);
+
 // ---- Connect (connect_kernels.hip) ----
 void connect_reset(const bgs_batch* b);
 void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count);  // count plies per board

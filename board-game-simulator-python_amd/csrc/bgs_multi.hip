@@ -606,7 +606,7 @@ int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_
     }
     if (he != hipSuccess) rc = fail(BGS_ERR_RUNTIME, "gather allocation failed: %s", hipGetErrorString(he));
     if (rc == BGS_OK && rank == 0) rc = bgs_sink_create(device, n_per_rank * world, slots, host_threads, &g->sink);
-    static const bool comm_alone = [] { const char* e = getenv("BGS_GATHER_COMM_ALONE"); return !(e && e[0] == '0'); }();
+    static const bool comm_alone = [] { const char* e = bgs::experiment("gather_comm_alone"); return !(e && e[0] == '0'); }();
     if (rc == BGS_OK && (world > 1 || comm_alone)) {
         // collective: every rank of the world is inside this call at the same time
         NcclUniqueId u;
@@ -666,8 +666,8 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
     NEED(max_plies >= 0, "max_plies must be >= 0");
     // fault injection for the tests (BGS_GATHER_INJECT_FAILURE=<step>): that step "cannot be enqueued" after its ticket
     // was claimed -- the path a device error would take
-    static const long long inject = getenv("BGS_GATHER_INJECT_FAILURE") ? atoll(getenv("BGS_GATHER_INJECT_FAILURE")) : -1;
-    static const int inject_rank = getenv("BGS_GATHER_INJECT_RANK") ? atoi(getenv("BGS_GATHER_INJECT_RANK")) : -1;  // -1: every rank
+    static const long long inject = bgs::experiment("gather_inject_failure") ? atoll(bgs::experiment("gather_inject_failure")) : -1;
+    static const int inject_rank = bgs::experiment("gather_inject_rank") ? atoi(bgs::experiment("gather_inject_rank")) : -1;  // -1: every rank
     if (g->world == 1) return bgs_sink_rollout(g->sink, b, seed, max_plies, flags, host_reward, ticket);
     HIP_TRY(hipSetDevice(g->device));
     int64_t t;

@@ -250,7 +250,7 @@ int bgs_pipeline_drain(bgs_pipeline* p) {
     // every stream is synchronised by its helper, starting NOW (see StreamSyncer); BGS_DRAIN_SERIAL_SYNC=1: by this
     // thread, one after the other, once the deliveries are in (the A/B of round 3, r3_drain.sh in the git history)
     const size_t depth = p->batches.size();
-    static const bool serial = getenv("BGS_DRAIN_SERIAL_SYNC") != nullptr;
+    static const bool serial = bgs::experiment("drain_serial_sync") != nullptr;
     const bool helpers = depth > 1 && !serial;
     if (helpers) {
         while (p->syncers.size() < depth) {

@@ -30,7 +30,8 @@ struct BounceGeom {
     uint64_t piece_idx[4];   // index planes of the start position: bit c of plane p = bit p of the index of the piece on cell c
 };
 
-constexpr int kBouncePiecesPark = 40;       // K3p with the device-wide pool: 32 / 40 / 48 / 56 / 63 read 11.8 / 12.2 / 11.9 / 11.8 / 3.0 x 10^9 with 20 in flight
+constexpr int kBouncePiecesPark = 32;       // K3p with the device-wide pool, 20 in flight / one launch at a time, x 10^9: round 4 32 / 40 / 48 / 56 / 63 = 11.8 / 12.2 / 11.9 / 11.8 / 3.0;
+                                            // round 5 (opening book): 17.57 / 17.47 / 17.48 / 17.30 / 3.85 pipelined, 3.17 / 3.00 / 2.69 / 0.30 / 0.09 alone
 constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBoards (0 = every wave drains alone)
 // K3p, automatic plan: the shape of a launch follows the number of launches the caller keeps in flight on the device
 // (bgs_set_launches_in_flight; the rollout executor passes its depth).  tail_cap: games longer than this are finished

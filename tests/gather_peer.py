@@ -136,7 +136,7 @@ def run_steps(directory, rank, world):
 
 
 def run_inject(directory, rank, world):
-    """BGS_GATHER_INJECT_FAILURE=5: step 5 "cannot be enqueued" after rank 0 claimed its sink ticket.  The call reports
+    """BGS_EXPERIMENT=gather_inject_failure=5: step 5 "cannot be enqueued" after rank 0 claimed its sink ticket.  The call reports
     it, the steps before it are delivered, nothing stalls: waits return, close() returns."""
     from simulator.batch import ConnectBatch
     from simulator.game._abi import BgsError
@@ -181,7 +181,7 @@ def run_inject(directory, rank, world):
 
 
 def run_inject_one(directory, rank, world):
-    """Round-4 advisor: ONE rank fails locally (BGS_GATHER_INJECT_RANK names it, BGS_GATHER_INJECT_FAILURE the step) while
+    """Round-4 advisor: ONE rank fails locally (BGS_EXPERIMENT: gather_inject_rank names it, gather_inject_failure the step) while
     its peers have posted -- or will post -- the matching halves of the group.  The failing rank still posts its message
     (zeros), so nobody stalls: it reports the failure itself, rank 0 gets every step, with that rank's rows of the failed
     step reading 0 / 0 ("still running") and everything else equal to the oracle."""
@@ -190,7 +190,7 @@ def run_inject_one(directory, rank, world):
     from simulator.sharding import RewardGather
 
     n, slots, steps = 1024, 8, 6
-    bad_rank, bad_step = int(os.environ["BGS_GATHER_INJECT_RANK"]), int(os.environ["BGS_GATHER_INJECT_FAILURE"])
+    bad_rank, bad_step = int(os.environ["PEER_BAD_RANK"]), int(os.environ["PEER_BAD_STEP"])   # (= BGS_EXPERIMENT's gather_inject_rank / _failure)
     assert bad_step == steps - 1, "the failing rank cannot submit anything after its failure: make it the last step"
     dist = FileDist(directory, rank, world)
     batch = ConnectBatch(6, 7, 4, n, use_torch=False)

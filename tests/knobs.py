@@ -1,0 +1,57 @@
+"""The library's A/B switches and test hooks live behind ONE environment variable, BGS_EXPERIMENT="name=value;name=value"
+(csrc: bgs::experiment; the names are listed in tools/README.md).  `knobs` is that variable as a mapping, for the tests
+that force a kernel family or inject a fault:
+
+    knobs["bounce_group"] = "1"; ...; del knobs["bounce_group"]
+    monkeypatch.setitem(knobs, "bounce_plan", "6:1,20:8,0:64")        # restored when the test ends
+    env = dict(os.environ, BGS_EXPERIMENT=experiment(transition="fused", transition_spin="0"))   # for a child process
+"""
+
+import os
+from collections.abc import MutableMapping
+
+
+def experiment(**settings) -> str:
+    """The BGS_EXPERIMENT string of `settings` (values may hold commas and colons, not semicolons)."""
+    return ";".join(f"{k}={v}" for k, v in settings.items())
+
+
+class _Knobs(MutableMapping):
+    @staticmethod
+    def _read() -> dict:
+        out = {}
+        for part in os.environ.get("BGS_EXPERIMENT", "").split(";"):
+            part = part.strip()
+            if part:
+                name, _, value = part.partition("=")
+                out[name] = value if _ else "1"
+        return out
+
+    @staticmethod
+    def _write(d: dict) -> None:
+        if d:
+            os.environ["BGS_EXPERIMENT"] = experiment(**d)
+        else:
+            os.environ.pop("BGS_EXPERIMENT", None)
+
+    def __getitem__(self, name):
+        return self._read()[name]
+
+    def __setitem__(self, name, value):
+        d = self._read()
+        d[name] = str(value)
+        self._write(d)
+
+    def __delitem__(self, name):
+        d = self._read()
+        del d[name]
+        self._write(d)
+
+    def __iter__(self):
+        return iter(self._read())
+
+    def __len__(self):
+        return len(self._read())
+
+
+knobs = _Knobs()

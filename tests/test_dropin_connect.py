@@ -9,6 +9,8 @@ import random
 import numpy as np
 import pytest
 
+from tests.knobs import experiment
+
 pytestmark = pytest.mark.gpu
 
 
@@ -248,7 +250,7 @@ print(h.hexdigest())
 def test_the_three_forms_of_the_round_trip_agree():
     """bgs_transition on a one-board batch: staged copies, blocks the device addresses in host memory, the same launches
     replayed from a HIP graph, and the default -- in place with move + observation fused into one kernel
-    (BGS_TRANSITION), the host taking the records when it sees the kernel's ticket or, BGS_TRANSITION_SPIN=0, when the
+    (BGS_EXPERIMENT: transition=...), the host taking the records when it sees the kernel's ticket or, transition_spin=0, when the
     stream has completed -- one digest over three playthroughs (12x13x5 and Bounce included)."""
     import subprocess
     import sys
@@ -257,8 +259,8 @@ def test_the_three_forms_of_the_round_trip_agree():
     code = _PLAYTHROUGH.format(root=root, pkg=os.path.join(root, "board-game-simulator-python_amd"))
     digests = {}
     for form in ("staged", "mapped", "graph", "fused", "fused-stream", "fused-thread"):
-        env = dict(os.environ, BGS_TRANSITION=form.split("-")[0], BGS_TRANSITION_SPIN="0" if form.endswith("stream") else "1",
-                   BGS_TRANSITION_WAVE="0" if form.endswith("thread") else "1")   # Bounce: a thread per board instead of a piece per lane
+        env = dict(os.environ, BGS_EXPERIMENT=experiment(transition=form.split("-")[0], transition_spin="0" if form.endswith("stream") else "1",
+                                                        transition_wave="0" if form.endswith("thread") else "1"))   # Bounce: a thread per board instead of a piece per lane
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         digests[form] = out.stdout.strip().splitlines()[-1]

@@ -4,6 +4,8 @@ sampled plies, caller-chosen moves, loads and rollouts.  Seeds are fixed; everyt
 import numpy as np
 import pytest
 
+from tests.knobs import knobs
+
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -174,8 +176,8 @@ def test_bounce_piece_list_random_grid(case):
     n = int(rng.choice([1, 63, 64, 65, 255, 257, 1000, 2500, 6000]))
     first = int(rng.integers(0, 1 << 40))
     cap = int(rng.choice([0, 1, 7, 60, 500, 769, 2000]))
-    old = os.environ.get("BGS_BOUNCE_GROUP")
-    os.environ["BGS_BOUNCE_GROUP"] = "1"
+    old = knobs.get("bounce_group")
+    knobs["bounce_group"] = "1"
     try:
         dev = BounceBatch(grid, n)
         orc = oracle.BounceOracle(grid, n)
@@ -188,6 +190,6 @@ def test_bounce_piece_list_random_grid(case):
         dev.close()
     finally:
         if old is None:
-            del os.environ["BGS_BOUNCE_GROUP"]
+            del knobs["bounce_group"]
         else:
-            os.environ["BGS_BOUNCE_GROUP"] = old
+            knobs["bounce_group"] = old

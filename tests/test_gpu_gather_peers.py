@@ -66,7 +66,7 @@ def test_a_step_that_cannot_be_enqueued_does_not_stall_the_gather(tmp_path):
     """Round-3 advisor: a failure after rank 0 claimed the step's sink ticket left the ticket unpublished and
     bgs_gather_destroy waiting for it.  The failed step now travels through the communication thread with its flag
     down: the call reports the failure, waits return, close() returns -- in the middle of a group of 4."""
-    outs, _ = run_ranks(tmp_path, 2, "inject", {"BGS_GATHER_INJECT_FAILURE": "5", "BGS_GATHER_BATCH": "4"}, timeout=120)
+    outs, _ = run_ranks(tmp_path, 2, "inject", {"BGS_EXPERIMENT": "gather_inject_failure=5", "BGS_GATHER_BATCH": "4"}, timeout=120)
     for r, out in enumerate(outs):
         assert f"INJECT_OK rank {r}" in out, out
 
@@ -118,7 +118,7 @@ def test_a_rank_that_submits_one_step_and_then_blocks_elsewhere(tmp_path):
 def test_one_rank_fails_alone_and_nobody_is_left_waiting(tmp_path, bad_rank):
     """Round-4 advisor (low): a step that cannot be enqueued on ONE rank.  That rank reports it; its message still goes
     out (zeros), the peers' groups complete, rank 0 delivers every step."""
-    outs, _ = run_ranks(tmp_path, 3, "inject_one", {"BGS_GATHER_INJECT_FAILURE": "5", "BGS_GATHER_INJECT_RANK": str(bad_rank),
-                                                    "BGS_GATHER_BATCH": "4"}, timeout=120)
+    outs, _ = run_ranks(tmp_path, 3, "inject_one", {"BGS_EXPERIMENT": f"gather_inject_failure=5;gather_inject_rank={bad_rank}", "PEER_BAD_RANK": str(bad_rank),
+                                                    "PEER_BAD_STEP": "5", "BGS_GATHER_BATCH": "4"}, timeout=120)
     for r, out in enumerate(outs):
         assert f"INJECT_ONE_OK rank {r}" in out, out

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.knobs import knobs
+
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -24,9 +26,9 @@ def bm():
 
 @pytest.fixture()
 def forced_generic():
-    os.environ["BGS_FORCE_GENERIC"] = "1"
+    knobs["force_generic"] = "1"
     yield
-    del os.environ["BGS_FORCE_GENERIC"]
+    del knobs["force_generic"]
 
 
 def assert_same(dev, orc, what=""):
@@ -112,7 +114,7 @@ def test_connect_generic_equals_packed(bm, forced_generic, h, w, k):
     n = 3000
     gen = bm.ConnectBatch(h, w, k, n)
     assert gen.generic
-    del os.environ["BGS_FORCE_GENERIC"]
+    del knobs["force_generic"]
     try:
         packed = bm.ConnectBatch(h, w, k, n)
         assert not packed.generic
@@ -130,7 +132,7 @@ def test_connect_generic_equals_packed(bm, forced_generic, h, w, k):
         np.testing.assert_array_equal(gen.plies, packed.plies)
         assert gen.steps == packed.steps
     finally:
-        os.environ["BGS_FORCE_GENERIC"] = "1"
+        knobs["force_generic"] = "1"
 
 
 def bounce_grid(h, w, rows, values):
@@ -183,7 +185,7 @@ def test_bounce_generic_equals_packed(bm, forced_generic):
     n = 2000
     gen = bm.BounceBatch(grid, n)
     assert gen.generic
-    del os.environ["BGS_FORCE_GENERIC"]
+    del knobs["force_generic"]
     try:
         packed = bm.BounceBatch(grid, n)
         assert not packed.generic
@@ -197,7 +199,7 @@ def test_bounce_generic_equals_packed(bm, forced_generic):
         np.testing.assert_array_equal(gen.action_count, packed.action_count)
         assert gen.steps == packed.steps
     finally:
-        os.environ["BGS_FORCE_GENERIC"] = "1"
+        knobs["force_generic"] = "1"
 
 
 def test_bounce_generic_chosen_moves(bm):

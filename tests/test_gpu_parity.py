@@ -6,6 +6,8 @@ Everything here needs a real MI355X: `pytest -m gpu`.
 import numpy as np
 import pytest
 
+from tests.knobs import knobs
+
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -230,8 +232,8 @@ def test_connect_large_board_full_size(batch_mod, opening):
     of every game, then the LDS-staged kernel picks the boards up from memory) and without it."""
     import os
 
-    old = os.environ.get("BGS_ROLLOUT_OPENING")
-    os.environ["BGS_ROLLOUT_OPENING"] = opening
+    old = knobs.get("rollout_opening")
+    knobs["rollout_opening"] = opening
     try:
         n = 1 << 18
         dev = batch_mod.ConnectBatch(12, 13, 5, n)
@@ -246,21 +248,21 @@ def test_connect_large_board_full_size(batch_mod, opening):
         dev.close()
     finally:
         if old is None:
-            del os.environ["BGS_ROLLOUT_OPENING"]
+            del knobs["rollout_opening"]
         else:
-            os.environ["BGS_ROLLOUT_OPENING"] = old
+            knobs["rollout_opening"] = old
 
 
 @pytest.mark.parametrize("kernel", ["lds", "registers"])
 def test_connect_large_board_entry_states(batch_mod, kernel):
     """Connect(12,13,5) rollouts from every entry state on the LDS-staged kernel (K2c: from the initial state, boards
     loaded from memory at any ply of a 4-ply block, ply caps, finished boards in the batch, fused outcome codes) and on
-    the register kernel it replaces (BGS_ROLLOUT_NO_LDS): boards, rewards, plies, step counts against the oracle."""
+    the register kernel it replaces (BGS_EXPERIMENT=rollout_no_lds): boards, rewards, plies, step counts against the oracle."""
     import os
 
-    old = os.environ.get("BGS_ROLLOUT_NO_LDS")
+    old = knobs.get("rollout_no_lds")
     if kernel == "registers":
-        os.environ["BGS_ROLLOUT_NO_LDS"] = "1"
+        knobs["rollout_no_lds"] = "1"
     try:
         n = 20011
         dev = batch_mod.ConnectBatch(12, 13, 5, n)
@@ -297,9 +299,9 @@ def test_connect_large_board_entry_states(batch_mod, kernel):
         dev.close()
     finally:
         if old is None:
-            os.environ.pop("BGS_ROLLOUT_NO_LDS", None)
+            knobs.pop("rollout_no_lds", None)
         else:
-            os.environ["BGS_ROLLOUT_NO_LDS"] = old
+            knobs["rollout_no_lds"] = old
 
 
 @pytest.mark.parametrize("mode", ["opening0", "opening1", "opening2", "opening3", "opening4", "generic"])
@@ -310,11 +312,11 @@ def test_connect_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
     K >= 4 and H >= 6), ragged sizes, a chunk that ends inside a round of 64."""
     import os
 
-    env = {"opening0": {"BGS_ROLLOUT_OPENING": "0"}, "opening1": {"BGS_ROLLOUT_OPENING": "1"},
-           "opening2": {"BGS_ROLLOUT_OPENING": "2"}, "opening3": {"BGS_ROLLOUT_OPENING": "3"},
-           "opening4": {"BGS_ROLLOUT_OPENING": "4"}, "generic": {"BGS_ROLLOUT_GENERIC": "1"}}[mode]
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    env = {"opening0": {"rollout_opening": "0"}, "opening1": {"rollout_opening": "1"},
+           "opening2": {"rollout_opening": "2"}, "opening3": {"rollout_opening": "3"},
+           "opening4": {"rollout_opening": "4"}, "generic": {"rollout_generic": "1"}}[mode]
+    old = {k: knobs.get(k) for k in env}
+    knobs.update(env)
     try:
         for (h, w, k), n in [((6, 7, 4), 70001), ((6, 7, 4), 63), ((4, 2, 3), 5000), ((5, 5, 3), 4097), ((8, 8, 4), 9999),
                              ((6, 2, 4), 3000), ((7, 8, 5), 8191), ((3, 7, 3), 2000), ((6, 1, 4), 500), ((6, 7, 2), 1000),
@@ -341,9 +343,9 @@ def test_connect_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
     finally:
         for k, v in old.items():
             if v is None:
-                del os.environ[k]
+                del knobs[k]
             else:
-                os.environ[k] = v
+                knobs[k] = v
 
 
 @pytest.mark.parametrize("mode", ["1", "1:flat", "8", "1:nested", "passes"])
@@ -354,11 +356,11 @@ def test_bounce_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
     passes, then a lane-group pass over the compacted work list)."""
     import os
 
-    env = {"1": {"BGS_BOUNCE_GROUP": "1"}, "1:flat": {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PIECES": "0"}, "8": {"BGS_BOUNCE_GROUP": "8"},
-           "1:nested": {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_FLAT": "0"},
-           "passes": {"BGS_BOUNCE_PLAN": "16:1,64:1,0:8", "BGS_BOUNCE_CHUNK": "8"}}[mode]
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    env = {"1": {"bounce_group": "1"}, "1:flat": {"bounce_group": "1", "bounce_pieces": "0"}, "8": {"bounce_group": "8"},
+           "1:nested": {"bounce_group": "1", "bounce_flat": "0"},
+           "passes": {"bounce_plan": "16:1,64:1,0:8", "bounce_chunk": "8"}}[mode]
+    old = {k: knobs.get(k) for k in env}
+    knobs.update(env)
     try:
         n = 9000
         dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
@@ -385,9 +387,9 @@ def test_bounce_rollout_kernel_families_agree_with_the_oracle(batch_mod, mode):
     finally:
         for k, v in old.items():
             if v is None:
-                del os.environ[k]
+                del knobs[k]
             else:
-                os.environ[k] = v
+                knobs[k] = v
 
 
 @pytest.mark.parametrize("pieces", ["1", "0"])
@@ -400,11 +402,11 @@ def test_bounce_flat_rollout_shared_drain_protocol(batch_mod, park, waves, chunk
     every board must be finished exactly once and match the oracle, the step count included."""
     import os
 
-    env = {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PARK": park, "BGS_BOUNCE_CHUNK": chunk, "BGS_BOUNCE_PIECES": pieces}
+    env = {"bounce_group": "1", "bounce_park": park, "bounce_chunk": chunk, "bounce_pieces": pieces}
     if waves != "0":
-        env["BGS_BOUNCE_FLAT_WAVES"] = waves
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+        env["bounce_flat_waves"] = waves
+    old = {k: knobs.get(k) for k in env}
+    knobs.update(env)
     try:
         for n in (1, 63, 64, 65, 255, 256, 257, 1000, 4099, 20011):
             dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
@@ -427,9 +429,9 @@ def test_bounce_flat_rollout_shared_drain_protocol(batch_mod, park, waves, chunk
     finally:
         for k, v in old.items():
             if v is None:
-                del os.environ[k]
+                del knobs[k]
             else:
-                os.environ[k] = v
+                knobs[k] = v
 
 
 @pytest.mark.parametrize("pool,park,waves,chunk", [("1", "40", "0", "0"), ("1", "63", "128", "32"), ("1", "3", "512", "64"),
@@ -442,13 +444,13 @@ def test_bounce_device_wide_pool_of_parked_boards(batch_mod, pool, park, waves, 
     board of a wave in the same iteration (the race that loses parked boards), repeated."""
     import os
 
-    env = {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_POOL": pool, "BGS_BOUNCE_PIECES_PARK": park}
+    env = {"bounce_group": "1", "bounce_pool": pool, "bounce_pieces_park": park}
     if waves != "0":
-        env["BGS_BOUNCE_FLAT_WAVES"] = waves
+        env["bounce_flat_waves"] = waves
     if chunk != "0":
-        env["BGS_BOUNCE_CHUNK"] = chunk
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+        env["bounce_chunk"] = chunk
+    old = {k: knobs.get(k) for k in env}
+    knobs.update(env)
     try:
         for n in (4099, 20011, 70001):
             want = {}
@@ -466,9 +468,9 @@ def test_bounce_device_wide_pool_of_parked_boards(batch_mod, pool, park, waves, 
     finally:
         for k, v in old.items():
             if v is None:
-                os.environ.pop(k, None)
+                knobs.pop(k, None)
             else:
-                os.environ[k] = v
+                knobs[k] = v
 
 
 @pytest.mark.parametrize("pieces", ["1", "0"])
@@ -480,9 +482,9 @@ def test_bounce_short_caps_leave_no_parked_board_behind(batch_mod, pieces):
     start position (K3p / K3f) and capped-then-finished rollouts from memory (K3f), every board and the step counter."""
     import os
 
-    env = {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PARK": "32", "BGS_BOUNCE_CHUNK": "32", "BGS_BOUNCE_PIECES": pieces}
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    env = {"bounce_group": "1", "bounce_park": "32", "bounce_chunk": "32", "bounce_pieces": pieces}
+    old = {k: knobs.get(k) for k in env}
+    knobs.update(env)
     try:
         n = 20011
         want = {}
@@ -512,9 +514,9 @@ def test_bounce_short_caps_leave_no_parked_board_behind(batch_mod, pieces):
     finally:
         for k, v in old.items():
             if v is None:
-                del os.environ[k]
+                del knobs[k]
             else:
-                os.environ[k] = v
+                knobs[k] = v
 
 
 def test_unsupported_geometry_is_an_error(batch_mod):
@@ -627,8 +629,8 @@ def test_bounce_piece_list_rollout(batch_mod, name):
     import os
 
     grid = PIECE_LIST_GRIDS[name]
-    old = os.environ.get("BGS_BOUNCE_GROUP")
-    os.environ["BGS_BOUNCE_GROUP"] = "1"
+    old = knobs.get("bounce_group")
+    knobs["bounce_group"] = "1"
     try:
         for n, cap in ((6000, 4096), (333, 60)):
             dev = batch_mod.BounceBatch(grid, n)
@@ -645,9 +647,9 @@ def test_bounce_piece_list_rollout(batch_mod, name):
             dev.close()
     finally:
         if old is None:
-            del os.environ["BGS_BOUNCE_GROUP"]
+            del knobs["bounce_group"]
         else:
-            os.environ["BGS_BOUNCE_GROUP"] = old
+            knobs["bounce_group"] = old
 
 
 @pytest.mark.parametrize("depth", ["1", "2", "3", "4"])
@@ -659,7 +661,7 @@ def test_bounce_opening_book(batch_mod, monkeypatch, name, depth):
     to 16 pieces (values up to 15, a blocked start: no book; paths that END inside the book: a piece in the goal row after two
     plies on the small grids), for every depth, under ply caps below, at and above the depth, and resumed from memory."""
     grid = PIECE_LIST_GRIDS[name]
-    monkeypatch.setenv("BGS_BOUNCE_GROUP", "1")
+    monkeypatch.setitem(knobs, "bounce_group", "1")
     monkeypatch.setenv("BGS_BOUNCE_BOOK", depth)   # (forces the book for a batch of any size)
     d = int(depth)
     for n, cap in ((6000, 4096), (777, d), (500, max(1, d - 1)), (333, d + 1)):
@@ -680,7 +682,7 @@ def test_bounce_opening_book_is_shared_and_released(batch_mod, monkeypatch):
     """The book belongs to the start position, not to the batch: batches of one start position on one device share it (the
     second create does not build), a different start position gets its own, and everything still plays the oracle's games
     after the first batch is gone."""
-    monkeypatch.setenv("BGS_BOUNCE_GROUP", "1")
+    monkeypatch.setitem(knobs, "bounce_group", "1")
     monkeypatch.setenv("BGS_BOUNCE_BOOK", "3")
     a = batch_mod.BounceBatch(DEFAULT_BOUNCE, 4000)
     b2 = batch_mod.BounceBatch(DEFAULT_BOUNCE, 2500)
@@ -704,9 +706,9 @@ def test_bounce_one_board_per_wave_pass(batch_mod, name):
     import os
 
     grid = PIECE_LIST_GRIDS[name]
-    env = {"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PLAN": "6:1,20:8,0:64"}
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    env = {"bounce_group": "1", "bounce_plan": "6:1,20:8,0:64"}
+    old = {k: knobs.get(k) for k in env}
+    knobs.update(env)
     try:
         for n, cap in ((2500, 4096), (700, 57), (64, 21), (300, 22)):
             dev = batch_mod.BounceBatch(grid, n)
@@ -720,9 +722,9 @@ def test_bounce_one_board_per_wave_pass(batch_mod, name):
     finally:
         for k, v in old.items():
             if v is None:
-                del os.environ[k]
+                del knobs[k]
             else:
-                os.environ[k] = v
+                knobs[k] = v
 
 
 @pytest.mark.parametrize("launches", [1, 4, 8, 16, 64])
@@ -832,10 +834,10 @@ def test_bounce_games_that_never_end(batch_mod, seed_offset, first_game):
 def test_bounce_memo_starts_over_when_its_epochs_run_out(batch_mod, monkeypatch, limit):
     """Round-4 advisor: a link of K3w's memo holds its epoch in 16 bits, and when the count of replacements reaches the
     limit the memo starts over empty -- stale rows of links are left behind and must not be followed.  2^16 replacements
-    do not happen in a test, so BGS_BOUNCE_EPOCH_LIMIT brings the restart within reach: a few waves, each playing a dozen
+    do not happen in a test, so BGS_EXPERIMENT=bounce_epoch_limit=<n> brings the restart within reach: a few waves, each playing a dozen
     boards -- among them a game that never ends -- replace remembered positions all the time."""
-    monkeypatch.setenv("BGS_BOUNCE_EPOCH_LIMIT", limit)
-    monkeypatch.setenv("BGS_BOUNCE_WAVE_GRID", "4")
+    monkeypatch.setitem(knobs, "bounce_epoch_limit", limit)
+    monkeypatch.setitem(knobs, "bounce_wave_grid", "4")
     n = 48
     for seed_offset, first_game, cap in ((0, 196997, 4096), (5, 2278, 1500)):
         dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)

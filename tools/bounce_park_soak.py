@@ -1,9 +1,10 @@
-"""Soak of the flat Bounce kernel's shared drain: the same seeds on a batch whose waves drain alone (BGS_BOUNCE_PARK=0)
+"""Soak of the flat Bounce kernel's shared drain: the same seeds on a batch whose waves drain alone (bounce_park=0)
 and on batches that park / adopt (threshold 32, several waves-per-launch settings) must give identical boards, plies,
 rewards and step counts -- a lost or doubly played parked board would show up here."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
+from tests.knobs import knobs  # BGS_EXPERIMENT ("name=value;...") as a mapping
 import numpy as np
 import torch
 from simulator.batch import BounceBatch
@@ -13,12 +14,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 16
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 
 def make(park, waves):
-    os.environ["BGS_BOUNCE_GROUP"] = "1"
-    os.environ["BGS_BOUNCE_PARK"] = str(park)
+    knobs["bounce_group"] = "1"
+    knobs["bounce_park"] = str(park)
     if waves:
-        os.environ["BGS_BOUNCE_FLAT_WAVES"] = str(waves)
+        knobs["bounce_flat_waves"] = str(waves)
     else:
-        os.environ.pop("BGS_BOUNCE_FLAT_WAVES", None)
+        knobs.pop("bounce_flat_waves", None)
     return BounceBatch(g, n, use_torch=True)
 
 ref = make(0, 0)

@@ -5,6 +5,7 @@ the tail pass, one launch, few waves, small parking threshold) must give identic
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
+from tests.knobs import knobs  # BGS_EXPERIMENT ("name=value;...") as a mapping
 import numpy as np
 import torch
 from simulator.batch import BounceBatch
@@ -12,23 +13,23 @@ from simulator.batch import BounceBatch
 g = np.zeros((9, 6), dtype=np.int8); g[1] = g[7] = [1, 2, 3, 3, 2, 1]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 16
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 150
-KEYS = ("BGS_BOUNCE_GROUP", "BGS_BOUNCE_PIECES", "BGS_BOUNCE_PLAN", "BGS_BOUNCE_PARK", "BGS_BOUNCE_FLAT_WAVES", "BGS_BOUNCE_POOL")
+KEYS = ("bounce_group", "bounce_pieces", "bounce_plan", "bounce_park", "bounce_flat_waves", "bounce_pool")
 
 def make(**env):
     for k in KEYS:
-        os.environ.pop(k, None)
-    os.environ["BGS_BOUNCE_GROUP"] = "1"
-    os.environ.update({k: str(v) for k, v in env.items()})
+        knobs.pop(k, None)
+    knobs["bounce_group"] = "1"
+    knobs.update({k: str(v) for k, v in env.items()})
     return BounceBatch(g, n, use_torch=True)
 
-ref = make(BGS_BOUNCE_PIECES=0, BGS_BOUNCE_PLAN="single", BGS_BOUNCE_PARK=0)
-variants = {"K3p default (bulk + tail)": make(), "K3p single launch": make(BGS_BOUNCE_PLAN="single"),
-            "K3p 64 waves": make(BGS_BOUNCE_FLAT_WAVES=64), "K3p park 5 / 300 waves": make(BGS_BOUNCE_PARK=5, BGS_BOUNCE_FLAT_WAVES=300),
-            "K3p tail at 96": make(BGS_BOUNCE_PLAN="96:1,0:8"),
+ref = make(bounce_pieces=0, bounce_plan="single", bounce_park=0)
+variants = {"K3p default (bulk + tail)": make(), "K3p single launch": make(bounce_plan="single"),
+            "K3p 64 waves": make(bounce_flat_waves=64), "K3p park 5 / 300 waves": make(bounce_park=5, bounce_flat_waves=300),
+            "K3p tail at 96": make(bounce_plan="96:1,0:8"),
             # round 4: the device-wide pool of parked boards is on by default (every variant above); off, and in the shapes that
             # stress it: many small workgroups' worth of waves, a parking threshold of 32 and of 3
-            "K3p no device-wide pool": make(BGS_BOUNCE_POOL=0), "K3p pool, 1024 waves, park 32": make(BGS_BOUNCE_FLAT_WAVES=1024, BGS_BOUNCE_PARK=32),
-            "K3p pool, 128 waves, park 3, single launch": make(BGS_BOUNCE_FLAT_WAVES=128, BGS_BOUNCE_PARK=3, BGS_BOUNCE_PLAN="single")}
+            "K3p no device-wide pool": make(bounce_pool=0), "K3p pool, 1024 waves, park 32": make(bounce_flat_waves=1024, bounce_park=32),
+            "K3p pool, 128 waves, park 3, single launch": make(bounce_flat_waves=128, bounce_park=3, bounce_plan="single")}
 # the launch shapes of bounce_shape(): one launch at a time (the default above), 8 and 16 in flight
 for hint in (8, 16):
     variants[f"K3p shape of {hint} in flight"] = make()

@@ -24,7 +24,7 @@ pass k2o_solo python3 $R/bench.py $BENCH
 BGS_ROLLOUT_WPS=6 pass k2o_3deep python3 $R/bench.py $BENCH --batch 3145728 --inflight 1
 # K2c (12x13x5): one launch of 2^18 boards, and 8 launches' worth in one
 pass k2c_solo python3 $R/tools/rollout_rate.py connect12x13 --depth 1 --reps 9
-BGS_ROLLOUT_WPS=8 BGS_ROLLOUT_CHUNK=256 pass k2c_8deep python3 $R/tools/rollout_rate.py connect12x13 --depth 1 --reps 9 --batch 2097152
+BGS_ROLLOUT_WPS=8 BGS_EXPERIMENT="rollout_chunk=256" pass k2c_8deep python3 $R/tools/rollout_rate.py connect12x13 --depth 1 --reps 9 --batch 2097152
 # K3p (Bounce): the launch shape of 20 in flight, one launch; and 8 launches' worth of boards in one launch
 pass k3p_solo python3 $R/tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 20
 pass k3p_8x python3 $R/tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 20 --batch 2097152

@@ -1,9 +1,10 @@
 """Soak of K2o against K2a: the same seeds on a batch played by the kernel without the opening stage
-(BGS_ROLLOUT_OPENING=0) and on batches played by K2o with 1..4 opening blocks and different chunk sizes must give
+(rollout_opening=0) and on batches played by K2o with 1..4 opening blocks and different chunk sizes must give
 identical rewards, boards and step counts."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
+from tests.knobs import knobs  # BGS_EXPERIMENT ("name=value;...") as a mapping
 import numpy as np
 import torch
 from simulator.batch import ConnectBatch
@@ -12,11 +13,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 
 def make(opening, chunk):
-    os.environ["BGS_ROLLOUT_OPENING"] = str(opening)
+    knobs["rollout_opening"] = str(opening)
     if chunk:
-        os.environ["BGS_ROLLOUT_CHUNK"] = str(chunk)
+        knobs["rollout_chunk"] = str(chunk)
     else:
-        os.environ.pop("BGS_ROLLOUT_CHUNK", None)
+        knobs.pop("rollout_chunk", None)
     return ConnectBatch(6, 7, 4, n, use_torch=True)
 
 ref = make(0, 0)

@@ -1,9 +1,10 @@
 """Soak of the Connect(12,13,5) rollout's opening launch: the same seeds through the LDS-staged kernel from the empty board
-(BGS_ROLLOUT_OPENING=0), through opening launch + rollout kernel (default) and through the register kernel K2b must give
+(rollout_opening=0), through opening launch + rollout kernel (default) and through the register kernel K2b must give
 identical planes, status, rewards and step counts on 2^18 boards."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
+from tests.knobs import knobs  # BGS_EXPERIMENT ("name=value;...") as a mapping
 import numpy as np
 import torch
 from simulator.batch import ConnectBatch
@@ -13,13 +14,13 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 
 def make(**env):
-    for k in ("BGS_ROLLOUT_OPENING", "BGS_ROLLOUT_NO_LDS"):
-        os.environ.pop(k, None)
-    os.environ.update({k: str(v) for k, v in env.items()})
+    for k in ("rollout_opening", "rollout_no_lds"):
+        knobs.pop(k, None)
+    knobs.update({k: str(v) for k, v in env.items()})
     return ConnectBatch(12, 13, 5, n, use_torch=True)
 
-ref = make(BGS_ROLLOUT_OPENING=0)
-variants = {"opening launch": make(), "register kernel": make(BGS_ROLLOUT_NO_LDS=1)}
+ref = make(rollout_opening=0)
+variants = {"opening launch": make(), "register kernel": make(rollout_no_lds=1)}
 t0 = time.perf_counter()
 for s in range(seeds):
     seed = 0x5EED0000 + 104729 * s

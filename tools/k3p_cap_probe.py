@@ -1,8 +1,9 @@
-"""Probe: short-cap rollouts from the start position (K3p, or K3f with BGS_BOUNCE_PIECES=0) with parking on: every board must be stored."""
+"""Probe: short-cap rollouts from the start position (K3p, or K3f with bounce_pieces=0) with parking on: every board must be stored."""
 import os, sys, collections
-os.environ.update({"BGS_BOUNCE_GROUP": "1", "BGS_BOUNCE_PARK": os.environ.get("PARK", "32"), "BGS_BOUNCE_CHUNK": "32"})
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
+from tests.knobs import knobs  # BGS_EXPERIMENT ("name=value;...") as a mapping
+knobs.update({"bounce_group": "1", "bounce_park": os.environ.get("PARK", "32"), "bounce_chunk": "32"})
 import numpy as np
 from oracle import oracle
 from simulator.batch import BounceBatch

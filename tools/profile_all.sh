@@ -27,10 +27,10 @@ need k2c && bash tools/profile_kernel.sh k2c python3 tools/rollout_rate.py conne
 need bounce && bash tools/profile_kernel.sh bounce python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 20
 need bounce_solo && bash tools/profile_kernel.sh bounce_solo python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 1
 if [ "${BGS_PROFILE_FULL:-0}" = "1" ]; then   # the kernels the defaults replaced, for the instruction-count comparisons
-need bounce_k3f && BGS_BOUNCE_PIECES=0 BGS_BOUNCE_PLAN=single bash tools/profile_kernel.sh bounce_k3f python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 20
-need bounce_lane_groups && BGS_BOUNCE_GROUP=8 bash tools/profile_kernel.sh bounce8 python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 20
+need bounce_k3f && BGS_EXPERIMENT="bounce_pieces=0;bounce_plan=single" bash tools/profile_kernel.sh bounce_k3f python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 20
+need bounce_lane_groups && BGS_EXPERIMENT="bounce_group=8" bash tools/profile_kernel.sh bounce8 python3 tools/rollout_rate.py bounce --depth 1 --reps 6 --hint 20
 # K2b: the register kernel K2c replaced on 12x13x5
-need k2b && BGS_ROLLOUT_NO_LDS=1 bash tools/profile_kernel.sh k2b python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9
+need k2b && BGS_EXPERIMENT="rollout_no_lds=1" bash tools/profile_kernel.sh k2b python3 tools/rollout_rate.py connect12x13 --depth 1 --reps 9
 fi
 # K4 and the rest (reset, unpack, legal, ...): kernel stats only
 cd /tmp && export TMPDIR=/tmp

@@ -13,10 +13,12 @@ if "--depth" in sys.argv:
 os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(2 * _depth, 32)) if _depth > 4 else 4))
 # Bounce with many batches in flight: fewer, longer-lived waves per launch (less drain per batch; the launches fill the chip
 # together).  Must be set before the library reads it at batch creation.
-if "--bounce-waves" in sys.argv:
-    os.environ["BGS_BOUNCE_FLAT_WAVES"] = sys.argv[sys.argv.index("--bounce-waves") + 1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
+if "--bounce-waves" in sys.argv:
+    from tests.knobs import knobs  # BGS_EXPERIMENT ("name=value;...") as a mapping
+
+    knobs["bounce_flat_waves"] = sys.argv[sys.argv.index("--bounce-waves") + 1]
 import numpy as np
 import torch
 from simulator.batch import BounceBatch, ConnectBatch
@@ -29,7 +31,7 @@ ap.add_argument("--reps", type=int, default=24)
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--max-plies", type=int, default=4096)
 ap.add_argument("--hint", type=int, default=0, help="launches-in-flight hint for every run (0: the run's own depth); counters of the pipelined launch shape can then be taken one launch at a time")
-ap.add_argument("--bounce-waves", type=int, default=0, help="BGS_BOUNCE_FLAT_WAVES for this run (0: library default)")
+ap.add_argument("--bounce-waves", type=int, default=0, help="BGS_EXPERIMENT bounce_flat_waves for this run (0: library default)")
 args = ap.parse_args()
 
 def make():

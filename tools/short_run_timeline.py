@@ -2,11 +2,12 @@
 """Where the time of a short timed region goes: the headline workload (Connect 6x7x4, 2^20 boards, 3 in flight, rewards
 to host) for K steps with every launch bracketed by events -- start and end of every launch relative to the first, and
 the host's clock around enqueue / drain.  Prints one JSON object.   python tools/short_run_timeline.py [K] [repeats]
-With BGS_SINK_TRACE=1 the sink's threads report (stderr, microseconds of the same clock) when each delivery's codes were
+With sink_trace=1 the sink's threads report (stderr, microseconds of the same clock) when each delivery's codes were
 seen and expanded; round 3, r3_drain.sh in the git history puts the two together for the last delivery of each repeat."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
+from tests.knobs import knobs  # BGS_EXPERIMENT ("name=value;...") as a mapping
 import numpy as np
 from simulator.game import _abi
 _abi.request_hardware_queues()
@@ -45,7 +46,7 @@ for rep in range(REPEATS):
     exe.kernel_ms()
     steps = sum(b.steps for b in batches)
     last_end = max(e for _, e in tl)
-    if os.environ.get("BGS_SINK_TRACE"):
+    if knobs.get("sink_trace"):
         print(f"host-trace rep {rep} t0 {t0 * 1e6:.1f} enqueue_returns {t1 * 1e6:.1f} drain_returns {t2 * 1e6:.1f} synchronized {t3 * 1e6:.1f}", file=sys.stderr)
     runs.append({"host_us": {"enqueue_returns": (t1 - t0) * 1e6, "drain_returns": (t2 - t0) * 1e6, "synchronized": (t3 - t0) * 1e6},
                  "device_us": {"last_kernel_ends_after_first_starts": last_end * 1e3,

@@ -4,6 +4,7 @@ time per step and the expansion rate: at 8 ranks the host array grows by 16 MiB 
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
+from tests.knobs import knobs  # BGS_EXPERIMENT ("name=value;...") as a mapping
 import numpy as np
 import torch
 from simulator.batch import RewardSink
@@ -37,4 +38,4 @@ for t in args.threads:
     dt = (time.perf_counter() - t0) / reps
     out.append({"threads": t, "us_per_step": dt * 1e6, "host_GBps": 2 * n / dt / 1e9})
     sink.close()
-print(json.dumps({"ranks": args.ranks, "games_per_step": n, "stream_stores": "BGS_NO_STREAM_STORES" not in os.environ, "by_threads": out}))
+print(json.dumps({"ranks": args.ranks, "games_per_step": n, "stream_stores": "no_stream_stores" not in knobs, "by_threads": out}))

@@ -77,11 +77,16 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t game, u
     return out;
 }
 
+// word (ply & 3) of a philox result, for a ply that differs from lane to lane.  Written with masks, not with selects or
+// an index: hipcc turns `j & 1 ? p.v[1] : p.v[0]` into an indexed read of the four words, puts them into LDS for it
+// (ds_write2 + ds_read + a wait in the middle of the ply) and the HBM-bound per-ply kernel lost a third of its rate to it
+// (round 5, 78 -> 111 us at 2^24 boards).
 __device__ __forceinline__ uint32_t philox_word(const Philox4& p, uint32_t ply) {
-    const uint32_t j = ply & 3u;
-    const uint32_t lo = (j & 1u) ? p.v[1] : p.v[0];
-    const uint32_t hi = (j & 1u) ? p.v[3] : p.v[2];
-    return (j & 2u) ? hi : lo;
+    uint32_t odd = 0u - (ply & 1u), upper = 0u - ((ply >> 1) & 1u);   // all ones or zero
+    asm("" : "+v"(odd), "+v"(upper));                                   // (keeps them masks)
+    const uint32_t lo = (p.v[1] & odd) | (p.v[0] & ~odd);
+    const uint32_t hi = (p.v[3] & odd) | (p.v[2] & ~odd);
+    return (hi & upper) | (lo & ~upper);
 }
 
 // Connect: the draw of sub-step j (0..3) of a block from the block's word -- j is a compile-time constant in the rollout

@@ -15,10 +15,12 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
 #include <immintrin.h>
+#include <string>
 #include <vector>
 
 #include "bgs_capi_util.h"
@@ -98,6 +100,20 @@ struct bgs_pipeline {
     // timing brackets
     std::vector<hipEvent_t> ev0, ev1;
     size_t brackets = 0;
+    // The FEEDER (bgs_pipeline_feed / _release; round 5): a thread of the pipeline's own that enqueues the steps a caller has
+    // fed -- one seed each -- as soon as the host array a step lands in has been RELEASED by the consumer, so that a consumer
+    // loop in a slow language (simulator.pipeline.RolloutPipeline.run: a generator in Python) only waits for a hand-over,
+    // reads it and releases it -- three cheap calls -- while the launches are made beside it.  `mu` guards step / handed /
+    // ticket / held / the feeder's own fields whenever a feeder exists.
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread feeder;
+    std::deque<uint64_t> fed;     // seeds not enqueued yet
+    int64_t released = 0;          // hand-overs [0, released) are the consumer's no more: their arrays may be overwritten
+    bool feeding = false;          // the feeder thread exists
+    bool stop = false;
+    int feed_rc = BGS_OK;          // the first failure of an enqueue made by the feeder ...
+    std::string feed_error;        // ... and its message (reported by the consumer's next call)
 };
 
 extern "C" {
@@ -161,12 +177,16 @@ static int consume(bgs_pipeline* p, int64_t j) {
     return bgs_progress_store(p->consumed, j + 1);
 }
 
-static int enqueue_steps(bgs_pipeline* p, const uint64_t* seeds, int64_t count, int handover, int time_stride) {
+static int enqueue_steps(bgs_pipeline* p, const uint64_t* seeds, int64_t count, int handover, int time_stride, bool from_feeder = false) {
     NEED(p != nullptr && count >= 0, "bad argument");
     NEED(!handover || p->sink || p->gather, "this pipeline has no hand-over");
+    NEED(from_feeder || !p->feeding || p->fed.empty(), "steps are being fed to this pipeline (bgs_pipeline_feed): enqueue when they have all been consumed");
     HIP_TRY(hipSetDevice(p->device));
     const int depth = (int)p->batches.size();
     const int n_host = (int)p->host.size();
+    // (with a feeder the consumer's bgs_pipeline_wait reads ticket / held beside this loop: the bookkeeping of a step is
+    // made under the pipeline's lock, the waits and the launches outside it)
+    std::unique_lock<std::mutex> lock(p->mu, std::defer_lock);
     for (int64_t i = 0; i < count; ++i) {
         bgs_batch* b = p->batches[p->step % depth];
         const uint64_t seed = seeds ? seeds[i] : p->seed0 + (uint64_t)p->step;
@@ -186,9 +206,14 @@ static int enqueue_steps(bgs_pipeline* p, const uint64_t* seeds, int64_t count, 
         if (handover) {
             const int64_t j = p->handed;
             const int h = (int)(j % n_host);
-            if (p->ticket[h] >= 0) {   // the array is about to be overwritten: its previous delivery must be over
-                if ((rc = wait_ticket(p, p->ticket[h]))) return rc;
-                p->ticket[h] = -1;
+            lock.lock();
+            const int64_t before = p->ticket[h];
+            lock.unlock();
+            if (before >= 0) {   // the array is about to be overwritten: its previous delivery must be over
+                if ((rc = wait_ticket(p, before))) return rc;
+                lock.lock();
+                if (p->ticket[h] == before) p->ticket[h] = -1;
+                lock.unlock();
             }
             if (p->rank_words) {
                 if (p->consumer && j - p->lag >= 0 && (rc = consume(p, j - p->lag))) return rc;
@@ -202,9 +227,13 @@ static int enqueue_steps(bgs_pipeline* p, const uint64_t* seeds, int64_t count, 
             // the ring's progress words count the sink's deliveries: hand-over j must be the sink's job j
             NEED(!p->rank_words || t == j, "a pipeline on a shared array needs a sink of its own (ticket %lld for hand-over %lld)",
                  (long long)t, (long long)j);
+            lock.lock();
             p->ticket[h] = t;
             p->held[h] = j;
             ++p->handed;
+            if (!from_feeder) p->released = p->handed;   // (a caller who enqueues himself answers for his arrays himself)
+            lock.unlock();
+            if (p->feeding) p->cv.notify_all();          // (a consumer may be waiting for this hand-over to exist)
         } else {
             if ((rc = bgs_rollout(b, seed, p->max_plies, p->flags))) return rc;
         }
@@ -214,9 +243,36 @@ static int enqueue_steps(bgs_pipeline* p, const uint64_t* seeds, int64_t count, 
             HIP_TRY(hipEventRecord(p->ev1[bracket], b->stream));
             ++p->brackets;
         }
+        lock.lock();
         ++p->step;
+        lock.unlock();
     }
     return BGS_OK;
+}
+
+// the feeder thread: one fed seed at a time, as soon as its host array has been released
+static void feeder_loop(bgs_pipeline* p) {
+    (void)hipSetDevice(p->device);
+    const int64_t n_host = (int64_t)p->host.size();
+    for (;;) {
+        uint64_t seed;
+        {
+            std::unique_lock<std::mutex> lock(p->mu);
+            p->cv.wait(lock, [&] { return p->stop || (!p->fed.empty() && p->feed_rc == BGS_OK && p->handed - p->released < n_host); });
+            if (p->stop) return;
+            seed = p->fed.front();
+        }
+        const int rc = enqueue_steps(p, &seed, 1, 1, 0, true);
+        {
+            std::lock_guard<std::mutex> lock(p->mu);
+            if (rc != BGS_OK && p->feed_rc == BGS_OK) {
+                p->feed_rc = rc;
+                p->feed_error = bgs_last_error();
+            }
+            if (rc == BGS_OK) p->fed.pop_front();
+        }
+        p->cv.notify_all();
+    }
 }
 
 int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, int time_stride) {
@@ -228,15 +284,57 @@ int bgs_pipeline_enqueue_seeds(bgs_pipeline* p, const uint64_t* seeds, int64_t c
     return enqueue_steps(p, seeds, count, handover, 0);
 }
 
+int bgs_pipeline_feed(bgs_pipeline* p, const uint64_t* seeds, int64_t count) {
+    NEED(p != nullptr && count >= 0 && (seeds != nullptr || count == 0), "bad argument");
+    NEED(p->sink || p->gather, "this pipeline has no hand-over");
+    NEED(!p->rank_words, "a pipeline on a shared array is driven by bgs_pipeline_enqueue");
+    {
+        std::lock_guard<std::mutex> lock(p->mu);
+        if (p->feed_rc != BGS_OK) return fail(p->feed_rc, "%s", p->feed_error.c_str());
+        if (!p->feeding) {
+            p->released = p->handed;   // (what was enqueued before is the caller's business)
+            p->feeding = true;
+            p->feeder = std::thread([p] { feeder_loop(p); });
+        }
+        p->fed.insert(p->fed.end(), seeds, seeds + count);
+    }
+    p->cv.notify_all();
+    return BGS_OK;
+}
+
+int bgs_pipeline_release(bgs_pipeline* p, int64_t handover_index) {
+    NEED(p != nullptr, "pipeline is NULL");
+    {
+        std::lock_guard<std::mutex> lock(p->mu);
+        NEED(handover_index >= 0 && handover_index < p->handed, "hand-over %lld has not been enqueued", (long long)handover_index);
+        if (handover_index + 1 > p->released) p->released = handover_index + 1;
+    }
+    p->cv.notify_all();
+    return BGS_OK;
+}
+
 int bgs_pipeline_wait(bgs_pipeline* p, int64_t handover_index) {
     NEED(p != nullptr, "pipeline is NULL");
-    NEED(handover_index >= 0 && handover_index < p->handed, "hand-over %lld has not been enqueued", (long long)handover_index);
-    const int h = (int)(handover_index % (int64_t)p->host.size());
-    NEED(p->held[h] == handover_index, "hand-over %lld is not in flight any more: its host array was reused by hand-over %lld",
-         (long long)handover_index, (long long)p->held[h]);
-    if (p->ticket[h] < 0) return BGS_OK;   // waited for before
-    int rc = wait_ticket(p, p->ticket[h]);
-    if (rc == BGS_OK) p->ticket[h] = -1;
+    int64_t t;
+    int h;
+    {
+        std::unique_lock<std::mutex> lock(p->mu);
+        // a fed step exists once the feeder has enqueued it
+        if (p->feeding && handover_index >= p->handed && handover_index < p->handed + (int64_t)p->fed.size())
+            p->cv.wait(lock, [&] { return handover_index < p->handed || p->feed_rc != BGS_OK || p->stop; });
+        if (p->feed_rc != BGS_OK && handover_index >= p->handed) return fail(p->feed_rc, "%s", p->feed_error.c_str());
+        NEED(handover_index >= 0 && handover_index < p->handed, "hand-over %lld has not been enqueued", (long long)handover_index);
+        h = (int)(handover_index % (int64_t)p->host.size());
+        NEED(p->held[h] == handover_index, "hand-over %lld is not in flight any more: its host array was reused by hand-over %lld",
+             (long long)handover_index, (long long)p->held[h]);
+        t = p->ticket[h];
+    }
+    if (t < 0) return BGS_OK;   // waited for before
+    int rc = wait_ticket(p, t);
+    if (rc == BGS_OK) {
+        std::lock_guard<std::mutex> lock(p->mu);
+        if (p->ticket[h] == t) p->ticket[h] = -1;
+    }
     return rc;
 }
 
@@ -244,6 +342,14 @@ int bgs_pipeline_drain(bgs_pipeline* p) {
     NEED(p != nullptr, "pipeline is NULL");
     HIP_TRY(hipSetDevice(p->device));
     int rc;
+    if (p->feeding) {
+        // what has been fed is enqueued first; every array is released (a drain ends the consumer's claim on them)
+        std::unique_lock<std::mutex> lock(p->mu);
+        p->released = p->handed + (int64_t)p->fed.size();
+        p->cv.notify_all();
+        p->cv.wait(lock, [&] { return p->fed.empty() || p->feed_rc != BGS_OK || p->stop; });
+        if (p->feed_rc != BGS_OK) return fail(p->feed_rc, "%s", p->feed_error.c_str());
+    }
     // the newest hand-over first: every waiter it turns urgent stays so until the last delivery is in
     int64_t newest = -1;
     for (int64_t t : p->ticket) newest = t > newest ? t : newest;
@@ -322,6 +428,16 @@ int bgs_pipeline_timeline(bgs_pipeline* p, float* start_ms, float* end_ms, int c
 int bgs_pipeline_destroy(bgs_pipeline* p) {
     if (!p) return BGS_OK;
     (void)hipSetDevice(p->device);
+    if (p->feeding) {   // (steps fed and not yet enqueued are dropped: nobody is there to consume them)
+        {
+            std::lock_guard<std::mutex> lock(p->mu);
+            p->stop = true;
+            p->fed.clear();
+        }
+        p->cv.notify_all();
+        if (p->feeder.joinable()) p->feeder.join();
+        p->feeding = false;
+    }
     (void)bgs_pipeline_drain(p);
     for (auto& h : p->syncers) {
         { std::lock_guard<std::mutex> lock(h->mu); h->cmd = 2; }

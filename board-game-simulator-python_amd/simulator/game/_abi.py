@@ -153,6 +153,8 @@ SIGNATURES = {
     "bgs_pipeline_enqueue": (ctypes.c_int, [c_handle, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "bgs_pipeline_enqueue_seeds": (ctypes.c_int, [c_handle, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
     "bgs_pipeline_wait": (ctypes.c_int, [c_handle, ctypes.c_int64]),
+    "bgs_pipeline_feed": (ctypes.c_int, [c_handle, ctypes.c_void_p, ctypes.c_int64]),
+    "bgs_pipeline_release": (ctypes.c_int, [c_handle, ctypes.c_int64]),
     "bgs_pipeline_drain": (ctypes.c_int, [c_handle]),
     "bgs_pipeline_progress": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "bgs_pipeline_kernel_ms": (ctypes.c_int, [c_handle, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),

@@ -78,6 +78,16 @@ class RolloutExecutor:
         _abi.check(_abi.lib().bgs_pipeline_enqueue_seeds(self._handle, ctypes.c_void_p(arr.ctypes.data), int(arr.size),
                                                          1 if handover else 0))
 
+    def feed(self, seeds) -> None:
+        """Hand the seeds of further steps to the pipeline's own feeder thread (`bgs_pipeline_feed`): it enqueues a step as
+        soon as the host array the step lands in has been released -- `release(j)` after `wait_handover(j)`."""
+        arr = np.ascontiguousarray(seeds, dtype=np.uint64)
+        _abi.check(_abi.lib().bgs_pipeline_feed(self._handle, ctypes.c_void_p(arr.ctypes.data), int(arr.size)))
+
+    def release(self, index: int) -> None:
+        """The caller is done with hand-over `index`'s host array (and with every earlier one)."""
+        _abi.check(_abi.lib().bgs_pipeline_release(self._handle, int(index)))
+
     def wait_handover(self, index: int) -> None:
         """Until hand-over number `index` is in its host array `host_arrays[index % len(host_arrays)]`."""
         _abi.check(_abi.lib().bgs_pipeline_wait(self._handle, int(index)))
@@ -245,35 +255,41 @@ class RolloutPipeline:
 
     # ---- the loop ----------------------------------------------------------------------------------
     def run(self, seeds: Iterable[int]) -> Iterator[Tuple[int, np.ndarray]]:
-        """Yield (step, rewards) for every seed, in order.  The launches run ahead of the consumer by up to
-        arrays_per_stream * depth steps and are enqueued in bursts (one library call per burst, not per step); the array
-        of a yielded step stays untouched until the consumer asks for the next one."""
+        """Yield (step, rewards) for every seed, in order.  The seeds are FED to the native loop (`bgs_pipeline_feed`): a
+        thread of the library's own enqueues a step as soon as the host array it lands in is free, up to
+        arrays_per_stream * depth steps ahead of the consumer, so this generator only waits for a step, yields its array
+        and releases it when the consumer comes back for the next one -- the launches are not made from Python at all
+        (round 4 made a Python call per step, round 5's first version a call per burst; both were bound by the interpreter
+        on a busy host).  The array of a yielded step stays untouched until the consumer asks for the next step."""
         it = iter(seeds)
-        burst = max(1, self.slots // 3)
         exhausted = False
         nxt = self._next          # the next step to yield
-        while True:
-            # steps [nxt, self._next) are in flight or delivered; the consumer holds nothing (it asked for the next step):
-            # everything up to nxt + slots may be enqueued without touching the array of a step that is still to be yielded
-            room = nxt + self.slots - self._next
-            if not exhausted and (room >= burst or self._next == nxt):
-                chunk = []
-                for seed in it:
-                    chunk.append(seed)
-                    if len(chunk) >= room:
-                        break
-                else:
-                    exhausted = True
-                self.submit_many(chunk)
-            if nxt >= self._next:
-                if exhausted:
-                    return
-                continue
-            rewards = self.result(nxt)
-            nxt += 1
-            # while the consumer holds the array of step nxt - 1, step nxt - 1 + slots must not be enqueued: `room` above
-            # is computed from nxt AFTER the consumer has come back
-            yield nxt - 1, rewards
+        try:
+            while True:
+                # keep a few hundred steps' worth of seeds with the feeder (it enqueues them as arrays come free)
+                if not exhausted and self._next - nxt < 2 * self.slots:
+                    chunk = []
+                    for seed in it:
+                        chunk.append(int(seed) & 0xFFFFFFFFFFFFFFFF)
+                        if len(chunk) >= 256:
+                            break
+                    else:
+                        exhausted = True
+                    if chunk:
+                        self._exe.feed(np.asarray(chunk, dtype=np.uint64))
+                        self._next += len(chunk)
+                if nxt >= self._next:
+                    if exhausted:
+                        return
+                    continue
+                self._exe.wait_handover(nxt)
+                yield nxt, self.host[nxt % self.slots]
+                self._exe.release(nxt)   # (the consumer is back: it is done with that array)
+                nxt += 1
+        finally:
+            # a consumer that stops early: whatever was fed is still played and delivered (its arrays are nobody's any more)
+            if nxt < self._next:
+                self._exe.drain()
 
     @property
     def env_steps(self) -> int:

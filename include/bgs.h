@@ -357,6 +357,15 @@ BGS_API int bgs_pipeline_enqueue(bgs_pipeline* p, int64_t count, int handover, i
 /* the same with the seed of every step given by the caller (seeds[i] for the i-th step of this call) instead of
  * seed0 + step index: a burst of a Python loop over arbitrary seeds (simulator.pipeline.RolloutPipeline.run) */
 BGS_API int bgs_pipeline_enqueue_seeds(bgs_pipeline* p, const uint64_t* seeds, int64_t count, int handover);
+/* The same for a consumer loop that cannot keep up with a launch per step itself (a Python generator): the seeds are FED, a
+ * thread of the pipeline's own enqueues a fed step as soon as the host array it lands in is free -- hand-over j waits until
+ * the caller has RELEASED hand-over j - n_host -- and the consumer only waits, reads, releases:
+ *     bgs_pipeline_feed(p, seeds, K);  for j: bgs_pipeline_wait(p, j); read host_rewards[j % n_host]; bgs_pipeline_release(p, j);
+ * bgs_pipeline_wait also waits for a fed hand-over to be enqueued; bgs_pipeline_drain enqueues and delivers whatever is
+ * still fed (and releases every array); bgs_pipeline_destroy drops what was fed and not yet enqueued.  Not for pipelines
+ * on a shared array (bgs_pipeline_set_ring).  Steps enqueued with bgs_pipeline_enqueue(_seeds) count as released. */
+BGS_API int bgs_pipeline_feed(bgs_pipeline* p, const uint64_t* seeds, int64_t count);
+BGS_API int bgs_pipeline_release(bgs_pipeline* p, int64_t handover_index);
 /* until hand-over number `handover_index` (0, 1, ... over the pipeline's life) is in its host array
  * host_rewards[handover_index % n_host]; BGS_ERR_ARG when a later hand-over has already reused that array */
 BGS_API int bgs_pipeline_wait(bgs_pipeline* p, int64_t handover_index);

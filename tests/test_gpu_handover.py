@@ -813,6 +813,39 @@ def test_rollout_pipeline_matches_the_oracle_step_by_step():
             np.testing.assert_array_equal(rewards, orc.reward, err_msg=f"bounce step {step}")
 
 
+def test_rollout_pipeline_feeder_survives_a_consumer_that_stops_early():
+    """`RolloutPipeline.run` feeds its seeds to the native loop's own thread (bgs_pipeline_feed / _release): a consumer
+    that breaks out of the loop after a few steps, starts a new loop, mixes in `submit` / `result`, and a slow consumer
+    that holds every array for a while -- every step it sees equals the oracle's for that seed."""
+    import time
+
+    from simulator.batch import ConnectBatch
+    from simulator.pipeline import RolloutPipeline
+
+    n = 3000
+
+    def want(seed):
+        orc = oracle.ConnectOracle(6, 7, 4, n)
+        orc.rollout(seed)
+        return orc.reward
+
+    with RolloutPipeline(ConnectBatch, (6, 7, 4), n, depth=2, host_threads=2) as pipe:
+        seen = []
+        for step, rewards in pipe.run(seeds=range(100, 140)):
+            np.testing.assert_array_equal(rewards, want(100 + step))
+            seen.append(step)
+            if len(seen) == 3:
+                break                      # 37 fed steps are still played and delivered, nobody reads them
+        assert seen == [0, 1, 2]
+        first = pipe._next                 # (steps fed so far: the next loop's indices go on from here)
+        for step, rewards in pipe.run(seeds=[7, 8, 9, 10, 11, 12, 13]):
+            time.sleep(0.002)              # a slow consumer: the feeder must not overwrite the array it is looking at
+            np.testing.assert_array_equal(rewards, want(7 + step - first), err_msg=f"second loop, step {step}")
+        i = pipe.submit(555)               # one step at a time still works beside it
+        np.testing.assert_array_equal(pipe.result(i), want(555))
+        assert sum(1 for _ in pipe.run(seeds=[])) == 0
+
+
 def test_policy_loop_replays_from_a_hip_graph(bm, torch_mod):
     """Policy-driven stepping (N2) captured once and replayed: legal mask on the device -> a torch policy -> bgs_step_actions
     with device actions are plain enqueues on the batch's stream (no allocation, no synchronisation), so torch.cuda.graphs

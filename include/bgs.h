@@ -95,7 +95,12 @@ BGS_API const char* bgs_kernel_unit_id(int unit);
 BGS_API int bgs_connect_arena_bytes(int height, int width, int count, int64_t n, size_t* bytes);
 BGS_API int bgs_connect_create(int height, int width, int count, int64_t n, int device, void* arena, size_t arena_bytes,
                        bgs_batch** out);
-/* replaces bounce::Config(grid) + Config::sample_initial_state (bounce.cpp:26,29); cfg_grid int8[height][width] host */
+/* replaces bounce::Config(grid) + Config::sample_initial_state (bounce.cpp:26,29); cfg_grid int8[height][width] host.
+ * Batches of 32768 boards and more (bit-packed boards, at most 16 pieces) also get the OPENING BOOK of their start position:
+ * every path of up to four plies from it, enumerated once per start position and device by the library's own move search
+ * and shared by the batches that have that start position -- the fused rollout's lanes start four plies in, with the
+ * game's own draws (results are those of searching every ply, bit for bit).  Device memory OUTSIDE the arena: 21.7 MB for
+ * the default 9x6 board, freed with the last batch that uses it.  BGS_BOUNCE_BOOK=0 switches it off. */
 BGS_API int bgs_bounce_arena_bytes(int height, int width, int64_t n, size_t* bytes);
 BGS_API int bgs_bounce_create(const int8_t* cfg_grid, int height, int width, int64_t n, int device, void* arena,
                       size_t arena_bytes, bgs_batch** out);

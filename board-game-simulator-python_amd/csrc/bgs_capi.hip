@@ -363,6 +363,15 @@ int device_facts(bgs_batch* b) {
         b->bounce_wave_pass = !(wave_pass && wave_pass[0] == '0');
         const char* epoch_limit = bgs::experiment("bounce_epoch_limit");
         b->bounce_epoch_limit = epoch_limit ? atoi(epoch_limit) : 0;
+        b->bounce_memo_cold = 4;      // (bounce_kernels.hip, K3w; "bounce_memo_policy=0:0": never without the memo)
+        b->bounce_memo_bypass = 28;
+        if (const char* policy = bgs::experiment("bounce_memo_policy")) {
+            int cold = 0, plies = 0;
+            if (sscanf(policy, "%d:%d", &cold, &plies) == 2 && cold >= 0 && plies >= 0 && plies <= 65535) {
+                b->bounce_memo_cold = cold > 0 ? cold : 0x7FFFFFFF;
+                b->bounce_memo_bypass = plies;
+            }
+        }
         b->bounce_passes = 0;
         b->bounce_plan_auto = strcmp(plan, "auto") == 0;
         if (!b->bounce_plan_auto && strcmp(plan, "single") != 0) {

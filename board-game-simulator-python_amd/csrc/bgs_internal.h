@@ -41,6 +41,7 @@ struct bgs_batch {
     int bounce_park;         // flat rollout: a draining wave parks its boards for its workgroup at this many or fewer (0..32; BGS_BOUNCE_PARK)
     int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (BGS_BOUNCE_CHUNK)
     int launches_in_flight;  // the caller's hint (bgs_set_launches_in_flight), 1 = one launch at a time: see bounce_shape()
+    int bounce_memo_cold, bounce_memo_bypass;  // K3w: after this many look-ups in a row that missed, this many plies without the memo (experiment "bounce_memo_policy=cold:plies")
     int bounce_epoch_limit;  // K3w: the memo starts over after this many replacements (0 = the 16 bits a link has; BGS_BOUNCE_EPOCH_LIMIT: the tests' way to reach the restart)
     int bounce_wave_pass;    // 1: the automatic plan ends with the one-board-per-wave pass (K3w); BGS_BOUNCE_WAVE_PASS=0 switches it off
     int bounce_plan_auto;    // 1: the library chooses between one launch and bulk + tail passes (BGS_BOUNCE_PLAN unset or "auto")

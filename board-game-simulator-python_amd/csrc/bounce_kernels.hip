@@ -1934,7 +1934,14 @@ __device__ __forceinline__ void enumerate_wave(const BounceGeom& g, const Board&
     const uint64_t occ = occupancy(b);
     const uint32_t pieces = (uint32_t)__popcll(occ);          // (uniform; <= PMAX: the host only sends such boards)
     const bool alive = lane < pieces;
-    const uint32_t cell = alive ? select_bit64(occ, lane) : 0u;
+    // the cell of the lane-th piece.  The board is the same on every lane, so lane c knows whether cell c is occupied and how
+    // many pieces stand below it (two v_mbcnt on the occupancy) -- the number of the lane that wants to know -- and tells it
+    // with ONE forward permute; the popcount-guided search for the lane-th set bit is forty instructions (round 5)
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(occ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)occ, 0u));
+    const bool occupied = ((occ >> lane) & 1ull) != 0ull;
+    static_assert(PMAX < 63, "lane 63 takes what the empty cells send");
+    const uint32_t told = (uint32_t)__builtin_amdgcn_ds_permute((int)((occupied ? below : 63u) << 2), (int)lane);
+    const uint32_t cell = alive ? told : 0u;
     const uint32_t value = alive ? value_at(b, (int)cell) : 0u;
     m.cell = cell;
     const uint64_t empty_interior = ~occ & g.interior;
@@ -2003,7 +2010,7 @@ __global__ void __launch_bounds__(BGS_WAVE)
 k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                       uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
                       unsigned long long* __restrict__ steps, const uint32_t* __restrict__ worklist,
-                      const uint32_t* __restrict__ work_count, uint32_t epoch_limit) {
+                      const uint32_t* __restrict__ work_count, uint32_t epoch_limit, uint32_t cold_limit, uint32_t bypass_plies) {
     static_assert(PMAX <= 16, "the prefix sum runs over one 16-lane row");
     __builtin_amdgcn_s_setprio(3);   // (see k_bounce_rollout: these waves are the launch's critical path)
     const uint32_t lane = threadIdx.x & 63u;
@@ -2054,9 +2061,23 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
         }
         const uint32_t first_ply = plies;
         WaveMoves mv;
-        Philox4 blk;
-        blk.v[0] = blk.v[1] = blk.v[2] = blk.v[3] = 0;
-        bool have_block = false;
+        // The words of the plies to come.  The board is one, the lanes are 64: lane l keeps the word of ply `ahead_first` + l
+        // (its own philox call, for the block that ply lies in), so one call's latency buys the words of 64 plies, and a
+        // ply's word is ONE v_readlane away -- a scalar.  That matters beyond the philox calls it saves (one every four
+        // plies on all lanes alike, a third of a hop's dependent chain): bgs_common.h's philox_word selects its word
+        // through vector registers on purpose, which made the word -- and with it the sampled index, the link, the loop
+        // exits and the ply count of this whole loop -- divergent in the compiler's eyes: every hop ran as masked vector
+        // code.  With the word a scalar the hop is scalar arithmetic around one LDS look-up (round 5).
+        uint32_t ahead = 0u;
+        uint32_t ahead_first = 0x80000000u;   // (uniform; nothing computed yet: every ply -- at most 65535 -- is "64 or more past it")
+        auto word_at = [&](uint32_t ply) -> uint32_t {
+            if (ply - ahead_first >= (uint32_t)BGS_WAVE) {   // (unsigned: also a ply below the window)
+                ahead_first = ply & ~3u;
+                const Philox4 mine = philox4x32_10(seed, first_game + (uint64_t)game, (ahead_first >> 2) + (lane >> 2));
+                ahead = philox_word(mine, lane);
+            }
+            return (uint32_t)__builtin_amdgcn_readlane((int)ahead, (int)(ply - ahead_first));
+        };
         // One enumeration site.  `side` is whose action list is built next; after a move it is the other player's, and
         // an empty list there means the game is over: the mover wins if HE could still move, else it is a draw -- one more
         // enumeration, for the mover (`blocked`).  A board that arrives blocked is settled by the same rule with the
@@ -2064,7 +2085,19 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
         uint32_t side = plies & 1u;
         bool blocked = false;
         uint32_t came_from = 0xFFFFFFFFu, came_by = 0;   // the slot and the action that led to the position about to be looked up
+        // The memo pays for games that stay among a few positions; a long game that WANDERS misses on every ply and pays for
+        // the look-up, the fill and the link bookkeeping all the same: a fifth of its ply (the longest such game, a few hundred
+        // plies, is what most launches of this kernel wait for -- an endless game hops through its 4000 plies in less).  So
+        // after `cold_limit` look-ups in a row that missed the wave plays `bypass_plies` plies without the memo, then looks
+        // again: a game that has settled into a cycle is found out within that many plies.
+        uint32_t cold = 0, bypass = 0, slot = 0;
+        auto same = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
         for (;;) {
+            // (the state of the ONE game this wave plays is the same on every lane; saying so keeps it in scalar registers
+            // and its tests on the scalar unit -- the compiler cannot see it through the loop's memory and lane traffic)
+            plies = same(plies);
+            side = same(side);
+            epoch = same(epoch);
             // The games this pass exists for do not wander: the one endless game of a 2^18-board batch of the default start
             // visits 27 positions in 4096 plies, four of them in its last 2000 (tools/bounce_endless.py).  The action list of a
             // position is a function of the position, so the wave keeps the lists it has built in LDS, keyed by the board and
@@ -2072,6 +2105,11 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             // on a known position costs a look-up instead of the search.  32 sets of two ways, the way not used last is
             // replaced: direct-mapped, two of a game's handful of hot positions shared a slot in one launch of ten and every
             // ply of that game missed (4.7 ms against 2.5).
+            const bool with_memo = bypass == 0u;
+            if (!with_memo) {
+                --bypass;
+                enumerate_wave<PMAX>(g, b, side, mv);
+            } else {
             uint32_t set;
             {
                 uint32_t h = (uint32_t)b.v[0] * 0x9E3779B1u ^ (uint32_t)(b.v[0] >> 32) * 0x85EBCA77u;
@@ -2095,8 +2133,9 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             }
             const uint32_t found = (uint32_t)__builtin_amdgcn_readfirstlane((int)((differ0 == 0u ? 1u : 0u) | (differ1 == 0u ? 2u : 0u)));
             const uint32_t way = found ? found >> 1 : ((uint32_t)__builtin_amdgcn_readfirstlane((int)last) ^ 1u) & 1u;   // hit, or the victim
-            const uint32_t slot = w0 + way;
+            slot = w0 + way;
             if (found) {
+                cold = 0;
                 const uint32_t at = lane < (uint32_t)PMAX ? lane : 0u;
                 const uint32_t packed = memo_lane[slot][at];
                 mv.targets = lane < (uint32_t)PMAX ? memo_targets[slot][at] : 0ull;
@@ -2132,6 +2171,11 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
                     memo_last[set] = way;
                 }
                 __syncthreads();   // (uniform branch, one wave: lane 0's stores before anybody's next look-up)
+                if (++cold >= cold_limit) {
+                    cold = 0;
+                    bypass = bypass_plies;
+                }
+            }
             }
             if (came_from != 0xFFFFFFFFu) {
                 // the move played last led HERE: remember it (unless this very look-up evicted the position it was played from)
@@ -2151,23 +2195,22 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
                 continue;
             }
             if (plies >= max_plies) break;
-            if (!have_block || (plies & 3u) == 0u) {
-                blk = philox4x32_10(seed, first_game + (uint64_t)game, plies >> 2);
-                have_block = true;
-            }
-            const uint32_t idx = sample_index(philox_word(blk, plies), mv.n);
+            const uint32_t idx = sample_index(word_at(plies), mv.n);
             {
                 // does the sampled action have a link?  Then hop: the successor's slot and the number of its actions are in
                 // the link, its own links are one look-up away -- the board stays behind until a hop has no link (or the
                 // ply cap is reached), and is then taken from the memo's key of the position the hops ended on
-                uint32_t link = idx < kWaveLinks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)memo_link[slot][idx]) : 0u;
+                uint32_t link = with_memo && idx < kWaveLinks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)memo_link[slot][idx]) : 0u;
                 if ((link >> 16) == epoch && ((link >> 8) & 255u) != 0u) {
                     uint32_t at = link & 255u, n_at = (link >> 8) & 255u;
+                    cold = 0;
                     ++plies;
                     side = 1u - side;
                     while (plies < max_plies) {
-                        if ((plies & 3u) == 0u) blk = philox4x32_10(seed, first_game + (uint64_t)game, plies >> 2);
-                        const uint32_t next = sample_index(philox_word(blk, plies), n_at);
+                        plies = same(plies);
+                        at = same(at);
+                        n_at = same(n_at);
+                        const uint32_t next = sample_index(word_at(plies), n_at);
                         link = next < kWaveLinks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)memo_link[at][next]) : 0u;
                         if ((link >> 16) != epoch || ((link >> 8) & 255u) == 0u) break;
                         at = link & 255u;
@@ -2181,16 +2224,20 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
                         b.v[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(word >> 32)) << 32) |
                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
                     }
-                    have_block = (plies & 3u) != 0u;   // (the block in hand is the current one unless a new one is due)
                     continue;   // the look-up at the top finds this position, and the ply goes on from its lists
                 }
             }
-            const uint32_t k = idx - mv.before;
-            const bool here = k < mv.count;   // (unsigned: idx < before wraps; count is 0 on every lane that is no source)
-            uint32_t pair = here ? (mv.cell | (select_bit64(mv.targets, here ? k : 0u) << 8)) : 0u;
-            const uint64_t owner = __builtin_amdgcn_ballot_w64(here);   // exactly one lane
-            pair = (uint32_t)__builtin_amdgcn_readlane((int)pair, (__ffsll((unsigned long long)owner) - 1) & 63);
-            const int s = (int)(pair & 255u), t = (int)(pair >> 8);
+            const bool here = idx - mv.before < mv.count;   // (unsigned: idx < before wraps; count is 0 on every lane that is no source)
+            const uint64_t owner = __builtin_amdgcn_ballot_w64(here);   // exactly one lane: the source
+            const int from = (__ffsll((unsigned long long)owner) - 1) & 63;
+            // its k-th target, found by the CELLS: lane c counts the targets below cell c; the one target cell whose count is k
+            // is it (a dozen instructions, most of them scalar, against the forty of the search for the k-th set bit)
+            const uint32_t k = idx - (uint32_t)__builtin_amdgcn_readlane((int)mv.before, from);
+            const uint32_t t_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv.targets, from);
+            const uint32_t t_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv.targets >> 32), from);
+            const uint64_t kth = __builtin_amdgcn_ballot_w64(__builtin_amdgcn_mbcnt_hi(t_hi, __builtin_amdgcn_mbcnt_lo(t_lo, 0u)) == k) &
+                                 (((uint64_t)t_hi << 32) | t_lo);
+            const int s = __builtin_amdgcn_readlane((int)mv.cell, from), t = __ffsll((unsigned long long)kth) - 1;
             move_piece(b, s, t);
             ++plies;
             if ((1ull << t) & (g.goal_top | g.goal_bottom)) {
@@ -2198,7 +2245,7 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
                 break;
             }
             side = 1u - side;
-            came_from = slot;
+            came_from = with_memo ? slot : 0xFFFFFFFFu;
             came_by = idx;
         }
         if (lane == 0u) {
@@ -2358,7 +2405,8 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
             hipLaunchKernelGGL((k_bounce_rollout_wave<PMAX>), dim3(wave_grid), dim3(BGS_WAVE), 0,
                                b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
                                seed, b->first_game, cap, b->d_steps, worklist, work_count,
-                               b->bounce_epoch_limit >= 2 && b->bounce_epoch_limit < (int)kWaveEpochLimit ? (uint32_t)b->bounce_epoch_limit : kWaveEpochLimit);
+                               b->bounce_epoch_limit >= 2 && b->bounce_epoch_limit < (int)kWaveEpochLimit ? (uint32_t)b->bounce_epoch_limit : kWaveEpochLimit,
+                               (uint32_t)b->bounce_memo_cold, (uint32_t)b->bounce_memo_bypass);
         };
         // (from_initial here: every board of the rollout descends from the configured start position, so none holds more
         // pieces than it; otherwise 16 lanes, and a board with more than that is played by lane 0)

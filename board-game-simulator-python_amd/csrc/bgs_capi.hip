@@ -368,7 +368,7 @@ int device_facts(bgs_batch* b) {
         if (const char* policy = bgs::experiment("bounce_memo_policy")) {
             int cold = 0, plies = 0;
             if (sscanf(policy, "%d:%d", &cold, &plies) == 2 && cold >= 0 && plies >= 0 && plies <= 65535) {
-                b->bounce_memo_cold = cold > 0 ? cold : 0x7FFFFFFF;
+                b->bounce_memo_cold = cold > 0 ? cold : 0x3FFFFFFF;
                 b->bounce_memo_bypass = plies;
             }
         }

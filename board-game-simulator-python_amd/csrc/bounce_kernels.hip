@@ -2025,11 +2025,13 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
     // A link holds as long as no remembered position has been replaced since it was written (`epoch` counts those; a slot's
     // row is cleared when the slot is filled).  A game that never ends hops along them -- one LDS look-up, a sample, no
     // board -- for as long as the sampled action has a link: 0.13 us a ply where the look-up of the position costs 0.55.
-    __shared__ uint32_t memo_link[kWaveMemoSlots][kWaveLinks];
+    // (a row has one more word than links, always 0: "no link" for an action beyond the row, read without a test)
+    __shared__ uint32_t memo_link[kWaveMemoSlots][kWaveLinks + 1u];
     uint32_t epoch = 1;
     for (uint32_t e = lane; e < kWaveMemoSlots; e += BGS_WAVE) {
         memo_tag[e] = 0xFFFFFFFFu;   // (no side is 0xFFFFFFFF)
         memo_last[e >> 1] = 1u;
+        memo_link[e][kWaveLinks] = 0u;
     }
     __syncthreads();   // (one wave: orders the LDS accesses of its lanes)
     const uint32_t total = *work_count;
@@ -2089,8 +2091,9 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
         // the look-up, the fill and the link bookkeeping all the same: a fifth of its ply (the longest such game, a few hundred
         // plies, is what most launches of this kernel wait for -- an endless game hops through its 4000 plies in less).  So
         // after `cold_limit` look-ups in a row that missed the wave plays `bypass_plies` plies without the memo, then looks
-        // again: a game that has settled into a cycle is found out within that many plies.
-        uint32_t cold = 0, bypass = 0, slot = 0;
+        // again: a game that has settled into a cycle is found out within that many plies.  (Twice the limit for a game's first
+        // look-ups: the memo may know nothing of it yet, and a game that arrives cycling should not sit out a bypass first.)
+        uint32_t cold = 0, bypass = 0, slot = 0, cold_now = 2u * cold_limit;
         auto same = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
         for (;;) {
             // (the state of the ONE game this wave plays is the same on every lane; saying so keeps it in scalar registers
@@ -2171,8 +2174,9 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
                     memo_last[set] = way;
                 }
                 __syncthreads();   // (uniform branch, one wave: lane 0's stores before anybody's next look-up)
-                if (++cold >= cold_limit) {
+                if (++cold >= cold_now) {
                     cold = 0;
+                    cold_now = cold_limit;
                     bypass = bypass_plies;
                 }
             }
@@ -2180,7 +2184,8 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             if (came_from != 0xFFFFFFFFu) {
                 // the move played last led HERE: remember it (unless this very look-up evicted the position it was played from)
                 if (came_from != slot && came_by < kWaveLinks) {
-                    if (lane == 0u) memo_link[came_from][came_by] = (epoch << 16) | ((mv.n <= 255u ? mv.n : 0u) << 8) | slot;
+                    // (a successor without actions -- the game ends there -- or with more than a byte holds gets no link: 0)
+                    if (lane == 0u) memo_link[came_from][came_by] = mv.n - 1u < 255u ? (epoch << 16) | (mv.n << 8) | slot : 0u;
                     __syncthreads();
                 }
                 came_from = 0xFFFFFFFFu;
@@ -2196,28 +2201,26 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             }
             if (plies >= max_plies) break;
             const uint32_t idx = sample_index(word_at(plies), mv.n);
-            {
+            if (with_memo) {
                 // does the sampled action have a link?  Then hop: the successor's slot and the number of its actions are in
                 // the link, its own links are one look-up away -- the board stays behind until a hop has no link (or the
-                // ply cap is reached), and is then taken from the memo's key of the position the hops ended on
-                uint32_t link = with_memo && idx < kWaveLinks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)memo_link[slot][idx]) : 0u;
-                if ((link >> 16) == epoch && ((link >> 8) & 255u) != 0u) {
-                    uint32_t at = link & 255u, n_at = (link >> 8) & 255u;
-                    cold = 0;
+                // ply cap is reached), and is then taken from the memo's key of the position the hops ended on.  A hop is a
+                // chain of dependent steps on a wave that has the SIMD to itself, so it is written for few of them: one test
+                // per link (a link is valid iff it carries the current epoch: 0, the empty word, never does), the row's extra
+                // word instead of "is the action inside the row".
+                uint32_t at = slot, next = idx;
+                const uint32_t ply0 = plies;
+                for (;;) {
+                    const uint32_t link = same(memo_link[at][next < kWaveLinks ? next : kWaveLinks]);
+                    if ((link >> 16) != epoch) break;
+                    at = link & 255u;
                     ++plies;
-                    side = 1u - side;
-                    while (plies < max_plies) {
-                        plies = same(plies);
-                        at = same(at);
-                        n_at = same(n_at);
-                        const uint32_t next = sample_index(word_at(plies), n_at);
-                        link = next < kWaveLinks ? (uint32_t)__builtin_amdgcn_readfirstlane((int)memo_link[at][next]) : 0u;
-                        if ((link >> 16) != epoch || ((link >> 8) & 255u) == 0u) break;
-                        at = link & 255u;
-                        n_at = (link >> 8) & 255u;
-                        ++plies;
-                        side = 1u - side;
-                    }
+                    if (plies >= max_plies) break;
+                    next = sample_index(word_at(plies), (link >> 8) & 255u);
+                }
+                if (plies != ply0) {
+                    cold = 0;
+                    side ^= (plies - ply0) & 1u;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const uint64_t word = memo_key[at][j];

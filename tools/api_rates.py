@@ -6,6 +6,7 @@ array, for BASELINE configs 2, 3 and 4, through
              enqueues its launches in bursts through the native loop (bgs_pipeline_enqueue_seeds) and waits per step;
   executor   `RolloutExecutor.enqueue(K); drain()`: the whole region as one library call (what bench.py times).
 One child process per (config, level): the hardware queues a deep Bounce pipeline needs are asked for before HIP starts.
+Every level is timed over three regions and the median is reported (`values_of_3` holds all three), as bench.py does.
 
     python3 tools/api_rates.py > profiles/r05_api_rates.json"""
 import json, os, subprocess, sys, time
@@ -36,13 +37,14 @@ def child(name, level):
         for s in range(3):
             b.rollout(SEED + s, max_plies=max_plies, from_initial=True)
             b.reward
-        b.reset_steps()
-        t0 = time.perf_counter()
-        for s in range(steps):
-            b.rollout(SEED + 10 + s, max_plies=max_plies, from_initial=True)
-            r = b.reward
-        dt = time.perf_counter() - t0
-        done = b.steps
+        regions = []
+        for rep_ in range(3):   # three timed regions, the median reported (bench.py's way: a busy host stalls a region now and then)
+            b.reset_steps()
+            t0 = time.perf_counter()
+            for s in range(steps):
+                b.rollout(SEED + 10 + s, max_plies=max_plies, from_initial=True)
+                r = b.reward
+            regions.append((b.steps, time.perf_counter() - t0))
     elif level == "pipeline":
         with pipeline.RolloutPipeline(cls, args, n, max_plies=max_plies) as pipe:
             for _ in pipe.run(range(4 * depth)):
@@ -51,13 +53,14 @@ def child(name, level):
             while time.perf_counter() < t_end:
                 for _ in pipe.run(range(100, 100 + 2 * depth)):
                     pass
-            before = pipe.env_steps
-            t0 = time.perf_counter()
-            check = 0
-            for step, rewards in pipe.run(range(1000, 1000 + steps)):
-                check += int(rewards[step % 1024, 0])   # (touch the result)
-            dt = time.perf_counter() - t0
-            done = pipe.env_steps - before
+            regions = []
+            for rep_ in range(3):
+                before = pipe.env_steps
+                t0 = time.perf_counter()
+                check = 0
+                for step, rewards in pipe.run(range(1000 * (rep_ + 1), 1000 * (rep_ + 1) + steps)):
+                    check += int(rewards[step % 1024, 0])   # (touch the result)
+                regions.append((pipe.env_steps - before, time.perf_counter() - t0))
             depth = pipe.depth
     else:
         import torch
@@ -76,18 +79,22 @@ def child(name, level):
         while time.perf_counter() < t_end:
             exe.enqueue(2 * depth)
             exe.drain()
-        for b in batches:
-            b.reset_steps()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        exe.enqueue(steps)
-        exe.drain()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        done = sum(b.steps for b in batches)
+        regions = []
+        for rep_ in range(3):
+            for b in batches:
+                b.reset_steps()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            exe.enqueue(steps)
+            exe.drain()
+            torch.cuda.synchronize()
+            regions.append((sum(b.steps for b in batches), time.perf_counter() - t0))
         exe.close()
         sink.close()
-    print(json.dumps({"value": done / dt, "unit": "env-steps/s", "steps": steps, "us_per_step": dt / steps * 1e6, "in_flight": 1 if level == "naive" else depth}))
+    rates = sorted(done / dt for done, dt in regions)
+    done, dt = sorted(regions, key=lambda r: r[0] / r[1])[1]
+    print(json.dumps({"value": done / dt, "values_of_3": rates, "unit": "env-steps/s", "steps": steps, "us_per_step": dt / steps * 1e6,
+                      "in_flight": 1 if level == "naive" else depth}))
 
 
 def main():

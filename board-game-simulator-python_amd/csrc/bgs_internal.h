@@ -29,29 +29,29 @@ struct bgs_batch {
     int planes;              // uint64 planes per board
     int num_cus;             // compute units of the device
     int rollout_wps;         // waves per SIMD the fused rollout is sized for
-    int bounce_group;        // lanes per board of a single-launch Bounce rollout: 8 (small batches) or 1 (BGS_BOUNCE_GROUP)
+    int bounce_group;        // lanes per board of a single-launch Bounce rollout: 8 (small batches) or 1 (experiment bounce_group)
     int bounce_group_auto;   // 1: not set from the environment (bounce_rollout may still choose by the launches in flight)
-    int bounce_flat;         // 1: one-lane-per-board Bounce rollouts use the flattened search (BGS_BOUNCE_FLAT=0: nested loops)
-    int bounce_pieces;       // 1: from-initial flat rollouts run on the piece list (K3p; BGS_BOUNCE_PIECES=0: K3f)
-    int bounce_block;        // K3p: threads per workgroup, 256 / 512 / 1024 (BGS_BOUNCE_BLOCK): the waves of a workgroup share their drain
-    int bounce_flat_wps;     // waves per SIMD of a flat Bounce rollout launch (BGS_BOUNCE_FLAT_WPS)
-    int bounce_flat_waves;   // > 0: that many waves per launch instead (BGS_BOUNCE_FLAT_WAVES)
-    int bounce_pool;         // K3p: the last wave of a workgroup parks its boards for other workgroups (BGS_BOUNCE_POOL=0: off)
-    int bounce_pieces_park;  // K3p: a draining wave parks its boards at this many or fewer (0..63; BGS_BOUNCE_PIECES_PARK, default: BGS_BOUNCE_PARK)
-    int bounce_park;         // flat rollout: a draining wave parks its boards for its workgroup at this many or fewer (0..32; BGS_BOUNCE_PARK)
-    int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (BGS_BOUNCE_CHUNK)
+    int bounce_flat;         // 1: one-lane-per-board Bounce rollouts use the flattened search (experiment bounce_flat=0: nested loops)
+    int bounce_pieces;       // 1: from-initial flat rollouts run on the piece list (K3p; experiment bounce_pieces=0: K3f)
+    int bounce_block;        // K3p: threads per workgroup, 256 / 512 / 1024 (experiment bounce_block): the waves of a workgroup share their drain
+    int bounce_flat_wps;     // waves per SIMD of a flat Bounce rollout launch (experiment bounce_flat_wps)
+    int bounce_flat_waves;   // > 0: that many waves per launch instead (experiment bounce_flat_waves)
+    int bounce_pool;         // K3p: the last wave of a workgroup parks its boards for other workgroups (experiment bounce_pool=0: off)
+    int bounce_pieces_park;  // K3p: a draining wave parks its boards at this many or fewer (0..63; experiment bounce_pieces_park, default: experiment bounce_park)
+    int bounce_park;         // flat rollout: a draining wave parks its boards for its workgroup at this many or fewer (0..32; experiment bounce_park)
+    int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (experiment bounce_chunk)
     int launches_in_flight;  // the caller's hint (bgs_set_launches_in_flight), 1 = one launch at a time: see bounce_shape()
     int bounce_memo_cold, bounce_memo_bypass;  // K3w: after this many look-ups in a row that missed, this many plies without the memo (experiment "bounce_memo_policy=cold:plies")
-    int bounce_epoch_limit;  // K3w: the memo starts over after this many replacements (0 = the 16 bits a link has; BGS_BOUNCE_EPOCH_LIMIT: the tests' way to reach the restart)
-    int bounce_wave_pass;    // 1: the automatic plan ends with the one-board-per-wave pass (K3w); BGS_BOUNCE_WAVE_PASS=0 switches it off
-    int bounce_plan_auto;    // 1: the library chooses between one launch and bulk + tail passes (BGS_BOUNCE_PLAN unset or "auto")
+    int bounce_epoch_limit;  // K3w: the memo starts over after this many replacements (0 = the 16 bits a link has; experiment bounce_epoch_limit: the tests' way to reach the restart)
+    int bounce_wave_pass;    // 1: the automatic plan ends with the one-board-per-wave pass (K3w); experiment bounce_wave_pass=0 switches it off
+    int bounce_plan_auto;    // 1: the library chooses between one launch and bulk + tail passes (experiment bounce_plan unset or "auto")
     int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board
     uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];
     int bounce_pass_group[BGS_BOUNCE_MAX_PASSES];
-    int rollout_generic;     // 1: never take the block-aligned from-initial kernel (A/B timing, BGS_ROLLOUT_GENERIC)
-    int rollout_chunk;       // games per wave of the fused rollout, 0 = derived from rollout_wps (BGS_ROLLOUT_CHUNK)
-    int rollout_opening;     // opening blocks of the from-initial one-word rollout: 0 = K2a, 1..4, default 3 (BGS_ROLLOUT_OPENING)
-    int rollout_no_lds;      // 1: large boards stay in registers (K2b) instead of the LDS-staged kernel (BGS_ROLLOUT_NO_LDS)
+    int rollout_generic;     // 1: never take the block-aligned from-initial kernel (A/B timing, experiment rollout_generic)
+    int rollout_chunk;       // games per wave of the fused rollout, 0 = derived from rollout_wps (experiment rollout_chunk)
+    int rollout_opening;     // opening blocks of the from-initial one-word rollout: 0 = K2a, 1..4, default 3 (experiment rollout_opening)
+    int rollout_no_lds;      // 1: large boards stay in registers (K2b) instead of the LDS-staged kernel (experiment rollout_no_lds)
     // device buffers (inside the arena)
     void* arena;
     size_t arena_bytes;

@@ -2528,7 +2528,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
 // The automatic plan is two passes: the kernel that suits the batch (K3p / K3f with one lane per board for large ones:
 // fewest instructions per ply; 8 lanes per board for small ones) up to a short cap, then ONE BOARD PER WAVE (K3w: the
 // shortest ply, and a memo of action lists -- what a handful of very long games is bound by).  Start positions of more
-// than 16 pieces keep round 3's plan (one launch, or K3p + an 8-lane tail).  BGS_BOUNCE_PLAN="cap:lanes,..." overrides.
+// than 16 pieces keep round 3's plan (one launch, or K3p + an 8-lane tail).  BGS_EXPERIMENT "bounce_plan=cap:lanes,..." overrides.
 void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) {
     uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
     if (cap > kMaxPlies) cap = kMaxPlies;  // plies are stored as uint16
@@ -2569,7 +2569,7 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
             // ... by ONE BOARD PER WAVE (K3w) where it can take them: its ply is shorter still, and it remembers the action lists
             // of the positions it has seen, which is what a game that never ends consists of.  Measured (tools/k3w_probe.sh,
             // 2^18 default boards): one launch at a time 1.40 -> 1.92-2.09 x 10^9 env-steps/s, 20 in flight 1.42 -> 1.54-1.57 x
-            // 10^10; an 8-lane pass in between (to 2x / 4x the bulk cap) reads the same.  BGS_BOUNCE_WAVE_PASS=0: the 8-lane
+            // 10^10; an 8-lane pass in between (to 2x / 4x the bulk cap) reads the same.  experiment bounce_wave_pass=0: the 8-lane
             // tail as before.
             pass_group_of[1] = wave_tail ? 64 : 8;
         } else if (b->bounce_plan_auto && wave_tail) {
@@ -2589,7 +2589,7 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
         for (int i = 1; i < passes; ++i)   // (a plan from the environment: K3w only where the configured position fits its lanes)
             if (pass_group_of[i] == 64 && !(b->bg.piece_count >= 1 && b->bg.piece_count <= BGS_BOUNCE_MAX_PIECES)) pass_group_of[i] = 8;
         if (passes >= 1 && pass_group_of[0] == 64) pass_group_of[0] = 1;
-        if (passes <= 1) {  // single launch (BGS_BOUNCE_PLAN=single, a plan with one entry, a ply cap too short for two passes)
+        if (passes <= 1) {  // single launch (experiment bounce_plan=single, a plan with one entry, a ply cap too short for two passes)
             launch_rollout(b, seed, cap, from_initial, lanes, lanes == 1 ? b->rollout_wps : 8, nullptr, nullptr, queues);
             return;
         }

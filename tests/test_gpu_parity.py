@@ -830,13 +830,18 @@ def test_bounce_games_that_never_end(batch_mod, seed_offset, first_game):
     dev.close()
 
 
+@pytest.mark.parametrize("policy", ["0:0", "4:28", "1:3"])
 @pytest.mark.parametrize("limit", ["2", "3", "7"])
-def test_bounce_memo_starts_over_when_its_epochs_run_out(batch_mod, monkeypatch, limit):
+def test_bounce_memo_starts_over_when_its_epochs_run_out(batch_mod, monkeypatch, limit, policy):
     """Round-4 advisor: a link of K3w's memo holds its epoch in 16 bits, and when the count of replacements reaches the
     limit the memo starts over empty -- stale rows of links are left behind and must not be followed.  2^16 replacements
     do not happen in a test, so BGS_EXPERIMENT=bounce_epoch_limit=<n> brings the restart within reach: a few waves, each playing a dozen
-    boards -- among them a game that never ends -- replace remembered positions all the time."""
+    boards -- among them a game that never ends -- replace remembered positions all the time.
+    Round 5: a game whose look-ups keep missing plays some plies WITHOUT the memo (bounce_memo_policy=misses:plies; default
+    4:28).  "0:0" keeps the memo on every ply (the most replacements, as in round 4), "1:3" switches between the two modes
+    all the time -- links written before a stretch without the memo must still be right after it."""
     monkeypatch.setitem(knobs, "bounce_epoch_limit", limit)
+    monkeypatch.setitem(knobs, "bounce_memo_policy", policy)
     monkeypatch.setitem(knobs, "bounce_wave_grid", "4")
     n = 48
     for seed_offset, first_game, cap in ((0, 196997, 4096), (5, 2278, 1500)):

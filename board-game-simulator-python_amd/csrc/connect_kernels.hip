@@ -610,6 +610,21 @@ __device__ __forceinline__ uint32_t select_bit64(uint64_t m, uint32_t k) {
 // with one always-empty sentinel bit on top of every column, (stones + column bottoms) carries through the stones of
 // each column and leaves exactly one bit per column, on the cell the next stone would take -- masked to the real
 // cells that is the list of legal moves AND the stone positions, and the idx-th legal column is its idx-th set bit.
+// The idx-th set bit of `landing` (K1s): `landing` holds at most ONE bit per column field of S = h + 1 bits and never a field's
+// top bit, so the search is arithmetic on the fields instead of the general popcount-guided search (forty instructions of
+// the ply's hundred and fifty; round 5): a field is non-empty iff adding 2^(S-1) - 1 carries into its top bit; the number
+// of non-empty fields up to field x is field x of (flags * bottoms) -- no carries between fields: a count is at most w --
+// and field x of (idx - flags) * bottoms + tops keeps its top bit iff fewer than idx + 1 non-empty fields lie at or below x,
+// i.e. iff the column sought lies above x: their number is that column.  K2a's nibble search, on fields of S bits.
+// Needs w <= 2^(S-1) = 2^h (the counts must fit under a field's top bit): play_plies asks.
+__device__ __forceinline__ uint32_t select_landing(uint64_t landing, uint64_t bottoms, uint64_t tops, uint32_t stride, uint32_t idx) {
+    const uint64_t flags = ((landing + (tops - bottoms)) & tops) >> (stride - 1u);
+    const uint64_t cmp = ((uint64_t)idx - flags) * bottoms + tops;
+    const uint32_t col = (uint32_t)__popcll(cmp & tops);
+    const uint64_t low = (1ull << stride) - 1ull;   // (uniform: a field's bits)
+    return (uint32_t)__ffsll((unsigned long long)(landing & (low << (col * stride)))) - 1u;
+}
+
 template <bool SINGLE, class G>
 __device__ __forceinline__ uint32_t play_plies(const G& g, uint64_t bottoms, uint64_t cells, uint64_t& p0, uint64_t& p1,
                                                uint32_t& st, uint64_t seed, uint64_t game, uint32_t count) {
@@ -622,7 +637,10 @@ __device__ __forceinline__ uint32_t play_plies(const G& g, uint64_t bottoms, uin
     for (uint32_t q = 0; q < count; ++q) {
         const uint64_t landing = ((p0 | p1) + bottoms) & cells;
         const uint32_t idx = sample_index(sub_draw(connect_word(blk, ply), ply & 3u), (uint32_t)__popcll(landing));
-        const uint32_t pos = select_bit64(landing, idx);
+        // (uniform; compile time for a static geometry.  Tall one-column boards keep the general search: fields of up to 16 bits)
+        const bool by_fields = g.h() <= 15 && (uint32_t)g.w() <= (1u << g.h());
+        const uint32_t pos = by_fields ? select_landing(landing, bottoms, bottoms << g.h(), (uint32_t)g.h() + 1u, idx)
+                                       : select_bit64(landing, idx);
         const bool second = ply & 1u;
         uint64_t mine = (second ? p1 : p0) | (1ull << pos);
         p0 = second ? p0 : mine;

@@ -72,7 +72,11 @@ def test_connect_step_random_lockstep(batch_mod, h, w, k):
 
 
 @pytest.mark.parametrize("h,w,k,n", [(6, 7, 4, 5000), (6, 7, 4, 4999), (2, 3, 2, 64), (4, 5, 3, 1002), (8, 8, 4, 770),
-                                     (7, 8, 5, 300), (12, 13, 5, 500), (1, 6, 2, 130)])
+                                     (7, 8, 5, 300), (12, 13, 5, 500), (1, 6, 2, 130),
+                                     # the streaming kernel finds the sampled column by arithmetic on the column fields when the
+                                     # column count fits under a field's top bit (w <= 2^h, h <= 15), else by the general search:
+                                     (3, 8, 3, 600), (2, 5, 2, 600), (2, 4, 2, 600), (15, 4, 4, 400), (31, 2, 4, 200), (63, 1, 4, 200),
+                                     (7, 7, 4, 1000), (4, 12, 4, 1000)])
 def test_connect_step_random_n(batch_mod, h, w, k, n):
     """bgs_step_random_n == that many bgs_step_random calls: the streaming kernel (one-word boards, even n: pairs of
     boards per lane, several plies per launch, philox block boundaries inside a launch) and the fallbacks (odd n,

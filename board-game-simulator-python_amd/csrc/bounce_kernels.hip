@@ -1900,8 +1900,12 @@ k_bounce_compact(const uint8_t* __restrict__ status, const uint16_t* __restrict_
 //   B2  a source's targets = the OR of its members' landing masks (masks over v_readlane, selected by sign-extended
 //       member bits), counts; the sources of the active row are neighbouring lanes in column order, so "actions before
 //       mine" is a prefix sum over 16 lanes (four DPP row shifts), the total is lane 15's;
-//   pick the lane whose range holds the index works out (source, target); a ballot and one v_readlane hand it to all.
-// ~320 VALU and ~50 v_readlane a ply against ~1000.  The board itself (four value planes) is wave-uniform.
+//   pick the lane whose range holds the index is the source (a ballot); its k-th target is found by the CELLS (lane c counts
+//       the targets below cell c with v_mbcnt; the target cell whose count is k is it): a dozen instructions.
+// ~320 VALU and ~50 v_readlane a ply against ~1000.  The board itself (four value planes) is wave-uniform, and so is all
+// the state of the wave's one game -- kept in scalar registers on purpose (see the ply loop: `same`, `word_at`).
+// Measured per ply of a wave that has its SIMD to itself (cycle counter, round 5): a full search 3 200 cycles, with the
+// memo's look-up, fill and link bookkeeping around it 4 400, a remembered position 1 300, a hop along a link 250.
 // Results cannot differ from the other kernels': the same rules, the same canonical action order (sources by column,
 // targets by cell index), the RNG keyed by game id and ply.
 // ------------------------------------------------------------------------------------------------

@@ -29,6 +29,12 @@
 
 #define OP_ADD(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(k));
 #define OP_AND(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_AND_LIT(x) asm volatile("v_and_b32 %0, 0x71111117, %0" : "+v"(x));
+#define OP_AND_S(x) asm volatile("v_and_b32 %0, %1, %0" : "+v"(x) : "s"(k));
+#define OP_AND_INL(x) asm volatile("v_and_b32 %0, 15, %0" : "+v"(x));
+#define OP_BITOP3_S(x) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x80" : "+v"(x) : "s"(k));
+#define OP_CMP_E32(x) asm volatile("v_cmp_lt_u32_e32 vcc, %1, %0" : "+v"(x) : "v"(k) : "vcc");
+#define OP_CMP_E64(x) asm volatile("v_cmp_lt_u32_e64 s[10:11], %1, %0" : "+v"(x) : "v"(k) : "s10", "s11");
 #define OP_SHR(x) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(x));
 #define OP_SHRV(x) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(x) : "v"(s));
 #define OP_ALIGN(x) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(x) : "v"(k));
@@ -70,6 +76,12 @@
     }
 KERNEL32(k_add, OP_ADD)
 KERNEL32(k_and, OP_AND)
+KERNEL32(k_and_lit, OP_AND_LIT)
+KERNEL32(k_and_s, OP_AND_S)
+KERNEL32(k_and_inl, OP_AND_INL)
+KERNEL32(k_bitop3_s, OP_BITOP3_S)
+KERNEL32(k_cmp_e32, OP_CMP_E32)
+KERNEL32(k_cmp_e64, OP_CMP_E64)
 KERNEL32(k_shr, OP_SHR)
 KERNEL32(k_shrv, OP_SHRV)
 KERNEL32(k_alignbit, OP_ALIGN)
@@ -145,7 +157,7 @@ int main() {
     hipMalloc(&out, 256 * 8 * 256 * 4 * 2);
     struct Case { const char* name; kern_t fn; double insts_per_iter; };
     std::vector<Case> cases = {
-        {"v_add_u32", k_add, 32}, {"v_and_b32", k_and, 32}, {"v_lshrrev_b32 const", k_shr, 32}, {"v_lshrrev_b32 var", k_shrv, 32},
+        {"v_add_u32", k_add, 32}, {"v_and_b32", k_and, 32}, {"v_and_b32 literal", k_and_lit, 32}, {"v_and_b32 sgpr", k_and_s, 32}, {"v_and_b32 inline const", k_and_inl, 32}, {"v_bitop3_b32 sgpr", k_bitop3_s, 32}, {"v_cmp_lt_u32_e32", k_cmp_e32, 32}, {"v_cmp_lt_u32_e64", k_cmp_e64, 32}, {"v_lshrrev_b32 const", k_shr, 32}, {"v_lshrrev_b32 var", k_shrv, 32},
         {"v_alignbit_b32", k_alignbit, 32}, {"v_bcnt_u32_b32", k_bcnt, 32}, {"v_mul_lo_u32", k_mullo, 32}, {"v_mul_hi_u32", k_mulhi, 32},
         {"v_bfe_u32", k_bfe, 32}, {"v_ffbl_b32", k_ffbl, 32}, {"v_bitop3_b32", k_bitop3, 32}, {"v_and_or_b32", k_and_or, 32},
         {"v_lshl_add_u32", k_lshl_add, 32}, {"v_cndmask_b32", k_cndmask, 32}, {"v_cmp_lt_u32+v_cndmask", k_cmp_cnd, 32},

@@ -551,7 +551,7 @@ int rollout_with_codes(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t 
 // graph 35 / 52 -- hipGraphLaunch costs more than the five launches it replaces.  From 8 threads the order of in place
 // and graph changed between runs (30 vs 42 and 48 vs 38 thousand Connect transitions per second).  The default goes one
 // step further on the packed geometries: in place, with the move and the whole observation in ONE kernel
-// (k_connect_transition / k_bounce_transition) instead of five.  BGS_TRANSITION=staged | mapped | graph select the
+// (k_connect_transition / k_bounce_transition) instead of five.  experiment transition=staged | mapped | graph select the
 // multi-kernel forms (the only ones for generic geometries and for batches above kSmallTransition boards).
 namespace {
 constexpr int64_t kSmallTransition = 64;
@@ -1265,7 +1265,7 @@ int bgs_transition(bgs_batch* b, const int8_t* grid, const int8_t* player, const
         HIP_TRY(hipMemsetAsync(d_out, 0, 8 * n, b->stream));
     }
     // The fused kernel publishes a ticket behind its records: the host takes them as soon as it SEES the ticket, which is
-    // earlier than the stream's completion signal comes back (BGS_TRANSITION_SPIN=0: wait for the stream as before).  The
+    // earlier than the stream's completion signal comes back (experiment transition_spin=0: wait for the stream as before).  The
     // kernel that wrote the ticket has nothing left to do, so the next call may reuse the blocks; the stream itself is
     // synchronised now and then, and whenever the ticket does not show within 2 ms (a failed launch reports itself there).
     static const bool spin_wanted = [] { const char* e = bgs::experiment("transition_spin"); return !(e && e[0] == '0'); }();

@@ -277,7 +277,7 @@ bool device_node_cpus(int device, cpu_set_t* out) {
 // reward sink: slots of pinned code buffers + worker threads
 // ------------------------------------------------------------------------------------------------
 namespace {
-// BGS_SINK_TRACE=1: the sink's threads report when they saw a job's codes, expanded their share and completed it, in
+// experiment sink_trace=1: the sink's threads report when they saw a job's codes, expanded their share and completed it, in
 // microseconds of CLOCK_MONOTONIC (what time.perf_counter() reads too) -- for tools/short_run_timeline.py
 inline bool sink_trace_on() {
     static const bool on = bgs::experiment("sink_trace") != nullptr;
@@ -324,7 +324,7 @@ struct bgs_reward_sink {
     // reported once, to the first bgs_sink_wait for that ticket or a later one, and the deliveries after it are as good
     // as any (round-3 advisor: a sticky flag made one argument error poison every later wait).  Under mu.
     std::vector<int64_t> failed_tickets;
-    bool poll = false;                   // worker 0 polls the slot's event instead of sleeping on it (BGS_SINK_POLL=1)
+    bool poll = false;                   // worker 0 polls the slot's event instead of sleeping on it (experiment sink_poll=1)
     std::vector<std::thread> workers;
     // Lock-free mirrors of the three counters: a waiter may spin on them for up to spin_us microseconds before it
     // sleeps on the condition variable (BGS_SINK_SPIN_US; default 0 = sleep at once).  Measured on the bench, spinning
@@ -749,7 +749,7 @@ static hipError_t enqueue_grids(bgs_reward_sink* s, bgs_batch* b, int slot) {
     const void* src = b->d_planes;  // Bounce value planes and generic int8 grids cross as they are
     if (!b->generic && b->game == BGS_GAME_CONNECT) {
         // The conversion kernel stores straight into the page-locked slot: coalesced 512-byte runs over PCIe, 51 GB/s
-        // measured at 2^20 boards (a copy engine behind a staging buffer, BGS_GRID_COPY=1: 36 GB/s)
+        // measured at 2^20 boards (a copy engine behind a staging buffer, experiment grid_copy=1: 36 GB/s)
         static const bool direct = bgs::experiment("grid_copy") == nullptr;
         if (direct) {
             bgs::connect_cell_planes(b, reinterpret_cast<uint64_t*>(s->mapped[slot]));

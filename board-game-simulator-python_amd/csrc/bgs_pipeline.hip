@@ -353,7 +353,7 @@ int bgs_pipeline_drain(bgs_pipeline* p) {
     // the newest hand-over first: every waiter it turns urgent stays so until the last delivery is in
     int64_t newest = -1;
     for (int64_t t : p->ticket) newest = t > newest ? t : newest;
-    // every stream is synchronised by its helper, starting NOW (see StreamSyncer); BGS_DRAIN_SERIAL_SYNC=1: by this
+    // every stream is synchronised by its helper, starting NOW (see StreamSyncer); experiment drain_serial_sync=1: by this
     // thread, one after the other, once the deliveries are in (the A/B of round 3, r3_drain.sh in the git history)
     const size_t depth = p->batches.size();
     static const bool serial = bgs::experiment("drain_serial_sync") != nullptr;

@@ -23,15 +23,18 @@ N > 1: one process per GPU, rank r owns global game ids [r * 2^20, (r+1) * 2^20)
 game id, so the shards reproduce the unsharded run).  The only exchange is the hand-over into THE one host array
 int8[N * 2^20, 2] (`--gather`, default `both`: the two hand-overs one after the other in the same run, each with its
 own timed regions and its own verification of rank 0's array against a replay of every rank's first games):
-  shm   the array lives in shared memory mapped by every rank of the node and each rank's own sink delivers its rows --
-        the one-GPU loop on every rank, every GPU on its own PCIe link, no collective in the data path; rank 0 is the
-        consumer: it waits (futex) for every rank's delivery of a step and releases the slot, and the timed region ends
-        when it has seen the last step of every rank (simulator/sharding.py: SharedRewardRing).  Carries `value`;
-  rccl  the north-star's collective: every rank's codes to rank 0's GPU over RCCL / xGMI, inside the library
+  rccl  the north-star's collective, and what `value` is (BASELINE.json: "RCCL over xGMI used only to gather per-game
+        rewards into one host array"): every rank's codes to rank 0's GPU over RCCL / xGMI, inside the library
         (bgs_gather_*: persistent communicator, communication stream and thread, one group of point-to-point calls per
         `slots / 2` steps; the launching thread never enters RCCL), rank 0's sink takes them to the host and expands them
-        all (`gather_rccl` block).  A gather that does not finish within BGS_BENCH_GATHER_TIMEOUT (180 s) is given up:
-        the line is printed with what the shared array measured and the gather's error.
+        all (`gather_rccl` block; `rccl_ranks` at the top of the line is what the communicator itself reports);
+  shm   beside it (`gather_shm` block): the array lives in shared memory mapped by every rank of the node and each rank's
+        own sink delivers its rows -- the one-GPU loop on every rank, every GPU on its own PCIe link, no collective in the
+        data path; rank 0 is the consumer: it waits (futex) for every rank's delivery of a step and releases the slot, and
+        the timed region ends when it has seen the last step of every rank (simulator/sharding.py: SharedRewardRing).
+The shared array is measured first, so that a gather that fails still leaves a measured line -- but a hand-over that was
+asked for and errors or does not finish within BGS_BENCH_GATHER_TIMEOUT (180 s) makes the run FAIL: the line is printed
+with what was measured and the error, and the exit code is not 0.
 Plus one all-reduce of the step counters after each timed region.  Weak scaling.
 
 Environment (experiments): BGS_BENCH_SLOT_FACTOR (host arrays per stream, default 3), BGS_BENCH_TRACE=1 (where the
@@ -78,6 +81,10 @@ PCIE_PEAK_GBS = 63.0         # PCIe Gen5 x16 spec (MI355X_MICROARCH.md)
 VALU_PEAK_SIMD32 = 256 * 4 * 2.4e9 / 2 / 1e9  # G wave64-instr/s: 256 CUs x 4 SIMD-32, 2 cycles per wave64 instruction
 # settings that change what a launch executes: counters taken under the defaults are not quoted when one is set
 LAUNCH_OVERRIDES = ("rollout_opening", "rollout_chunk", "rollout_generic", "rollout_no_lds", "force_generic")   # names in BGS_EXPERIMENT
+RNG_CONTRACT = ("per-block: philox4x32-10 keyed by (seed, global game id); one 32-bit word per block of four plies, the plies' draws "
+                "its sub-draws word * 747796405^j mod 2^32 (include/bgs.h; the library's default since round 5)")
+RNG_STRICT = ("per-ply: philox4x32-10 keyed by (seed, global game id); one 32-bit word per ply (BGS_RNG_PER_PLY, the strict contract: "
+              "an independent uniform choice per ply, as random.choice gives the reference's callers)")
 BOUNCE_GRID = [[0] * 6, [1, 2, 3, 3, 2, 1]] + [[0] * 6] * 5 + [[1, 2, 3, 3, 2, 1], [0] * 6]  # textual/bounce.py:66-78
 OTHER_CONFIGS = {
     # name: (BASELINE.json config, boards, batches in flight, max plies, SURVEY 8d bytes per env-step, counters file, kernel)
@@ -166,7 +173,7 @@ def cpu_threads():
     return avail, cap, min(avail, cap)
 
 
-def cpu_baseline(last_seed, host_reward_head):
+def cpu_baseline(last_seed, host_reward_head, per_ply=False):
     """Time the oracle on this host's cores on a bounded sample of the same workload, and use the same run to
     cross-check the rewards the last timed step delivered (first games of the host array).  `value` is the BEST of a few
     thread-team sizes -- a one-GPU share of the host (16), 64, every core the process may use -- with the team that gave it
@@ -192,7 +199,7 @@ def cpu_baseline(last_seed, host_reward_head):
     for team in teams:
         if gomp is not None:
             gomp.omp_set_num_threads(team)
-        orc = oracle.ConnectOracle(HEIGHT, WIDTH, COUNT, n)   # (its reset: first touch by this team)
+        orc = oracle.ConnectOracle(HEIGHT, WIDTH, COUNT, n, per_ply=per_ply)   # (its reset: first touch by this team)
         orc.rollout(SEED, max_plies=4)  # start the thread team
         reps = 8 if team == share else 4   # (~1.2 s a repetition on 16 threads: about 20 s of CPU work in all)
         total, elapsed = 0, 0.0
@@ -588,9 +595,9 @@ def main() -> int:
                     help="N > 1: how the ranks' rewards reach the one host array. shm: the array is in shared "
                          "memory and every rank's own sink delivers its rows (no collective, every GPU uses its own PCIe "
                          "link); rccl: outcome codes gathered to rank 0's GPU over RCCL inside the library, rank 0's sink "
-                         "expands them all; both (default): one after the other in the same run -- `value` is the shared "
-                         "array's, and the line carries a `gather_shm` and a `gather_rccl` block, each with its own "
-                         "verification of rank 0's host array")
+                         "expands them all; both (default): one after the other in the same run -- `value` is the RCCL "
+                         "gather's (the north-star's collective), and the line carries a `gather_rccl` and a `gather_shm` "
+                         "block, each with its own verification of rank 0's host array")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed steps (hand-over included) before the W warm-up steps until this many milliseconds have "
                     "passed: the GPU's power state climbs for tens of milliseconds under load, and RCCL connects on first "
@@ -600,6 +607,11 @@ def main() -> int:
                     help="skip the extra, separately timed pass without hand-over that fills `device_resident`")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 3 and 4 (`other_configs`)")
     ap.add_argument("--no-repeats", action="store_true", help="skip the two extra timed regions behind `value_median_of_3`")
+    ap.add_argument("--rng", choices=("per-block", "per-ply"), default="per-block",
+                    help="the RNG contract `value` is measured under (config.rng names it).  per-block (default): the library's "
+                    "default, a philox word per four plies.  per-ply: the strict contract, a word per ply.  Whichever is chosen, a "
+                    "one-GPU run also times the OTHER contract on the same batches (`rng_other` block: its value and the ratio), so "
+                    "the cost of the strict contract is on the line")
     ap.add_argument("--only", choices=sorted(OTHER_CONFIGS), help="measure one of the other BASELINE configs and print its JSON object")
     args = ap.parse_args()
     if args.gather not in ("shm", "rccl", "both"):
@@ -675,7 +687,8 @@ def main() -> int:
         return 2
     handover = args.handover
     # which hand-overs this run measures: one GPU -> the plain sink; N > 1 -> `--gather` (default both: the shared host
-    # array first -- it carries `value` -- then the in-library RCCL gather, each with its own verification)
+    # array first -- a line exists whatever the collective does -- then the in-library RCCL gather, which carries `value`
+    # when it succeeds; each with its own verification)
     if not sharded or handover == "none":
         kinds = ["sink"]
     else:
@@ -695,6 +708,7 @@ def main() -> int:
         with torch.cuda.stream(s):
             b = ConnectBatch(HEIGHT, WIDTH, COUNT, n, device=local_rank, use_torch=True)  # ordered onto stream s
             b.set_first_game(shard_range(n * world, rank, world)[0])
+            b.set_rng_contract(args.rng)
             batches.append(b)
     device = gpu if backend == "nccl" else torch.device("cpu")
     # HIP-event pairs bracket a sample of the launches on the launch stream: about 32 pairs (at least every other launch
@@ -778,13 +792,15 @@ def main() -> int:
                       f"rewards on the host at {(t_drained - t0) * 1e3:.3f} ms, device idle at {dt * 1e3:.3f} ms", file=sys.stderr)
             steps_local = sum(b.steps for b in batches)
             kernel_ms = exe.kernel_ms()[0] if stride else None
+            dt_fastest = dt
             if dist is not None:
-                t = torch.tensor([dt], dtype=torch.float64, device=device)
+                t = torch.tensor([dt, -dt], dtype=torch.float64, device=device)   # (max over the ranks of dt and of -dt)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t.item())
+                dt, dt_fastest = float(t[0].item()), -float(t[1].item())
                 steps_total = sum_steps(dist, steps_local, device)
             else:
                 steps_total = steps_local
+            timed_region.rank_spread = (dt_fastest, dt)
             return dt, steps_total, steps_local, kernel_ms
 
         # untimed: bring the device to its loaded power state (and RCCL to connected peers), then the W warm-up steps
@@ -805,6 +821,7 @@ def main() -> int:
         exe.enqueue(args.warmup, handover != "none")
         exe.drain()
         elapsed, steps_total, steps_local, kernel_ms = timed_region(args.steps, True, stride)
+        rank_spread = timed_region.rank_spread   # (the fastest and the slowest rank's own clock around the region)
         last = exe.steps - 1  # index (= seed offset) of the last timed step
 
         # the host array of the LAST timed step (a copy: the extra passes below reuse the slots)
@@ -838,6 +855,27 @@ def main() -> int:
             dt, st, _, k_ms = timed_region(reps, False, max(1, reps // 32))
             device_resident = {"value": st / dt, "unit": "env-steps/s", "ms_per_step": dt / reps * 1e3, "steps": reps,
                                "kernel_ms_per_launch": k_ms}
+        # the OTHER RNG contract on the same batches and hand-over, timed separately: what the strict contract costs
+        rng_other = None
+        if with_device_resident and handover != "none" and not sharded:
+            other = "per-ply" if args.rng == "per-block" else "per-block"
+            for b in batches:
+                b.set_rng_contract(other)
+            exe.enqueue(max(args.warmup, 2 * depth), True)
+            exe.drain()
+            dt, st, _, k_ms = timed_region(args.steps, True, max(2, args.steps // 32))
+            # (parity of this leg: the host array of its last step against the oracle under the same contract)
+            probe_host = np.array(exe.last_host_array()[:4096])
+            from oracle import oracle as _orc
+
+            o = _orc.ConnectOracle(HEIGHT, WIDTH, COUNT, 4096, per_ply=(other == "per-ply"))
+            o.rollout(SEED + exe.steps - 1, first_game=shard_range(n * world, rank, world)[0])
+            rng_other = {"rng": RNG_STRICT if other == "per-ply" else RNG_CONTRACT, "value": st / dt, "unit": "env-steps/s",
+                         "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "kernel_ms_per_launch": k_ms,
+                         "env_steps_per_step": st / args.steps, "rewards_to_host": True,
+                         "parity_with_oracle_first_4096": bool((probe_host == o.reward).all())}
+            for b in batches:
+                b.set_rng_contract(args.rng)
         # one launch at a time (no hand-over, one stream): what the pipelining of `depth` launches buys
         solo = None
         if with_device_resident and os.environ.get("BGS_BENCH_SOLO", "1") != "0":
@@ -861,9 +899,9 @@ def main() -> int:
             for b in batches:   # (the launch shape follows the launches in flight: back to the pipeline's)
                 b.set_launches_in_flight(depth)
         result = {"kind": kind, "elapsed": elapsed, "steps_total": steps_total, "steps_local": steps_local, "kernel_ms": kernel_ms,
-                  "last": last, "final_host": final_host, "gather_ok": gather_ok, "repeats": repeats, "solo": solo,
+                  "last": last, "final_host": final_host, "gather_ok": gather_ok, "repeats": repeats, "solo": solo, "rng_other": rng_other,
                   "device_resident": device_resident, "prewarm_steps": prewarm_steps, "host_slots": host_slots,
-                  "host_threads": host_threads, "rows": rows, "note": note}
+                  "host_threads": host_threads, "rows": rows, "note": note, "rank_spread": rank_spread}
         exe.close()
         if gather is not None:
             gather.close()
@@ -899,15 +937,19 @@ def main() -> int:
         v = res["steps_total"] / res["elapsed"]
         to_host = code_bytes * (world if res["kind"] == "rccl" else 1)
         ms = res["elapsed"] / args.steps * 1e3
-        return {"value": v, "unit": "env-steps/s", "ms_per_step": ms, "values_of_3": res["repeats"] if len(res["repeats"]) == 3 else None,
+        return {"value": v, "unit": "env-steps/s", "ms_per_step": ms,
+                "ms_per_step_fastest_rank": res["rank_spread"][0] / args.steps * 1e3, "ms_per_step_slowest_rank": res["rank_spread"][1] / args.steps * 1e3,
+                "values_of_3": res["repeats"] if len(res["repeats"]) == 3 else None,
                 "gathered_rewards_verified": res["gather_ok"], "sharding": sharding_text(res), "host_arrays": res["host_slots"],
                 "host_threads": res["host_threads"], "gather_info": res["note"],
                 "pcie_bytes_per_step_on_rank0": to_host, "pcie_GBps_on_rank0": to_host / (ms * 1e-3) / 1e9}
 
     def build_line(results, extra=None):
-        """The one JSON line: `value` and the roofline from the FIRST hand-over measured, every hand-over of an N > 1 run in
-        its own `gather_<kind>` block."""
-        primary = results[0]
+        """The one JSON line: `value` and the roofline from the hand-over that carries the metric -- the RCCL gather when it
+        was measured, else the first one that was -- and every hand-over of an N > 1 run in its own `gather_<kind>` block."""
+        good = [r for r in results if "error" not in r]
+        primary = next((r for r in good if r["kind"] == "rccl"), good[0])
+        aside = next((r for r in good if r["device_resident"] is not None), primary)   # (the passes without hand-over ran once)
         elapsed, steps_total, steps_local, kernel_ms = primary["elapsed"], primary["steps_total"], primary["steps_local"], primary["kernel_ms"]
         repeats = primary["repeats"]
         value = steps_total / elapsed
@@ -956,11 +998,16 @@ def main() -> int:
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
+            # N > 1: the size of the communicator the gather ran on (ncclCommCount), and the ranks' own clocks around the region
+            "rccl_ranks": (primary["note"] or {}).get("ranks") if primary["kind"] == "rccl" else None,
+            "ms_per_step_fastest_rank": primary["rank_spread"][0] / args.steps * 1e3,
+            "ms_per_step_slowest_rank": primary["rank_spread"][1] / args.steps * 1e3,
             "value_median_of_3": sorted(repeats)[len(repeats) // 2] if len(repeats) == 3 else None,
             "values_of_3": repeats if len(repeats) == 3 else None,
             "config": {
                 "workload": f"Connect4({HEIGHT},{WIDTH},{COUNT}) uniform-random rollout from the initial state to terminal, "
                 f"batch={n} boards per GPU, seed 0x{SEED:016X}+step, philox4x32-10 keyed by global game id",
+                "rng": RNG_STRICT if args.rng == "per-ply" else RNG_CONTRACT,
                 "batch_per_gpu": n,
                 "global_batch": n * world,
                 "env_steps_per_step": steps_total / args.steps,
@@ -987,12 +1034,15 @@ def main() -> int:
             # every hand-over this run measured, each with its own verification of rank 0's host array; `value` is the first
             for r in results:
                 out[f"gather_{r['kind']}"] = block(r)
-        if primary["device_resident"] is not None:
-            primary["device_resident"]["host_over_device"] = value / primary["device_resident"]["value"]
-            out["device_resident"] = primary["device_resident"]
-        if primary.get("solo") is not None:
-            primary["solo"]["pipelined_over_solo"] = value / primary["solo"]["value"]
-            out["solo"] = primary["solo"]
+        if aside["device_resident"] is not None:
+            aside["device_resident"]["host_over_device"] = value / aside["device_resident"]["value"]
+            out["device_resident"] = aside["device_resident"]
+        if aside.get("rng_other") is not None:
+            aside["rng_other"]["over_value"] = aside["rng_other"]["value"] / value
+            out["rng_other"] = aside["rng_other"]
+        if aside.get("solo") is not None:
+            aside["solo"]["pipelined_over_solo"] = value / aside["solo"]["value"]
+            out["solo"] = aside["solo"]
         out.update(extra or {})
         return out
 
@@ -1002,7 +1052,7 @@ def main() -> int:
     state = {"line_printed": False}
 
     def emit(extra=None):
-        if rank == 0 and not state["line_printed"] and results and "error" not in results[0]:
+        if rank == 0 and not state["line_printed"] and any("error" not in r for r in results):
             state["line_printed"] = True
             print(json.dumps(build_line(results, extra)), flush=True)
 
@@ -1010,15 +1060,17 @@ def main() -> int:
 
     for k, kind in enumerate(kinds):
         dog = None
-        if k > 0:
+        if sharded:
             limit = float(os.environ.get("BGS_BENCH_GATHER_TIMEOUT", "180"))
 
             def bark(kind=kind, limit=limit):
+                # the line goes out with what was measured and the error -- and the run FAILS: a hand-over that was asked
+                # for is dead (a driver that reads the exit code must not see success)
                 print(f"bench.py: rank {rank}: the {kind} hand-over did not finish within {limit:.0f} s; giving it up", file=sys.stderr)
-                emit({f"gather_{kind}": {"error": f"did not finish within {limit:.0f} s"}})
+                emit({f"gather_{kind}": {"error": f"did not finish within {limit:.0f} s"}, "failed_handovers": [kind]})
                 sys.stdout.flush()
                 sys.stderr.flush()
-                os._exit(0 if state["line_printed"] or rank != 0 else 3)
+                os._exit(4)
 
             dog = threading.Timer(limit, bark)
             dog.daemon = True
@@ -1039,9 +1091,11 @@ def main() -> int:
             res = measure("rccl", with_device_resident=not args.no_device_resident)
         res.setdefault("kind", kind)
         results.append(res)
-    results.sort(key=lambda r: "error" in r)   # (stable: the first hand-over that was measured carries `value`)
-    if "error" in results[0]:
-        print(f"bench.py: rank {rank}: {results[0]['error']}", file=sys.stderr)
+    failed = [r["kind"] for r in results if "error" in r]
+    for r in results:
+        if "error" in r:
+            print(f"bench.py: rank {rank}: the {r['kind']} hand-over failed: {r['error']}", file=sys.stderr)
+    if len(failed) == len(results):
         return 1
 
     extra = {}
@@ -1050,11 +1104,13 @@ def main() -> int:
         if not args.no_cpu_baseline:
             os.sched_setaffinity(0, free_cpus)
             head = primary["final_host"][:65536] if primary["final_host"] is not None else batches[primary["last"] % depth].reward[:65536]
-            extra["cpu_baseline"] = cpu_baseline(SEED + primary["last"], head)
+            extra["cpu_baseline"] = cpu_baseline(SEED + primary["last"], head, per_ply=(args.rng == "per-ply"))
             extra["cpu_baseline"]["gpu_single_game_latency_us"] = gpu_single_game_latency()
         if not args.no_other_configs:
             extra["grids_to_host"] = grids_to_host()
             extra["other_configs"] = early_other if early_other is not None else other_configs()
+    if failed:
+        extra["failed_handovers"] = failed
     emit(extra)
     if dist is not None:
         # The ranks part company here.  If a hand-over failed on some rank only, the others may never reach this barrier:
@@ -1073,8 +1129,8 @@ def main() -> int:
             print(f"bench.py: rank {rank}: the closing barrier did not complete; leaving", file=sys.stderr)
             sys.stdout.flush()
             sys.stderr.flush()
-            os._exit(0)
-    return 0
+            os._exit(4 if failed else 0)
+    return 4 if failed else 0   # (a hand-over that was asked for and failed: the line is there, the run is not a success)
 
 
 if __name__ == "__main__":

@@ -302,6 +302,7 @@ int device_facts(bgs_batch* b) {
         const int v = atoi(e);
         if (v >= 64 && v <= (1 << 20)) b->rollout_chunk = v;
     }
+    b->rng_per_ply = 0;
     b->rollout_generic = bgs::experiment("rollout_generic") != nullptr;
     b->rollout_no_lds = bgs::experiment("rollout_no_lds") != nullptr;
     b->rollout_opening = kRolloutOpeningBlocks;
@@ -321,11 +322,11 @@ int device_facts(bgs_batch* b) {
     if (const char* env = bgs::experiment("bounce_flat")) b->bounce_flat = atoi(env) != 0;
     b->bounce_pieces = 1;
     if (const char* env = bgs::experiment("bounce_pieces")) b->bounce_pieces = atoi(env) != 0;
-    b->bounce_block = 256;
+    b->bounce_block = kBounceBlock;
     if (const char* env = bgs::experiment("bounce_block")) b->bounce_block = atoi(env);
     b->bounce_pool = 1;
     if (const char* env = bgs::experiment("bounce_pool")) b->bounce_pool = atoi(env) != 0;
-    b->bounce_flat_chunk = 32;
+    b->bounce_flat_chunk = kBounceFlatChunk;
     if (const char* env = bgs::experiment("bounce_chunk")) {
         const int v = atoi(env);
         if (v >= 1 && v <= 4096) b->bounce_flat_chunk = v;
@@ -346,7 +347,7 @@ int device_facts(bgs_batch* b) {
         const int v = atoi(env);
         if (v >= 1 && v <= (1 << 16)) b->bounce_flat_waves = v;
     }
-    b->bounce_flat_wps = 2;
+    b->bounce_flat_wps = kBounceFlatWps;
     if (const char* env = bgs::experiment("bounce_flat_wps")) {
         const int v = atoi(env);
         if (v >= 1 && v <= 8) b->bounce_flat_wps = v;
@@ -357,14 +358,16 @@ int device_facts(bgs_batch* b) {
         // default "auto": one launch, except for large from-initial batches on the piece-list kernel, whose handful of
         // very long games (a random Bounce game can go on for ever: it stops at max_plies) is finished by a second pass
         // with 8 lanes per board -- see bounce_rollout()
-        const char* plan = bgs::experiment("bounce_plan");
-        if (!plan) plan = "auto";
+        // (experiment() hands out a buffer its next call overwrites: the plan is copied before the other knobs are read)
+        const char* plan_value = bgs::experiment("bounce_plan");
+        const std::string plan_text = plan_value ? plan_value : "auto";
+        const char* plan = plan_text.c_str();
         const char* wave_pass = bgs::experiment("bounce_wave_pass");
         b->bounce_wave_pass = !(wave_pass && wave_pass[0] == '0');
         const char* epoch_limit = bgs::experiment("bounce_epoch_limit");
         b->bounce_epoch_limit = epoch_limit ? atoi(epoch_limit) : 0;
-        b->bounce_memo_cold = 4;      // (bounce_kernels.hip, K3w; "bounce_memo_policy=0:0": never without the memo)
-        b->bounce_memo_bypass = 28;
+        b->bounce_memo_cold = kBounceMemoCold;      // (bounce_kernels.hip, K3w; "bounce_memo_policy=0:0": never without the memo)
+        b->bounce_memo_bypass = kBounceMemoBypass;
         if (const char* policy = bgs::experiment("bounce_memo_policy")) {
             int cold = 0, plies = 0;
             if (sscanf(policy, "%d:%d", &cold, &plies) == 2 && cold >= 0 && plies >= 0 && plies <= 65535) {
@@ -532,7 +535,8 @@ int rollout_with_codes(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t 
     NEED(max_plies >= 0, "max_plies must be >= 0");
     NEED(codes_out != nullptr && ((uintptr_t)codes_out % 16) == 0, "codes destination must be 16-byte aligned");
     bool fused = false;
-    if (b->generic) bgs::generic_play(b, seed, (uint32_t)max_plies, 0xFFFFFFFFu, (flags & BGS_ROLLOUT_FROM_INITIAL) != 0);
+    NEED((flags & ~(uint32_t)(BGS_ROLLOUT_FROM_INITIAL | BGS_ROLLOUT_DRAW_PER_PLY)) == 0, "unknown rollout flags 0x%x", flags);
+    if (b->generic) bgs::generic_play(b, seed, (uint32_t)max_plies, 0xFFFFFFFFu, (flags & BGS_ROLLOUT_FROM_INITIAL) != 0, (flags & BGS_ROLLOUT_DRAW_PER_PLY) != 0);
     else if (b->game == BGS_GAME_CONNECT) fused = bgs::connect_rollout(b, seed, max_plies, flags, reinterpret_cast<uint32_t*>(codes_out));
     else bgs::bounce_rollout(b, seed, max_plies, flags);
     if (!fused) bgs::pack_outcomes(b, codes_out);
@@ -835,6 +839,13 @@ int bgs_set_first_game(bgs_batch* b, uint64_t first_game) {
     return BGS_OK;
 }
 
+int bgs_set_rng_contract(bgs_batch* b, int contract) {
+    NEED(b != nullptr, "batch handle is NULL");
+    NEED(contract == BGS_RNG_PER_BLOCK || contract == BGS_RNG_PER_PLY, "unknown RNG contract %d", contract);
+    b->rng_per_ply = contract == BGS_RNG_PER_PLY;
+    return BGS_OK;
+}
+
 int bgs_synchronize(bgs_batch* b) {
     int rc = enter(b);
     if (rc) return rc;
@@ -973,7 +984,8 @@ int bgs_rollout(bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags) 
     int rc = enter(b);
     if (rc) return rc;
     NEED(max_plies >= 0, "max_plies must be >= 0");
-    if (b->generic) bgs::generic_play(b, seed, (uint32_t)max_plies, 0xFFFFFFFFu, (flags & BGS_ROLLOUT_FROM_INITIAL) != 0);
+    NEED((flags & ~(uint32_t)(BGS_ROLLOUT_FROM_INITIAL | BGS_ROLLOUT_DRAW_PER_PLY)) == 0, "unknown rollout flags 0x%x", flags);
+    if (b->generic) bgs::generic_play(b, seed, (uint32_t)max_plies, 0xFFFFFFFFu, (flags & BGS_ROLLOUT_FROM_INITIAL) != 0, (flags & BGS_ROLLOUT_DRAW_PER_PLY) != 0);
     else if (b->game == BGS_GAME_CONNECT) (void)bgs::connect_rollout(b, seed, max_plies, flags, nullptr);
     else bgs::bounce_rollout(b, seed, max_plies, flags);
     return finish_launch();

@@ -103,6 +103,45 @@ __host__ __device__ __forceinline__ uint32_t sub_draw(uint32_t word, uint32_t j)
 // Connect: the word of ply's block out of the philox call that covers it (philox4x32_10(seed, game, ply >> 4))
 __device__ __forceinline__ uint32_t connect_word(const Philox4& p, uint32_t ply) { return philox_word(p, ply >> 2); }
 
+// ---- Connect under a NAMED contract (round 6).  The word-per-block contract above is the default; the strict one --
+// BGS_ROLLOUT_DRAW_PER_PLY / bgs_set_rng_contract(b, BGS_RNG_PER_PLY) -- gives every ply a philox word of its own, exactly
+// as Bounce draws: draw(seed, game, ply) = philox(counter = (game lo, game hi, ply >> 2, 0))[ply & 3].
+// The draw of one ply, for kernels that make a philox call per ply or per launch:
+template <bool PER_PLY>
+__device__ __forceinline__ Philox4 connect_philox(uint64_t seed, uint64_t game, uint32_t ply) {
+    return philox4x32_10(seed, game, ply >> (PER_PLY ? 2 : 4));
+}
+template <bool PER_PLY>
+__device__ __forceinline__ uint32_t connect_draw(const Philox4& p, uint32_t ply) {
+    return PER_PLY ? philox_word(p, ply) : sub_draw(connect_word(p, ply), ply & 3u);
+}
+// ... the same with the contract as a wave-uniform run-time value (the kernels off the fast paths): per_ply = 0 / 1
+__device__ __forceinline__ Philox4 connect_philox(uint32_t per_ply, uint64_t seed, uint64_t game, uint32_t ply) {
+    return philox4x32_10(seed, game, ply >> (per_ply ? 2u : 4u));
+}
+__device__ __forceinline__ uint32_t connect_draw(uint32_t per_ply, const Philox4& p, uint32_t ply) {
+    return sub_draw(philox_word(p, per_ply ? ply : ply >> 2), per_ply ? 0u : ply & 3u);
+}
+// The four draws of block `blk` (plies 4 blk .. 4 blk + 3) of a game, for the block-aligned rollout kernels: ONE philox
+// call either way -- per block of four plies under the strict contract (its four words ARE the draws), per four blocks
+// otherwise (a lane-dependent word of it, multiplied up)
+template <bool PER_PLY>
+struct BlockDraws {
+    Philox4 p;
+    uint32_t word;
+    __device__ __forceinline__ BlockDraws(uint64_t seed, uint64_t game, uint32_t blk) {
+        p = philox4x32_10(seed, game, PER_PLY ? blk : blk >> 2);
+        word = PER_PLY ? 0u : philox_word(p, blk);
+    }
+    template <uint32_t J>
+    __device__ __forceinline__ uint32_t draw() const {
+        return PER_PLY ? p.v[J] : sub_draw<J>(word);
+    }
+    __device__ __forceinline__ uint32_t draw(uint32_t j) const {   // j: a constant once the ply loop is unrolled
+        return PER_PLY ? p.v[j] : sub_draw(word, j);
+    }
+};
+
 __host__ __device__ __forceinline__ uint32_t sample_index(uint32_t draw, uint32_t n_actions) {
     return (uint32_t)(((uint64_t)draw * n_actions) >> 32);
 }

@@ -52,6 +52,7 @@ struct bgs_batch {
     int rollout_chunk;       // games per wave of the fused rollout, 0 = derived from rollout_wps (experiment rollout_chunk)
     int rollout_opening;     // opening blocks of the from-initial one-word rollout: 0 = K2a, 1..4, default 3 (experiment rollout_opening)
     int rollout_no_lds;      // 1: large boards stay in registers (K2b) instead of the LDS-staged kernel (experiment rollout_no_lds)
+    int rng_per_ply;         // Connect: 1 = the strict RNG contract, a philox word per ply (bgs_set_rng_contract); 0 = a word per four plies
     // device buffers (inside the arena)
     void* arena;
     size_t arena_bytes;
@@ -130,7 +131,7 @@ void bounce_pack(const bgs_batch* b, const int8_t* d_grid, const int8_t* d_playe
 // ---- any geometry (generic_kernels.hip): the batch's "planes" region holds int8[n][h][w] ----
 size_t generic_bounce_legal_bytes(int h, int w);  // bytes per board of the wide legal-move record
 void generic_reset(const bgs_batch* b);
-void generic_play(const bgs_batch* b, uint64_t seed, uint32_t max_plies, uint32_t count, bool from_initial);
+void generic_play(const bgs_batch* b, uint64_t seed, uint32_t max_plies, uint32_t count, bool from_initial, bool per_ply = false);
 void generic_step_actions(const bgs_batch* b, const int32_t* d_actions, int32_t* d_status_out);
 void generic_unpack_grid(const bgs_batch* b, int8_t* d_grid);
 void generic_meta(const bgs_batch* b, int8_t* d_player, uint8_t* d_ended, int8_t* d_winner, int32_t* d_plies);

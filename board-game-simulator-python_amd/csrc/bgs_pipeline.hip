@@ -108,7 +108,9 @@ struct bgs_pipeline {
     std::mutex mu;
     std::condition_variable cv;
     std::thread feeder;
-    std::deque<uint64_t> fed;     // seeds not enqueued yet
+    std::deque<uint64_t> fed;     // seeds the feeder has not taken yet
+    int64_t fed_end = 0;           // the hand-over index one past the last fed step: the steps [handed, fed_end) are fed and
+                                   // not enqueued yet -- waiting in `fed`, or the ONE the feeder is enqueuing right now
     int64_t released = 0;          // hand-overs [0, released) are the consumer's no more: their arrays may be overwritten
     bool feeding = false;          // the feeder thread exists
     bool stop = false;
@@ -180,13 +182,15 @@ static int consume(bgs_pipeline* p, int64_t j) {
 static int enqueue_steps(bgs_pipeline* p, const uint64_t* seeds, int64_t count, int handover, int time_stride, bool from_feeder = false) {
     NEED(p != nullptr && count >= 0, "bad argument");
     NEED(!handover || p->sink || p->gather, "this pipeline has no hand-over");
-    NEED(from_feeder || !p->feeding || p->fed.empty(), "steps are being fed to this pipeline (bgs_pipeline_feed): enqueue when they have all been consumed");
+    // (with a feeder the consumer's bgs_pipeline_wait reads ticket / held beside this loop: the bookkeeping of a step is
+    // made under the pipeline's lock, the waits and the launches outside it)
+    std::unique_lock<std::mutex> lock(p->mu);
+    const bool fed_pending = p->feeding && p->handed < p->fed_end && p->feed_rc == BGS_OK;
+    lock.unlock();
+    NEED(from_feeder || !fed_pending, "steps are being fed to this pipeline (bgs_pipeline_feed): enqueue when they have all been consumed");
     HIP_TRY(hipSetDevice(p->device));
     const int depth = (int)p->batches.size();
     const int n_host = (int)p->host.size();
-    // (with a feeder the consumer's bgs_pipeline_wait reads ticket / held beside this loop: the bookkeeping of a step is
-    // made under the pipeline's lock, the waits and the launches outside it)
-    std::unique_lock<std::mutex> lock(p->mu, std::defer_lock);
     for (int64_t i = 0; i < count; ++i) {
         bgs_batch* b = p->batches[p->step % depth];
         const uint64_t seed = seeds ? seeds[i] : p->seed0 + (uint64_t)p->step;
@@ -250,7 +254,9 @@ static int enqueue_steps(bgs_pipeline* p, const uint64_t* seeds, int64_t count, 
     return BGS_OK;
 }
 
-// the feeder thread: one fed seed at a time, as soon as its host array has been released
+// the feeder thread: one fed seed at a time, as soon as its host array has been released.  The seed LEAVES the deque under
+// the lock that finds it there (nobody else ever sees a seed that is being enqueued: a destroy or a drain beside this
+// thread counts pending steps with fed_end, not with the deque's size)
 static void feeder_loop(bgs_pipeline* p) {
     (void)hipSetDevice(p->device);
     const int64_t n_host = (int64_t)p->host.size();
@@ -261,15 +267,15 @@ static void feeder_loop(bgs_pipeline* p) {
             p->cv.wait(lock, [&] { return p->stop || (!p->fed.empty() && p->feed_rc == BGS_OK && p->handed - p->released < n_host); });
             if (p->stop) return;
             seed = p->fed.front();
+            p->fed.pop_front();
         }
         const int rc = enqueue_steps(p, &seed, 1, 1, 0, true);
-        {
+        if (rc != BGS_OK) {
             std::lock_guard<std::mutex> lock(p->mu);
-            if (rc != BGS_OK && p->feed_rc == BGS_OK) {
+            if (p->feed_rc == BGS_OK) {
                 p->feed_rc = rc;
                 p->feed_error = bgs_last_error();
             }
-            if (rc == BGS_OK) p->fed.pop_front();
         }
         p->cv.notify_all();
     }
@@ -296,6 +302,8 @@ int bgs_pipeline_feed(bgs_pipeline* p, const uint64_t* seeds, int64_t count) {
             p->feeding = true;
             p->feeder = std::thread([p] { feeder_loop(p); });
         }
+        if (p->fed_end < p->handed) p->fed_end = p->handed;   // (steps the caller enqueued himself since the last feed)
+        p->fed_end += count;
         p->fed.insert(p->fed.end(), seeds, seeds + count);
     }
     p->cv.notify_all();
@@ -320,7 +328,7 @@ int bgs_pipeline_wait(bgs_pipeline* p, int64_t handover_index) {
     {
         std::unique_lock<std::mutex> lock(p->mu);
         // a fed step exists once the feeder has enqueued it
-        if (p->feeding && handover_index >= p->handed && handover_index < p->handed + (int64_t)p->fed.size())
+        if (p->feeding && handover_index >= p->handed && handover_index < p->fed_end)
             p->cv.wait(lock, [&] { return handover_index < p->handed || p->feed_rc != BGS_OK || p->stop; });
         if (p->feed_rc != BGS_OK && handover_index >= p->handed) return fail(p->feed_rc, "%s", p->feed_error.c_str());
         NEED(handover_index >= 0 && handover_index < p->handed, "hand-over %lld has not been enqueued", (long long)handover_index);
@@ -345,9 +353,10 @@ int bgs_pipeline_drain(bgs_pipeline* p) {
     if (p->feeding) {
         // what has been fed is enqueued first; every array is released (a drain ends the consumer's claim on them)
         std::unique_lock<std::mutex> lock(p->mu);
-        p->released = p->handed + (int64_t)p->fed.size();
+        if (p->fed_end > p->released) p->released = p->fed_end;
         p->cv.notify_all();
-        p->cv.wait(lock, [&] { return p->fed.empty() || p->feed_rc != BGS_OK || p->stop; });
+        p->cv.wait(lock, [&] { return p->handed >= p->fed_end || p->feed_rc != BGS_OK || p->stop; });
+        p->released = p->handed;   // (never past what exists: the next fed step waits for ITS array's release again)
         if (p->feed_rc != BGS_OK) return fail(p->feed_rc, "%s", p->feed_error.c_str());
     }
     // the newest hand-over first: every waiter it turns urgent stays so until the last delivery is in
@@ -432,10 +441,11 @@ int bgs_pipeline_destroy(bgs_pipeline* p) {
         {
             std::lock_guard<std::mutex> lock(p->mu);
             p->stop = true;
-            p->fed.clear();
         }
         p->cv.notify_all();
-        if (p->feeder.joinable()) p->feeder.join();
+        if (p->feeder.joinable()) p->feeder.join();   // (a step it was enqueuing is enqueued; the drain below waits for it)
+        p->fed.clear();
+        p->fed_end = p->handed;
         p->feeding = false;
     }
     (void)bgs_pipeline_drain(p);

@@ -33,6 +33,12 @@ struct BounceGeom {
 constexpr int kBouncePiecesPark = 32;       // K3p with the device-wide pool, 20 in flight / one launch at a time, x 10^9: round 4 32 / 40 / 48 / 56 / 63 = 11.8 / 12.2 / 11.9 / 11.8 / 3.0;
                                             // round 5 (opening book): 17.57 / 17.47 / 17.48 / 17.30 / 3.85 pipelined, 3.17 / 3.00 / 2.69 / 0.30 / 0.09 alone
 constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBoards (0 = every wave drains alone)
+// defaults that change what a launch executes (here and not in bgs_capi.hip so that the unit's id moves with them)
+constexpr int kBounceBlock = 256;           // threads a workgroup of the flat / piece-list rollouts
+constexpr int kBounceFlatChunk = 32;        // flat rollout: boards a wave draws from the queue at a time
+constexpr int kBounceFlatWps = 2;           // flat rollout: waves per SIMD
+constexpr int kBounceMemoCold = 4;          // K3w: consecutive memo misses after which a game plays without the memo ...
+constexpr int kBounceMemoBypass = 28;       // ... for this many plies, then looks again
 // K3p, automatic plan: the shape of a launch follows the number of launches the caller keeps in flight on the device
 // (bgs_set_launches_in_flight; the rollout executor passes its depth).  tail_cap: games longer than this are finished
 // by the tail pass; boards_per_wave: boards a wave of the bulk pass plays.  Alone on the chip a launch is bound by its

@@ -485,7 +485,7 @@ template <class G, class Game, bool FROM_INITIAL, bool CAPPED>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                   int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
-                  unsigned long long* __restrict__ steps, uint32_t games_per_wave) {
+                  unsigned long long* __restrict__ steps, uint32_t games_per_wave, uint32_t per_ply) {
     constexpr int NW = G::NW;
     // wave-uniform queue of this wave's games: begin + [taken, avail)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BGS_BLOCK / BGS_WAVE) + (threadIdx.x >> 6));
@@ -524,12 +524,18 @@ k_connect_rollout(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ stat
             taken = avail - taken < wanted ? avail : taken + wanted;
         }
         if (__builtin_amdgcn_ballot_w64(live)) {
-            uint32_t word = 0;   // the block's word: one philox call serves the sixteen plies of four blocks
-            if (live) word = connect_word(philox4x32_10(seed, first_game + (uint64_t)game, gm.plies() >> 4), gm.plies());
+            // the block's draws: one philox call serves the sixteen plies of four blocks (the four of this block under the
+            // strict contract, per_ply: its words are the draws)
+            Philox4 four = {{0u, 0u, 0u, 0u}};
+            uint32_t word = 0;
+            if (live) {
+                four = connect_philox(per_ply, seed, first_game + (uint64_t)game, gm.plies());
+                word = connect_word(four, gm.plies());
+            }
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 if (live && (FROM_INITIAL || (gm.plies() & 3u) == j)) {
-                    const bool running = gm.ply(g, sub_draw(word, j));
+                    const bool running = gm.ply(g, per_ply ? four.v[j] : sub_draw(word, j));
                     live = running && (!CAPPED || gm.plies() < max_plies);
                     if (!live) {
                         finished = true;
@@ -559,7 +565,7 @@ k_connect_rollout(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ stat
 template <class G, class Game>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
-                      int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps) {
+                      int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps, uint32_t per_ply) {
     constexpr int NW = G::NW;
     const int64_t i = (int64_t)blockIdx.x * BGS_BLOCK + threadIdx.x;
     uint32_t stepped = 0;
@@ -571,8 +577,8 @@ k_connect_step_random(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
             Game gm;
             gm.load(g, p0, p1);
             const uint32_t ply = gm.plies();
-            const Philox4 blk = philox4x32_10(seed, first_game + (uint64_t)i, ply >> 4);
-            const bool running = gm.ply(g, sub_draw(connect_word(blk, ply), ply & 3u));
+            const Philox4 blk = connect_philox(per_ply, seed, first_game + (uint64_t)i, ply);
+            const bool running = gm.ply(g, connect_draw(per_ply, blk, ply));
             gm.planes(p0, p1);
             const uint32_t mover = ply & 1u;  // only the mover's plane changed
 #pragma unroll
@@ -625,18 +631,18 @@ __device__ __forceinline__ uint32_t select_landing(uint64_t landing, uint64_t bo
     return (uint32_t)__ffsll((unsigned long long)(landing & (low << (col * stride)))) - 1u;
 }
 
-template <bool SINGLE, class G>
+template <bool SINGLE, bool PER_PLY, class G>
 __device__ __forceinline__ uint32_t play_plies(const G& g, uint64_t bottoms, uint64_t cells, uint64_t& p0, uint64_t& p1,
                                                uint32_t& st, uint64_t seed, uint64_t game, uint32_t count) {
     if (st != BGS_ST_RUNNING) return 0u;
     if (SINGLE) count = 1u;  // (straight-line code: no loop, no second philox call)
     uint32_t ply = (uint32_t)__popcll(p0) + (uint32_t)__popcll(p1);
     const uint32_t full = (uint32_t)(g.h() * g.w());
-    Philox4 blk = philox4x32_10(seed, game, ply >> 4);
+    Philox4 blk = connect_philox<PER_PLY>(seed, game, ply);
     uint32_t played = 0;
     for (uint32_t q = 0; q < count; ++q) {
         const uint64_t landing = ((p0 | p1) + bottoms) & cells;
-        const uint32_t idx = sample_index(sub_draw(connect_word(blk, ply), ply & 3u), (uint32_t)__popcll(landing));
+        const uint32_t idx = sample_index(connect_draw<PER_PLY>(blk, ply), (uint32_t)__popcll(landing));
         // (uniform; compile time for a static geometry.  Tall one-column boards keep the general search: fields of up to 16 bits)
         const bool by_fields = g.h() <= 15 && (uint32_t)g.w() <= (1u << g.h());
         const uint32_t pos = by_fields ? select_landing(landing, bottoms, bottoms << g.h(), (uint32_t)g.h() + 1u, idx)
@@ -657,7 +663,7 @@ __device__ __forceinline__ uint32_t play_plies(const G& g, uint64_t bottoms, uin
         ++played;
         if (won) { st = (second ? 2u : 1u); break; }
         if (ply == full) { st = BGS_ST_DRAW; break; }
-        if ((ply & 15u) == 0u && q + 1u < count) blk = philox4x32_10(seed, game, ply >> 4);
+        if ((ply & (PER_PLY ? 3u : 15u)) == 0u && q + 1u < count) blk = connect_philox<PER_PLY>(seed, game, ply);
     }
     return played;
 }
@@ -669,7 +675,7 @@ __device__ __forceinline__ uint32_t play_plies(const G& g, uint64_t bottoms, uin
 // next pair are issued before the current one is played, so every wave always has a pair's 34 bytes per lane in
 // flight while it computes.  `count` plies are played per launch on the boards in registers (bgs_step_random_n): the
 // per-ply traffic divides by count.
-template <class G, bool SINGLE>
+template <class G, bool SINGLE, bool PER_PLY>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                              int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps,
@@ -727,8 +733,8 @@ k_connect_step_random_stream(G g, uint64_t* __restrict__ planes, uint8_t* __rest
         const uint32_t was0 = st0, was1 = st1;
         const uint64_t game = first_game + 2ull * (uint64_t)t;
         uint64_t p00 = a.x, p01 = b.x, p10 = a.y, p11 = b.y;  // board 2t: planes p00 / p01, board 2t + 1: p10 / p11
-        const uint32_t n0 = play_plies<SINGLE>(g, bottoms, cells, p00, p01, st0, seed, game, count);
-        const uint32_t n1 = play_plies<SINGLE>(g, bottoms, cells, p10, p11, st1, seed, game + 1ull, count);
+        const uint32_t n0 = play_plies<SINGLE, PER_PLY>(g, bottoms, cells, p00, p01, st0, seed, game, count);
+        const uint32_t n1 = play_plies<SINGLE, PER_PLY>(g, bottoms, cells, p10, p11, st1, seed, game + 1ull, count);
         // The next pair's loads have had this pair's play to arrive: wait for them HERE, before this pair's stores go
         // out.  Left to itself the compiler waits at the top of the next iteration -- after that iteration's own loads
         // were issued, and with vmcnt(0) because a run-time number of stores sits between the two: it waited for the
@@ -904,7 +910,7 @@ struct WaveCodes {
 // sub-step j is player j & 1: no plane swap, no ply counter.  A lane that is not playing executes the same
 // instructions with `live` = 0 -- the stone it drops is (live << position) = 0 -- so the four plies of a block and
 // the philox call in front of them form ONE basic block for the scheduler; only refill and store are conditional.
-template <class G, bool CAPPED, bool FROM_INITIAL, bool CODES>
+template <class G, bool CAPPED, bool FROM_INITIAL, bool CODES, bool PER_PLY>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                           int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
@@ -990,12 +996,12 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
         // ---- the block's word (one philox call covers four blocks; lanes sit in different blocks, so it is made every
         // time), four plies, no control flow
         const uint32_t was_live = live;
-        const uint32_t word = philox_word(philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk >> 2), blk);
+        const BlockDraws<PER_PLY> draws(seed, first_game + (uint64_t)(begin + game), blk);
         uint32_t open = (hts >> 3) & ONES;
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t cnt = (uint32_t)__popc(open);
-            const uint32_t idx = sample_index(sub_draw(word, j), cnt);
+            const uint32_t idx = sample_index(draws.draw(j), cnt);
             // nibble x of cmp = 8 + idx - (open columns among 0..x): (idx - open) * ONES is idx * ONES - open * ONES
             uint64_t cmp64, carry;  // (idx - open) * ONES + 0x88888888 as one v_mad_u64_u32 (hipcc would pick mul_lo + add)
             asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(cmp64), "=s"(carry) : "v"(idx - open), "s"(ONES), "v"(eights));
@@ -1078,11 +1084,12 @@ k_connect_rollout_aligned(G g, uint64_t* __restrict__ planes, uint8_t* __restric
 // The pool is a ring of 64 slots (128 before: with the words a slot is 52 bytes, and six workgroups a CU -- three launches
 // in flight -- leave each wave 6 KB of LDS): when it runs dry the lanes that need a board first take what is left, THEN
 // all 64 lanes open the chunk's next 64 games over the emptied slots, then the remaining needy lanes take from those.
-template <class G, int OPEN_BLOCKS>
+template <class G, int OPEN_BLOCKS, bool PER_PLY = false>
 struct OpenedWords {
     // the last block a game can reach; run-time geometries: the launcher admits boards of at most 48 cells (12 blocks)
     static constexpr int LAST = G::STATIC_H > 0 ? (G::STATIC_H * G::STATIC_W + 3) / 4 - 1 : 11;
-    static constexpr int COUNT = LAST - OPEN_BLOCKS + 1 > 1 ? LAST - OPEN_BLOCKS + 1 : 1;   // words parked with a board
+    // words parked with a board (the strict contract parks none: its loop makes a philox call a block, as round 4's did)
+    static constexpr int COUNT = PER_PLY ? 1 : (LAST - OPEN_BLOCKS + 1 > 1 ? LAST - OPEN_BLOCKS + 1 : 1);
     static constexpr int QUADS = (COUNT + 3) / 4;
     static_assert(LAST <= 11 && OPEN_BLOCKS >= 1 && OPEN_BLOCKS <= 4, "three philox calls cover blocks 0 .. 11");
 };
@@ -1095,12 +1102,14 @@ struct OpenedPool {  // per wave
     uint4 words[QUADS][SLOTS];     // the words of blocks OPEN_BLOCKS, OPEN_BLOCKS + 1, ...
 };
 
-template <class G, int OPEN_BLOCKS, bool CODES>
+// PER_PLY (round 6): the same kernel under the strict RNG contract -- a philox word per ply.  Nothing is parked beside a
+// board: a block makes its own philox call (its four words are its draws), the opening one per block.
+template <class G, int OPEN_BLOCKS, bool CODES, bool PER_PLY>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                          int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps,
                          uint32_t games_per_wave, uint32_t* __restrict__ codes_out) {
-    using OW = OpenedWords<G, OPEN_BLOCKS>;
+    using OW = OpenedWords<G, OPEN_BLOCKS, PER_PLY>;
     constexpr int NWORDS = OW::QUADS * 4;
     using Pool = OpenedPool<OW::QUADS>;
     extern __shared__ uint32_t code_lds[];  // one outcome BYTE per game of the wave's chunk: games_per_wave / 4 dwords per wave
@@ -1134,6 +1143,7 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
     uint32_t wnext = 0;    // the word of this lane's next block (read from lane_words a block ahead)
     uint32_t* const my_words = &lane_words[threadIdx.x >> 6][0][lane];
     uint32_t wrow = 0;     // the row of lane_words the block after next reads
+    uint32_t myblk = 0;    // PER_PLY: the block this lane's game plays next
 
     if (avail == 0u) return;
     // The outcome of game i of the chunk is byte i of the wave's LDS slice (a plain byte store where the game ends, no
@@ -1204,14 +1214,21 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
     // and reward follow from the codes); the lane's words move down one
     auto play_block = [&]() {
         const uint32_t was_live = live;
-        const uint32_t word = wnext;
-        wnext = my_words[wrow * BGS_WAVE];   // (used by the NEXT block: the read has a whole block to arrive)
-        wrow = wrow + 1u < (uint32_t)NWORDS - 1u ? wrow + 1u : (uint32_t)NWORDS - 1u;   // (a finished lane idles on the last row)
+        Philox4 four = {{0u, 0u, 0u, 0u}};
+        uint32_t word = 0u;
+        if constexpr (PER_PLY) {
+            four = philox4x32_10(seed, first_game + (uint64_t)(begin + game), myblk);
+            myblk += 1u;
+        } else {
+            word = wnext;
+            wnext = my_words[wrow * BGS_WAVE];   // (used by the NEXT block: the read has a whole block to arrive)
+            wrow = wrow + 1u < (uint32_t)NWORDS - 1u ? wrow + 1u : (uint32_t)NWORDS - 1u;   // (a finished lane idles on the last row)
+        }
         uint32_t open = (hts >> 3) & ONES;
-        full_ply(std::integral_constant<uint32_t, 0>{}, sub_draw<0>(word), p, hts, open, live, anywon);
-        full_ply(std::integral_constant<uint32_t, 1>{}, sub_draw<1>(word), p, hts, open, live, anywon);
-        full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(word), p, hts, open, live, anywon);
-        full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(word), p, hts, open, live, anywon);
+        full_ply(std::integral_constant<uint32_t, 0>{}, PER_PLY ? four.v[0] : sub_draw<0>(word), p, hts, open, live, anywon);
+        full_ply(std::integral_constant<uint32_t, 1>{}, PER_PLY ? four.v[1] : sub_draw<1>(word), p, hts, open, live, anywon);
+        full_ply(std::integral_constant<uint32_t, 2>{}, PER_PLY ? four.v[2] : sub_draw<2>(word), p, hts, open, live, anywon);
+        full_ply(std::integral_constant<uint32_t, 3>{}, PER_PLY ? four.v[3] : sub_draw<3>(word), p, hts, open, live, anywon);
         if (was_live != 0 && live == 0) {
             *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane0) + (game * 8u)) = p[0];
             *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(plane1) + (game * 8u)) = p[1];
@@ -1225,13 +1242,17 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
         p[0] = pool.plane[0][slot];
         p[1] = pool.plane[1][slot];
         hts = pool.cols[slot];
+        if constexpr (PER_PLY) {
+            myblk = (uint32_t)OPEN_BLOCKS;
+        } else {
 #pragma unroll
-        for (int k = 0; k < OW::QUADS; ++k) {
-            const uint4 v = pool.words[k][slot];
-            if (k == 0) wnext = v.x; else my_words[(4 * k) * BGS_WAVE] = v.x;
-            my_words[(4 * k + 1) * BGS_WAVE] = v.y;
-            my_words[(4 * k + 2) * BGS_WAVE] = v.z;
-            my_words[(4 * k + 3) * BGS_WAVE] = v.w;
+            for (int k = 0; k < OW::QUADS; ++k) {
+                const uint4 v = pool.words[k][slot];
+                if (k == 0) wnext = v.x; else my_words[(4 * k) * BGS_WAVE] = v.x;
+                my_words[(4 * k + 1) * BGS_WAVE] = v.y;
+                my_words[(4 * k + 2) * BGS_WAVE] = v.z;
+                my_words[(4 * k + 3) * BGS_WAVE] = v.w;
+            }
         }
         wrow = 1u;
         anywon = false;
@@ -1245,37 +1266,47 @@ k_connect_rollout_opened(G g, uint64_t* __restrict__ planes, uint8_t* __restrict
         uint32_t h4 = top * columns, alive = ~0u, op = columns;
         bool won_any = false;
         uint32_t words[12];   // the words of blocks 0 .. 11: three philox calls (fewer when the board cannot last that long)
-        {
-            const Philox4 d = philox4x32_10(seed, id, 0u);
-            words[0] = d.v[0]; words[1] = d.v[1]; words[2] = d.v[2]; words[3] = d.v[3];
-        }
+        // the draws of block b of the opening: sub-draws of its word, or (strict contract) the four words of its own call
+        Philox4 own = philox4x32_10(seed, id, 0u);
+        using J0 = std::integral_constant<uint32_t, 0>; using J1 = std::integral_constant<uint32_t, 1>;
+        using J2 = std::integral_constant<uint32_t, 2>; using J3 = std::integral_constant<uint32_t, 3>;
+#define BGS_DRAW_OF(JT, b) (PER_PLY ? own.v[JT::value] : sub_draw<JT::value>(words[b]))
+        if constexpr (!PER_PLY) {
+            words[0] = own.v[0]; words[1] = own.v[1]; words[2] = own.v[2]; words[3] = own.v[3];
 #pragma unroll
-        for (int c = 1; c < 3; ++c) {
-            if (4 * c <= OW::LAST) {
-                const Philox4 d = philox4x32_10(seed, id, (uint32_t)c);
-                words[4 * c] = d.v[0]; words[4 * c + 1] = d.v[1]; words[4 * c + 2] = d.v[2]; words[4 * c + 3] = d.v[3];
-            } else {
-                words[4 * c] = words[4 * c + 1] = words[4 * c + 2] = words[4 * c + 3] = 0u;
+            for (int c = 1; c < 3; ++c) {
+                if (4 * c <= OW::LAST) {
+                    const Philox4 d = philox4x32_10(seed, id, (uint32_t)c);
+                    words[4 * c] = d.v[0]; words[4 * c + 1] = d.v[1]; words[4 * c + 2] = d.v[2]; words[4 * c + 3] = d.v[3];
+                } else {
+                    words[4 * c] = words[4 * c + 1] = words[4 * c + 2] = words[4 * c + 3] = 0u;
+                }
             }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 12; ++c) words[c] = 0u;
         }
-        cheap_ply(0u, sub_draw<0>(words[0]), q, h4);
-        cheap_ply(1u, sub_draw<1>(words[0]), q, h4);
-        cheap_ply(2u, sub_draw<2>(words[0]), q, h4);
-        cheap_ply(3u, sub_draw<3>(words[0]), q, h4);
+        cheap_ply(0u, BGS_DRAW_OF(J0, 0), q, h4);
+        cheap_ply(1u, BGS_DRAW_OF(J1, 0), q, h4);
+        cheap_ply(2u, BGS_DRAW_OF(J2, 0), q, h4);
+        cheap_ply(3u, BGS_DRAW_OF(J3, 0), q, h4);
         if (OPEN_BLOCKS >= 2) {
-            cheap_ply(0u, sub_draw<0>(words[1]), q, h4);
-            cheap_ply(1u, sub_draw<1>(words[1]), q, h4);
+            if constexpr (PER_PLY) own = philox4x32_10(seed, id, 1u);
+            cheap_ply(0u, BGS_DRAW_OF(J0, 1), q, h4);
+            cheap_ply(1u, BGS_DRAW_OF(J1, 1), q, h4);
             op = (h4 >> 3) & ONES;
-            full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(words[1]), q, h4, op, alive, won_any);
-            full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(words[1]), q, h4, op, alive, won_any);
+            full_ply(J2{}, BGS_DRAW_OF(J2, 1), q, h4, op, alive, won_any);
+            full_ply(J3{}, BGS_DRAW_OF(J3, 1), q, h4, op, alive, won_any);
         }
 #pragma unroll
         for (int ob = 2; ob < OPEN_BLOCKS; ++ob) {  // further blocks in lock step
-            full_ply(std::integral_constant<uint32_t, 0>{}, sub_draw<0>(words[ob]), q, h4, op, alive, won_any);
-            full_ply(std::integral_constant<uint32_t, 1>{}, sub_draw<1>(words[ob]), q, h4, op, alive, won_any);
-            full_ply(std::integral_constant<uint32_t, 2>{}, sub_draw<2>(words[ob]), q, h4, op, alive, won_any);
-            full_ply(std::integral_constant<uint32_t, 3>{}, sub_draw<3>(words[ob]), q, h4, op, alive, won_any);
+            if constexpr (PER_PLY) own = philox4x32_10(seed, id, (uint32_t)ob);
+            full_ply(J0{}, BGS_DRAW_OF(J0, ob), q, h4, op, alive, won_any);
+            full_ply(J1{}, BGS_DRAW_OF(J1, ob), q, h4, op, alive, won_any);
+            full_ply(J2{}, BGS_DRAW_OF(J2, ob), q, h4, op, alive, won_any);
+            full_ply(J3{}, BGS_DRAW_OF(J3, ob), q, h4, op, alive, won_any);
         }
+#undef BGS_DRAW_OF
         if (OPEN_BLOCKS >= 2 && og < avail && alive == 0) {  // ended inside the opening: a win, or a small board is full
             plane0[og] = q[0];
             plane1[og] = q[1];
@@ -1357,7 +1388,8 @@ template <class G, bool CAPPED>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout_aligned_wide(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status,
                                uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game,
-                               uint32_t max_plies, unsigned long long* __restrict__ steps, uint32_t games_per_wave) {
+                               uint32_t max_plies, unsigned long long* __restrict__ steps, uint32_t games_per_wave,
+                               uint32_t per_ply) {
     constexpr int NW = G::NW;
     constexpr uint32_t ONES = 0x11111111u;
     const int h = g.h(), w = g.w();
@@ -1402,11 +1434,13 @@ k_connect_rollout_aligned_wide(G g, uint64_t* __restrict__ planes, uint8_t* __re
         }
 
         const uint64_t was_live = live;
-        const uint32_t word = philox_word(philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk >> 2), blk);
+        // (per_ply, wave-uniform: the strict contract -- the call's four words are the block's draws)
+        const Philox4 four = philox4x32_10(seed, first_game + (uint64_t)(begin + game), per_ply ? blk : blk >> 2);
+        const uint32_t word = philox_word(four, blk);
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t count_lo = (uint32_t)__popc(open_lo);
-            const uint32_t idx = sample_index(sub_draw(word, j), count_lo + (uint32_t)__popc(open_hi));
+            const uint32_t idx = sample_index(per_ply ? four.v[j] : sub_draw(word, j), count_lo + (uint32_t)__popc(open_hi));
             const bool in_lo = idx < count_lo;
             const uint32_t part = in_lo ? open_lo : open_hi;
             const uint32_t rank_in_part = in_lo ? idx : idx - count_lo;
@@ -1521,7 +1555,7 @@ struct OpenedBoard {
 };
 static_assert(sizeof(OpenedBoard) == 64, "one cache line");
 
-template <class G>
+template <class G, bool PER_PLY>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_open_lds(G g, OpenedBoard* __restrict__ opened, int64_t n, uint64_t seed, uint64_t first_game,
                    unsigned long long* __restrict__ steps) {
@@ -1535,9 +1569,11 @@ k_connect_open_lds(G g, OpenedBoard* __restrict__ opened, int64_t n, uint64_t se
         const Philox4 words = philox4x32_10(seed, first_game + (uint64_t)i, 0u);   // the words of blocks 0 .. 3
 #pragma unroll
         for (uint32_t blk = 0; blk < kOpenedBlocks; ++blk) {
+            Philox4 own = words;   // the strict contract: a call per block, its four words are the block's draws
+            if (PER_PLY && blk > 0u) own = philox4x32_10(seed, first_game + (uint64_t)i, blk);
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t col = sample_index(sub_draw(words.v[blk], j), (uint32_t)W);   // every column is open
+                const uint32_t col = sample_index(PER_PLY ? own.v[j] : sub_draw(words.v[blk], j), (uint32_t)W);   // every column is open
                 const uint32_t v = (uint32_t)(hts >> (4u * col)) & 15u;
                 set_bit(p[j & 1u], (int)(col * (uint32_t)(H + 1) + v));
                 hts += 1ull << (4u * col);
@@ -1559,7 +1595,7 @@ k_connect_open_lds(G g, OpenedBoard* __restrict__ opened, int64_t n, uint64_t se
     add_steps(steps, stepped);
 }
 
-template <class G, bool CAPPED, bool CODES, int ENTRY>
+template <class G, bool CAPPED, bool CODES, int ENTRY, bool PER_PLY>
 __global__ void __launch_bounds__(BGS_BLOCK)
 k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ reward,
                       int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
@@ -1705,11 +1741,11 @@ k_connect_rollout_lds(G g, uint64_t* __restrict__ planes, uint8_t* __restrict__ 
         }
 
         const uint32_t was_live = live;
-        const uint32_t word = philox_word(philox4x32_10(seed, first_game + (uint64_t)(begin + game), blk >> 2), blk);
+        const BlockDraws<PER_PLY> draws(seed, first_game + (uint64_t)(begin + game), blk);
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t count_lo = (uint32_t)__popc(open_lo);
-            const uint32_t idx = sample_index(sub_draw(word, j), count_lo + (uint32_t)__popc(open_hi));
+            const uint32_t idx = sample_index(draws.draw(j), count_lo + (uint32_t)__popc(open_hi));
             const bool in_lo = idx < count_lo;
             const uint32_t part = in_lo ? open_lo : open_hi;
             const uint32_t rank_in_part = in_lo ? idx : idx - count_lo;
@@ -2054,14 +2090,19 @@ void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
         dispatch(b->cg, [&](auto g) {
             using G = decltype(g);
             if constexpr (G::NW == 1) {
-                if (count == 1u)
-                    hipLaunchKernelGGL((k_connect_step_random_stream<G, true>), dim3((unsigned)blocks), dim3(BGS_BLOCK), 0,
+                auto launch = [&](auto single_tag, auto rng_tag) {
+                    constexpr bool SINGLE = decltype(single_tag)::value, PER_PLY = decltype(rng_tag)::value;
+                    hipLaunchKernelGGL((k_connect_step_random_stream<G, SINGLE, PER_PLY>), dim3((unsigned)blocks), dim3(BGS_BLOCK), 0,
                                        b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
                                        seed, b->first_game, b->d_steps, count);
-                else
-                    hipLaunchKernelGGL((k_connect_step_random_stream<G, false>), dim3((unsigned)blocks), dim3(BGS_BLOCK), 0,
-                                       b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
-                                       seed, b->first_game, b->d_steps, count);
+                };
+                if (count == 1u) {
+                    if (b->rng_per_ply) launch(std::true_type{}, std::true_type{});
+                    else launch(std::true_type{}, std::false_type{});
+                } else {
+                    if (b->rng_per_ply) launch(std::false_type{}, std::true_type{});
+                    else launch(std::false_type{}, std::false_type{});
+                }
             }
         });
         return;
@@ -2072,7 +2113,7 @@ void connect_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
         using Game = typename decltype(game_tag)::type;
         hipLaunchKernelGGL((k_connect_step_random<G, Game>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g,
                            b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
-                           b->d_steps);
+                           b->d_steps, b->rng_per_ply ? 1u : 0u);
     });
 }
 
@@ -2111,6 +2152,12 @@ void status_to_ended(const bgs_batch* b, uint8_t* d_ended) {
 // k_pack_outcomes behind it)
 bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32_t flags, uint32_t* codes_out) {
     const uint32_t cap = max_plies < 0 ? 0u : (uint32_t)max_plies;
+    // the RNG contract of this call: the batch's (bgs_set_rng_contract), or the strict one by flag (BGS_ROLLOUT_DRAW_PER_PLY)
+    const bool per_ply = b->rng_per_ply || (flags & 4u);
+    auto with_rng = [&](auto&& f) {
+        if (per_ply) f(std::true_type{});
+        else f(std::false_type{});
+    };
     // resident waves: CUs x 4 SIMDs x waves per SIMD; every wave gets an equal contiguous chunk of games, a multiple
     // of 64 (whole dwords of outcome codes per wave, whole refill rounds)
     const int64_t resident = (int64_t)b->num_cus * 4 * b->rollout_wps;
@@ -2131,7 +2178,7 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
             constexpr bool CAPPED = decltype(capped_tag)::value;
             hipLaunchKernelGGL((k_connect_rollout<G, Game, INITIAL, CAPPED>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream,
                                g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
-                               b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+                               b->first_game, cap, b->d_steps, (uint32_t)per_wave, per_ply ? 1u : 0u);
         };
         // a cap of height * width plies or more can never bind: drop the per-ply test
         const bool capped = cap < (uint32_t)(b->cg.h * b->cg.w);
@@ -2150,17 +2197,20 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
                 auto launch_aligned = [&](auto capped_tag, auto initial_tag) {
                     constexpr bool CAPPED = decltype(capped_tag)::value;
                     constexpr bool INITIAL = decltype(initial_tag)::value;
-                    if (fuse_codes) {
-                        hipLaunchKernelGGL((k_connect_rollout_aligned<G, CAPPED, INITIAL, true>), dim3(blocks), dim3(BGS_BLOCK),
-                                           code_lds, b->stream, g, b->d_planes, b->d_status,
-                                           reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps,
-                                           (uint32_t)per_wave, codes_out);
-                        fused = true;
-                    } else {
-                        hipLaunchKernelGGL((k_connect_rollout_aligned<G, CAPPED, INITIAL, false>), dim3(blocks), dim3(BGS_BLOCK),
-                                           0, b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward),
-                                           b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr);
-                    }
+                    with_rng([&](auto rng_tag) {
+                        constexpr bool PER_PLY = decltype(rng_tag)::value;
+                        if (fuse_codes) {
+                            hipLaunchKernelGGL((k_connect_rollout_aligned<G, CAPPED, INITIAL, true, PER_PLY>), dim3(blocks), dim3(BGS_BLOCK),
+                                               code_lds, b->stream, g, b->d_planes, b->d_status,
+                                               reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps,
+                                               (uint32_t)per_wave, codes_out);
+                            fused = true;
+                        } else {
+                            hipLaunchKernelGGL((k_connect_rollout_aligned<G, CAPPED, INITIAL, false, PER_PLY>), dim3(blocks), dim3(BGS_BLOCK),
+                                               0, b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward),
+                                               b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr);
+                        }
+                    });
                 };
                 const size_t outcome_lds = (size_t)4 * per_wave;  // K2o: one outcome byte per game
                 // (boards of at most 48 cells: a game is at most 12 blocks of four plies, whose words three philox calls give)
@@ -2170,10 +2220,13 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
                     auto launch_opened = [&](auto blocks_tag, auto codes_tag) {
                         constexpr int OPEN_BLOCKS = decltype(blocks_tag)::value;
                         constexpr bool CODES = decltype(codes_tag)::value;
-                        hipLaunchKernelGGL((k_connect_rollout_opened<G, OPEN_BLOCKS, CODES>), dim3(blocks), dim3(BGS_BLOCK),
-                                           outcome_lds, b->stream, g, b->d_planes, b->d_status,
-                                           reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, b->d_steps,
-                                           (uint32_t)per_wave, CODES ? codes_out : nullptr);
+                        with_rng([&](auto rng_tag) {
+                            constexpr bool PER_PLY = decltype(rng_tag)::value;
+                            hipLaunchKernelGGL((k_connect_rollout_opened<G, OPEN_BLOCKS, CODES, PER_PLY>), dim3(blocks), dim3(BGS_BLOCK),
+                                               outcome_lds, b->stream, g, b->d_planes, b->d_status,
+                                               reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, b->d_steps,
+                                               (uint32_t)per_wave, CODES ? codes_out : nullptr);
+                        });
                         fused = CODES;
                     };
                     const bool deep = b->cg.k >= 4 && b->cg.h >= 6;
@@ -2209,25 +2262,31 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
                 auto launch_lds = [&](auto capped_tag, auto entry_tag) {
                     constexpr bool CAPPED = decltype(capped_tag)::value;
                     constexpr int ENTRY = decltype(entry_tag)::value;
-                    if (fuse_codes) {
-                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, true, ENTRY>), dim3(blocks), dim3(BGS_BLOCK),
-                                           tile + code_lds, b->stream, g, b->d_planes, b->d_status,
-                                           reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps,
-                                           (uint32_t)per_wave, codes_out, heights);
-                        fused = true;
-                    } else {
-                        hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, false, ENTRY>), dim3(blocks), dim3(BGS_BLOCK), tile,
-                                           b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward),
-                                           b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr, heights);
-                    }
+                    with_rng([&](auto rng_tag) {
+                        constexpr bool PER_PLY = decltype(rng_tag)::value;
+                        if (fuse_codes) {
+                            hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, true, ENTRY, PER_PLY>), dim3(blocks), dim3(BGS_BLOCK),
+                                               tile + code_lds, b->stream, g, b->d_planes, b->d_status,
+                                               reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps,
+                                               (uint32_t)per_wave, codes_out, heights);
+                            fused = true;
+                        } else {
+                            hipLaunchKernelGGL((k_connect_rollout_lds<G, CAPPED, false, ENTRY, PER_PLY>), dim3(blocks), dim3(BGS_BLOCK), tile,
+                                               b->stream, g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward),
+                                               b->n, seed, b->first_game, cap, b->d_steps, (uint32_t)per_wave, nullptr, heights);
+                        }
+                    });
                 };
                 // the opening as a launch of its own: nobody can win and no column can fill in the first kOpenedPlies plies
                 constexpr bool can_open = G::STATIC_K > 0 && 2 * G::STATIC_K - 2 >= (int)kOpenedPlies &&
                                           G::STATIC_H >= (int)kOpenedPlies && G::STATIC_H <= 15;
                 if ((flags & 1u) && !capped && can_open && G::NW <= 3 && b->rollout_opening &&
                     b->staging_bytes >= (size_t)b->n * sizeof(OpenedBoard)) {
-                    hipLaunchKernelGGL((k_connect_open_lds<G>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, g,
-                                       reinterpret_cast<OpenedBoard*>(b->d_staging), b->n, seed, b->first_game, b->d_steps);
+                    with_rng([&](auto rng_tag) {
+                        hipLaunchKernelGGL((k_connect_open_lds<G, decltype(rng_tag)::value>), dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0,
+                                           b->stream, g, reinterpret_cast<OpenedBoard*>(b->d_staging), b->n, seed, b->first_game,
+                                           b->d_steps);
+                    });
                     launch_lds(std::false_type{}, std::integral_constant<int, kEntryOpened>{});
                 } else if (flags & 1u) {
                     if (capped) launch_lds(std::true_type{}, std::integral_constant<int, kEntryInitial>{});
@@ -2243,11 +2302,11 @@ bool connect_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint3
             if (capped)
                 hipLaunchKernelGGL((k_connect_rollout_aligned_wide<G, true>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream,
                                    g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
-                                   b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+                                   b->first_game, cap, b->d_steps, (uint32_t)per_wave, per_ply ? 1u : 0u);
             else
                 hipLaunchKernelGGL((k_connect_rollout_aligned_wide<G, false>), dim3(blocks), dim3(BGS_BLOCK), 0, b->stream,
                                    g, b->d_planes, b->d_status, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed,
-                                   b->first_game, cap, b->d_steps, (uint32_t)per_wave);
+                                   b->first_game, cap, b->d_steps, (uint32_t)per_wave, per_ply ? 1u : 0u);
             return;
         }
         with_game(Tag<GenericGame<G>>{});

@@ -30,17 +30,19 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBl
 // the draw of a ply (RNG contract: bgs_common.h).  Bounce: a philox word per ply, one call per 4 plies; Connect: a word per
 // block of four plies, one call per 16 plies, the ply's draw a sub-draw of its block's word.  Recomputed when the ply
 // leaves the plies the held call covers.
+// (Connect under the strict contract -- per_ply, wave-uniform -- draws as Bounce does)
 template <bool CONNECT>
 struct Draws {
-    static constexpr uint32_t SHIFT = CONNECT ? 4u : 2u;
     Philox4 blk;
     uint32_t have;  // index of the call held + 1 (0 = none)
+    uint32_t per_ply = 0;
     __device__ __forceinline__ uint32_t at(uint64_t seed, uint64_t game, uint32_t ply) {
-        if (have != (ply >> SHIFT) + 1u) {
-            blk = philox4x32_10(seed, game, ply >> SHIFT);
-            have = (ply >> SHIFT) + 1u;
+        const uint32_t shift = (CONNECT && !per_ply) ? 4u : 2u;
+        if (have != (ply >> shift) + 1u) {
+            blk = philox4x32_10(seed, game, ply >> shift);
+            have = (ply >> shift) + 1u;
         }
-        return CONNECT ? sub_draw(connect_word(blk, ply), ply & 3u) : philox_word(blk, ply);
+        return CONNECT ? connect_draw(per_ply, blk, ply) : philox_word(blk, ply);
     }
 };
 
@@ -105,7 +107,7 @@ g_connect_reset(GConnect c, int8_t* __restrict__ grid, uint8_t* __restrict__ sta
 __global__ void __launch_bounds__(kBlock)
 g_connect_play(GConnect c, int8_t* __restrict__ grid, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
-               uint32_t count, int from_initial, unsigned long long* __restrict__ steps) {
+               uint32_t count, int from_initial, unsigned long long* __restrict__ steps, uint32_t per_ply) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     uint32_t stepped = 0;
     if (i < n) {
@@ -121,6 +123,7 @@ g_connect_play(GConnect c, int8_t* __restrict__ grid, uint8_t* __restrict__ stat
         }
         Draws<true> draws;
         draws.have = 0;
+        draws.per_ply = per_ply;
         while (st == BGS_ST_RUNNING && plies < max_plies && stepped < count) {
             const uint32_t idx = sample_index(draws.at(seed, first_game + (uint64_t)i, plies), (uint32_t)gc_legal_count(c, g));
             int x = 0;
@@ -686,11 +689,12 @@ void generic_reset(const bgs_batch* b) {
 }
 
 // count plies per board (count = UINT32_MAX with max_plies as the bound = rollout)
-void generic_play(const bgs_batch* b, uint64_t seed, uint32_t max_plies, uint32_t count, bool from_initial) {
+void generic_play(const bgs_batch* b, uint64_t seed, uint32_t max_plies, uint32_t count, bool from_initial, bool per_ply) {
     if (max_plies > 65535u) max_plies = 65535u;  // plies are stored as uint16
     if (b->game == BGS_GAME_CONNECT)
         hipLaunchKernelGGL(g_connect_play, dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream, gconnect(b), cells(b), b->d_status,
-                           b->d_plies, rewards(b), b->n, seed, b->first_game, max_plies, count, from_initial ? 1 : 0, b->d_steps);
+                           b->d_plies, rewards(b), b->n, seed, b->first_game, max_plies, count, from_initial ? 1 : 0, b->d_steps,
+                           (per_ply || b->rng_per_ply) ? 1u : 0u);
     else
         with_words(b, [&](auto words) {
             hipLaunchKernelGGL((g_bounce_play<decltype(words)::value>), dim3(blocks_for(b->n)), dim3(kBlock), 0, b->stream,

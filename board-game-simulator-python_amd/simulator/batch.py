@@ -338,6 +338,15 @@ class _Batch:
         """Global id of board 0: RNG streams are keyed by global game id, so shards reproduce the unsharded run."""
         _abi.check(_abi.lib().bgs_set_first_game(self._handle, ctypes.c_uint64(first_game)))
 
+    def set_rng_contract(self, contract: str) -> None:
+        """Connect: "per-block" (default: a philox word per block of four plies) or "per-ply" (strict: a word per ply, as
+        Bounce draws -- one independent uniform choice per ply, what `random.choice` gives a caller of the reference,
+        README.md:62).  Applies to every later random step / rollout of this batch (bgs_set_rng_contract)."""
+        codes = {"per-block": _abi.RNG_PER_BLOCK, "per-ply": _abi.RNG_PER_PLY}
+        if contract not in codes:
+            raise ValueError(f"unknown RNG contract {contract!r}: 'per-block' or 'per-ply'")
+        _abi.check(_abi.lib().bgs_set_rng_contract(self._handle, codes[contract]))
+
     def set_launches_in_flight(self, launches: int) -> None:
         """A hint: how many rollout launches the caller keeps in flight on the device (1, the default: one at a time).
         Results never depend on it; the Bounce rollout shapes its launch by it (bgs_set_launches_in_flight).  The

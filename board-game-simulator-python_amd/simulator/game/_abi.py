@@ -23,6 +23,8 @@ BGS_ERR_NO_DEVICE = -4
 
 BUF_PLANES, BUF_STATUS, BUF_PLIES, BUF_REWARD, BUF_STEPS, BUF_STAGING = range(6)
 ROLLOUT_FROM_INITIAL = 1
+ROLLOUT_DRAW_PER_PLY = 4   # Connect: this rollout call draws under the strict contract
+RNG_PER_BLOCK, RNG_PER_PLY = 0, 1   # bgs_set_rng_contract
 ENV_AUTO_RESET = 1
 
 GAME_CONNECT = 1
@@ -56,6 +58,7 @@ SIGNATURES = {
     "bgs_stream_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "bgs_stream_destroy": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "bgs_set_first_game": (ctypes.c_int, [c_handle, ctypes.c_uint64]),
+    "bgs_set_rng_contract": (ctypes.c_int, [c_handle, ctypes.c_int]),
     "bgs_set_launches_in_flight": (ctypes.c_int, [c_handle, ctypes.c_int32]),
     "bgs_synchronize": (ctypes.c_int, [c_handle]),
     "bgs_info": (

@@ -288,7 +288,8 @@ class RolloutPipeline:
                 nxt += 1
         finally:
             # a consumer that stops early: whatever was fed is still played and delivered (its arrays are nobody's any more)
-            if nxt < self._next:
+            # (a generator left suspended across close() finds no executor any more: close() has drained and dropped it)
+            if nxt < self._next and self._exe is not None:
                 self._exe.drain()
 
     @property

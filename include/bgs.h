@@ -33,6 +33,9 @@
  *            plies within 4 x 10^-7 of 1 / 49 (13 columns: 2.9 x 10^-4, 16 columns: 4.3 x 10^-4; tools/subdraw_lattice.c).
  *            Different blocks use different philox words.  (Round 5; until then Connect drew a word per ply too.  One philox
  *            call now serves sixteen plies, and the bench kernel's ply loop holds none: DESIGN.md section 3.)
+ *   Connect, strict contract (round 6; bgs_set_rng_contract(b, BGS_RNG_PER_PLY) or BGS_ROLLOUT_DRAW_PER_PLY): exactly
+ *            Bounce's rule -- a philox word per ply.  The word-per-block contract stays the default; both are pinned by the
+ *            oracle (oracle/bgs_oracle.h: ORC_RNG_PER_BLOCK / ORC_RNG_PER_PLY) and by the -m gpu parity tests.
  * `game` = first_game + index in batch, so results do not depend on sharding, launch geometry or kernel family.
  */
 #ifndef BGS_H
@@ -75,6 +78,14 @@ typedef enum bgs_buffer_id {
 /* rollout flags */
 #define BGS_ROLLOUT_DEFAULT 0u
 #define BGS_ROLLOUT_FROM_INITIAL 1u /* ignore the stored boards: every game starts from Config.sample_initial_state() */
+#define BGS_ROLLOUT_DRAW_PER_PLY 4u /* Connect: this call draws under the strict RNG contract (BGS_RNG_PER_PLY below) */
+
+/* RNG contracts of a Connect batch (bgs_set_rng_contract; Bounce draws a word per ply under either) */
+#define BGS_RNG_PER_BLOCK 0 /* default: a philox word per block of four plies, the plies' draws its sub-draws (see above) */
+#define BGS_RNG_PER_PLY 1   /* strict: a philox word per ply -- draw(seed, game, ply) = philox(counter = (game lo, game hi,
+                             * ply >> 2, 0))[ply & 3], exactly Bounce's: one independent uniform choice per ply, what a
+                             * caller of the reference gets from random.choice (README.md:62).  Costs the rollout kernels a
+                             * philox call per four plies instead of per sixteen (bench.py --rng per-ply prints both rates). */
 
 /* ---- library ------------------------------------------------------------------------------------ */
 BGS_API int bgs_version(void);
@@ -115,6 +126,10 @@ BGS_API int bgs_set_stream(bgs_batch* b, void* hip_stream);
 BGS_API int bgs_stream_create(int device, void** hip_stream);
 BGS_API int bgs_stream_destroy(int device, void* hip_stream);
 BGS_API int bgs_set_first_game(bgs_batch* b, uint64_t first_game); /* global id of board 0 (sharding across GPUs) */
+/* The RNG contract every later random step / rollout of this (Connect) batch draws under: BGS_RNG_PER_BLOCK (default) or
+ * BGS_RNG_PER_PLY.  Build-defined like the RNG itself (the reference has none: its callers use random.choice,
+ * README.md:62); a single rollout call can ask for the strict contract with BGS_ROLLOUT_DRAW_PER_PLY instead. */
+BGS_API int bgs_set_rng_contract(bgs_batch* b, int contract);
 /* A hint, not a rule of the game: how many rollout launches the caller keeps in flight on this batch's device (its own
  * included; 1 = one launch at a time, the default).  Results never depend on it.  The Bounce rollout shapes its launch
  * by it -- alone on the chip: a short bulk pass on many waves (shortest time to the last reward); among 16: few

@@ -173,12 +173,14 @@ int orc_connect_step_actions(int h, int w, int k, int64_t n, int8_t* grid, int8_
 
 /* the caller loop of reference README.md:52-69 with random.choice replaced by the RNG contract of bgs_oracle.h */
 static uint64_t connect_play(int h, int w, int k, int8_t* g, int8_t* player, int8_t* winner, int32_t* plies,
-                             uint64_t seed, uint64_t game, int32_t max_plies, int single_ply) {
+                             uint64_t seed, uint64_t game, int32_t max_plies, int single_ply, int per_ply) {
     int cols[64];
     uint64_t steps = 0;
     while (*winner == -1 && *plies < max_plies) {
         int n = connect_legal_one(h, w, g, *winner, cols);
-        uint32_t idx = orc_connect_sample_index(seed, game, (uint32_t)*plies, (uint32_t)n);
+        /* per_ply: the strict contract (ORC_RNG_PER_PLY) -- a philox word of its own for every ply, as Bounce draws */
+        uint32_t idx = per_ply ? orc_sample_index(seed, game, (uint32_t)*plies, (uint32_t)n)
+                               : orc_connect_sample_index(seed, game, (uint32_t)*plies, (uint32_t)n);
         connect_apply_one(h, w, k, g, player, winner, plies, cols[idx]);
         ++steps;
         if (single_ply) break;
@@ -186,28 +188,38 @@ static uint64_t connect_play(int h, int w, int k, int8_t* g, int8_t* player, int
     return steps;
 }
 
-int orc_connect_step_random(int h, int w, int k, int64_t n, int8_t* grid, int8_t* player, int8_t* winner,
-                            int32_t* plies, uint64_t seed, uint64_t first_game, uint64_t* steps) {
-    if (!connect_cfg_ok(h, w, k) || n < 0) return ORC_ERR_ARG;
+int orc_connect_step_random_rng(int h, int w, int k, int64_t n, int8_t* grid, int8_t* player, int8_t* winner,
+                                int32_t* plies, uint64_t seed, uint64_t first_game, int rng, uint64_t* steps) {
+    if (!connect_cfg_ok(h, w, k) || n < 0 || (rng != ORC_RNG_PER_BLOCK && rng != ORC_RNG_PER_PLY)) return ORC_ERR_ARG;
     uint64_t total = 0;
 #pragma omp parallel for reduction(+ : total) schedule(static)
     for (int64_t i = 0; i < n; ++i)
         total += connect_play(h, w, k, grid + i * h * w, player + i, winner + i, plies + i, seed, first_game + (uint64_t)i,
-                              INT32_MAX, 1);
+                              INT32_MAX, 1, rng == ORC_RNG_PER_PLY);
     if (steps) *steps = total;
     return ORC_OK;
 }
 
-int orc_connect_rollout(int h, int w, int k, int64_t n, int8_t* grid, int8_t* player, int8_t* winner,
-                        int32_t* plies, uint64_t seed, uint64_t first_game, int32_t max_plies, uint64_t* steps) {
-    if (!connect_cfg_ok(h, w, k) || n < 0) return ORC_ERR_ARG;
+int orc_connect_rollout_rng(int h, int w, int k, int64_t n, int8_t* grid, int8_t* player, int8_t* winner,
+                            int32_t* plies, uint64_t seed, uint64_t first_game, int32_t max_plies, int rng, uint64_t* steps) {
+    if (!connect_cfg_ok(h, w, k) || n < 0 || (rng != ORC_RNG_PER_BLOCK && rng != ORC_RNG_PER_PLY)) return ORC_ERR_ARG;
     uint64_t total = 0;
 #pragma omp parallel for reduction(+ : total) schedule(static)
     for (int64_t i = 0; i < n; ++i)
         total += connect_play(h, w, k, grid + i * h * w, player + i, winner + i, plies + i, seed, first_game + (uint64_t)i,
-                              max_plies, 0);
+                              max_plies, 0, rng == ORC_RNG_PER_PLY);
     if (steps) *steps = total;
     return ORC_OK;
+}
+
+int orc_connect_step_random(int h, int w, int k, int64_t n, int8_t* grid, int8_t* player, int8_t* winner,
+                            int32_t* plies, uint64_t seed, uint64_t first_game, uint64_t* steps) {
+    return orc_connect_step_random_rng(h, w, k, n, grid, player, winner, plies, seed, first_game, ORC_RNG_PER_BLOCK, steps);
+}
+
+int orc_connect_rollout(int h, int w, int k, int64_t n, int8_t* grid, int8_t* player, int8_t* winner,
+                        int32_t* plies, uint64_t seed, uint64_t first_game, int32_t max_plies, uint64_t* steps) {
+    return orc_connect_rollout_rng(h, w, k, n, grid, player, winner, plies, seed, first_game, max_plies, ORC_RNG_PER_BLOCK, steps);
 }
 
 /* ------------------------------------------------------------------------------------------------ */

@@ -48,8 +48,14 @@ extern "C" {
  *           plies of a block share is 32 bits of entropy, and their JOINT distribution is the lattice of that generator:
  *           counted over all 2^32 words (tools/subdraw_lattice.c), every one of the 7^4 four-move sequences of a 7-column
  *           board comes within 4.2 x 10^-5 (relative) of 1 / 7^4, every pair of plies within 4 x 10^-7 of 1 / 49;
- *           13 columns: 2.9 x 10^-4, 16 columns: 4.3 x 10^-4.  Blocks are independent philox words. */
+ *           13 columns: 2.9 x 10^-4, 16 columns: 4.3 x 10^-4.  Blocks are independent philox words.
+ *   Connect, STRICT contract (ORC_RNG_PER_PLY; round 6, the form SURVEY.md 7.3 wrote down and the only one until round 5):
+ *           a word per ply exactly as Bounce -- orc_draw / orc_sample_index -- i.e. one independent uniform choice per
+ *           ply, what the reference's callers get from random.choice (README.md:62).  The library offers it as
+ *           BGS_ROLLOUT_DRAW_PER_PLY / bgs_set_rng_contract. */
 #define ORC_SUBDRAW_A 747796405u
+#define ORC_RNG_PER_BLOCK 0   /* Connect: a word per block of four plies (the default) */
+#define ORC_RNG_PER_PLY 1     /* Connect: a word per ply */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint32_t orc_draw(uint64_t seed, uint64_t game, uint32_t ply);            /* Bounce: a word per ply */
 uint32_t orc_sample_index(uint64_t seed, uint64_t game, uint32_t ply, uint32_t n_actions);
@@ -71,6 +77,11 @@ int orc_connect_step_random(int h, int w, int k, int64_t n, int8_t* grid, int8_t
 /* play every running board to its end (or max_plies total plies) */
 int orc_connect_rollout(int h, int w, int k, int64_t n, int8_t* grid, int8_t* player, int8_t* winner,
                         int32_t* plies, uint64_t seed, uint64_t first_game, int32_t max_plies, uint64_t* steps);
+/* the same two under a named RNG contract (ORC_RNG_PER_BLOCK = the two above, ORC_RNG_PER_PLY = the strict one) */
+int orc_connect_step_random_rng(int h, int w, int k, int64_t n, int8_t* grid, int8_t* player, int8_t* winner,
+                                int32_t* plies, uint64_t seed, uint64_t first_game, int rng, uint64_t* steps);
+int orc_connect_rollout_rng(int h, int w, int k, int64_t n, int8_t* grid, int8_t* player, int8_t* winner,
+                            int32_t* plies, uint64_t seed, uint64_t first_game, int32_t max_plies, int rng, uint64_t* steps);
 
 /* ---- Bounce (reference surface: src/simulator/game/bounce.cpp:24-53) ---- */
 /* grid int8[n][h][w]: 0 empty, v>0 a piece that moves exactly v steps; (x, y) coordinates, y=0 bottom */

@@ -127,9 +127,12 @@ class _Batch:
 
 
 class ConnectOracle(_Batch):
-    def __init__(self, height: int, width: int, count: int, n: int):
+    def __init__(self, height: int, width: int, count: int, n: int, per_ply: bool = False):
+        """per_ply: the strict RNG contract (a philox word of its own for every ply, bgs_oracle.h: ORC_RNG_PER_PLY)
+        instead of the default word per block of four plies."""
         super().__init__(n, height, width)
         self.k = int(count)
+        self.rng = 1 if per_ply else 0
         self.reset()
 
     def reset(self) -> None:
@@ -157,9 +160,9 @@ class ConnectOracle(_Batch):
     def step_random(self, seed: int, first_game: int = 0) -> int:
         steps = ctypes.c_uint64(0)
         _check(
-            lib().orc_connect_step_random(
+            lib().orc_connect_step_random_rng(
                 self.h, self.w, self.k, ctypes.c_int64(self.n), *self._state_args(), ctypes.c_uint64(seed),
-                ctypes.c_uint64(first_game), ctypes.byref(steps),
+                ctypes.c_uint64(first_game), ctypes.c_int(self.rng), ctypes.byref(steps),
             ),
             "connect_step_random",
         )
@@ -168,9 +171,9 @@ class ConnectOracle(_Batch):
     def rollout(self, seed: int, first_game: int = 0, max_plies: int = 2**31 - 1) -> int:
         steps = ctypes.c_uint64(0)
         _check(
-            lib().orc_connect_rollout(
+            lib().orc_connect_rollout_rng(
                 self.h, self.w, self.k, ctypes.c_int64(self.n), *self._state_args(), ctypes.c_uint64(seed),
-                ctypes.c_uint64(first_game), ctypes.c_int32(max_plies), ctypes.byref(steps),
+                ctypes.c_uint64(first_game), ctypes.c_int32(max_plies), ctypes.c_int(self.rng), ctypes.byref(steps),
             ),
             "connect_rollout",
         )

@@ -17,7 +17,18 @@
 //          raises the entry's `ready` count once the event has fired;
 //   recv:  the host waits for `ready`, a copy KERNEL mailbox entry -> destination on the caller's stream (a kernel, so
 //          that device-mapped host destinations work like any other), an event, the helper raises `consumed`.
-// Every wait is bounded (60 s) and ends in an error code, never in a hang.
+// Every wait is bounded (60 s; BGS_FAKE_RCCL_TIMEOUT_MS) and ends in an error code, never in a hang.
+//
+// What it REFUSES (round 6) -- the mistakes that RCCL answers with an error, a hang or silent corruption end in an error
+// code here, so that a test sees them:
+//   * a receive whose element count or data type differs from the matching send's (RCCL: undefined -- truncation or a hang);
+//   * a point-to-point call outside ncclGroupStart / ncclGroupEnd (libbgs posts every send / receive inside a group:
+//     ungrouped blocking calls between two ranks that both send first dead-lock on the real thing), a ncclGroupEnd without
+//     a ncclGroupStart, a communicator call with a group left open by the same thread at ncclCommDestroy;
+//   * a peer outside the communicator, a NULL buffer with a non-zero count, an unknown data type, a destroyed communicator;
+//   * a peer that never posts its half: the wait runs into the time limit and the call fails ("never sent" / "never took").
+// A test hook of its own: BGS_FAKE_RCCL_MUTE_AFTER=<rank>:<k> -- rank <rank> stops posting its sends after its first k
+// messages (they are accepted and dropped), i.e. a peer that has gone silent without an error.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
@@ -42,11 +53,21 @@ namespace {
 
 constexpr int kEntries = 16;         // messages in flight per ordered pair of ranks
 constexpr int kMaxWorld = 8;
-constexpr int64_t kTimeoutMs = 60000;
+
+int64_t timeout_ms() {
+    static const int64_t value = [] {
+        const char* e = getenv("BGS_FAKE_RCCL_TIMEOUT_MS");
+        const long long v = e ? atoll(e) : 0;
+        return (int64_t)(v > 0 ? v : 60000);
+    }();
+    return value;
+}
 
 struct alignas(64) Mailbox {
     std::atomic<uint64_t> ready;     // messages whose bytes are in their entry
     std::atomic<uint64_t> consumed;  // messages whose bytes have been copied out
+    uint64_t meta[kEntries];         // per entry: (element count << 8) | data type of the message, written by the sender
+                                     // before `ready` is raised for it
 };
 
 struct alignas(64) Header {
@@ -58,7 +79,7 @@ struct alignas(64) Header {
     Mailbox box[kMaxWorld * kMaxWorld];  // [src * world + dst]
 };
 
-constexpr size_t kHeaderBytes = 8192;   // the payload starts on a page boundary (it is registered with HIP)
+constexpr size_t kHeaderBytes = 16384;   // the payload starts on a page boundary (it is registered with HIP)
 static_assert(sizeof(Header) <= kHeaderBytes, "header must fit its pages");
 
 thread_local std::string g_error = "no error";
@@ -93,6 +114,8 @@ struct Comm {
     std::deque<Op> ops;
     bool stop = false;
     bool broken = false;
+    int mute_after = -1;             // BGS_FAKE_RCCL_MUTE_AFTER: sends beyond this many are dropped
+    uint64_t posted = 0;
 
     uint8_t* entry(int src, int dst, uint64_t seq, bool device_view) const {
         const Header* h = region->header;
@@ -129,8 +152,18 @@ struct Comm {
     }
 };
 
+// the communicators that exist (a destroyed one's memory is gone: its handle is looked up, never dereferenced)
+std::mutex g_live_mu;
+std::vector<Comm*> g_live;
+Comm* live(void* comm) {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    for (Comm* c : g_live)
+        if (c == comm) return c;
+    return nullptr;
+}
+
 bool wait_for(const std::atomic<uint64_t>& counter, uint64_t at_least) {
-    const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(kTimeoutMs);
+    const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms());
     while (counter.load(std::memory_order_acquire) < at_least) {
         if (std::chrono::steady_clock::now() > until) return false;
         std::this_thread::sleep_for(std::chrono::microseconds(20));
@@ -147,6 +180,7 @@ struct Pending {
     bool send;
     void* buf;
     size_t bytes;
+    uint64_t meta;   // (count << 8) | type
     int peer;
     Comm* comm;
     hipStream_t stream;
@@ -162,9 +196,11 @@ int execute(const Pending& p) {
     if (c->broken) return fail("an earlier operation failed");
     if (hipSetDevice(c->device) != hipSuccess) return fail("hipSetDevice failed");
     if (p.send) {
+        if (c->mute_after >= 0 && c->posted++ >= (uint64_t)c->mute_after) return 0;   // (the test hook: a peer gone silent)
         Mailbox& box = h->box[c->rank * c->world + p.peer];
         const uint64_t seq = c->sent[p.peer]++;
         if (seq >= (uint64_t)h->entries && !wait_for(box.consumed, seq + 1 - h->entries)) return fail("send: the peer never took the earlier messages (timeout)");
+        box.meta[seq % h->entries] = p.meta;   // (published by the release store that raises `ready`)
         if (p.bytes && hipMemcpyAsync(c->entry(c->rank, p.peer, seq, false), p.buf, p.bytes, hipMemcpyDeviceToHost, p.stream) != hipSuccess)
             return fail("send: hipMemcpyAsync failed");
         return c->after(p.stream, &box.ready, seq + 1);
@@ -172,6 +208,14 @@ int execute(const Pending& p) {
     Mailbox& box = h->box[p.peer * c->world + c->rank];
     const uint64_t seq = c->received[p.peer]++;
     if (!wait_for(box.ready, seq + 1)) return fail("recv: the peer never sent the message (timeout)");
+    if (box.meta[seq % h->entries] != p.meta) {
+        static thread_local char text[160];
+        const uint64_t m = box.meta[seq % h->entries];
+        snprintf(text, sizeof text, "recv: count / data type mismatch with the matching send (sent %llu x type %d, receiving %llu x type %d)",
+                 (unsigned long long)(m >> 8), (int)(m & 255), (unsigned long long)(p.meta >> 8), (int)(p.meta & 255));
+        c->broken = true;
+        return fail(text);
+    }
     if (p.bytes) {
         hipLaunchKernelGGL(k_deliver, dim3((unsigned)((p.bytes + 255) / 256)), dim3(256), 0, p.stream,
                            c->entry(p.peer, c->rank, seq, true), static_cast<uint8_t*>(p.buf), p.bytes);
@@ -190,7 +234,15 @@ size_t message_bytes() {
 
 int start(Comm* c) {
     if (hipGetDevice(&c->device) != hipSuccess) return fail("hipGetDevice failed");
+    if (const char* e = getenv("BGS_FAKE_RCCL_MUTE_AFTER")) {
+        int rank = -1, k = -1;
+        if (sscanf(e, "%d:%d", &rank, &k) == 2 && rank == c->rank && k >= 0) c->mute_after = k;
+    }
     c->helper = std::thread([c] { c->run(); });
+    {
+        std::lock_guard<std::mutex> lock(g_live_mu);
+        g_live.push_back(c);
+    }
     return 0;
 }
 
@@ -243,7 +295,7 @@ int ncclCommInitRank(void** comm, int world, ncclUniqueId id, int rank) {
     }
     // the collective part: everybody has mapped the file before anybody goes on (and then its name can go)
     r->header->arrived.fetch_add(1, std::memory_order_acq_rel);
-    const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(kTimeoutMs);
+    const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms());
     while (r->header->arrived.load(std::memory_order_acquire) < world) {
         if (std::chrono::steady_clock::now() > until) return fail("ncclCommInitRank: not every rank arrived (timeout)");
         std::this_thread::sleep_for(std::chrono::microseconds(100));
@@ -291,9 +343,17 @@ int ncclCommInitAll(void** comms, int n, const int* devices) {
     return 0;
 }
 
+
 int ncclCommDestroy(void* comm) {
-    Comm* c = static_cast<Comm*>(comm);
-    if (!c) return 0;
+    if (!comm) return 0;
+    Comm* c = live(comm);
+    if (!c) return fail("ncclCommDestroy: not a live communicator (destroyed twice?)");
+    if (g_depth > 0) return fail("ncclCommDestroy inside an open group (ncclGroupEnd is missing)");
+    {
+        std::lock_guard<std::mutex> lock(g_live_mu);
+        for (size_t i = 0; i < g_live.size(); ++i)
+            if (g_live[i] == c) { g_live.erase(g_live.begin() + i); break; }
+    }
     {
         std::lock_guard<std::mutex> lock(c->mu);
         c->stop = true;
@@ -315,13 +375,13 @@ int ncclCommDestroy(void* comm) {
 }
 
 int ncclCommCount(void* comm, int* count) {
-    if (!comm || !count) return fail("bad arguments to ncclCommCount");
+    if (!live(comm) || !count) return fail("bad arguments to ncclCommCount");
     *count = static_cast<Comm*>(comm)->world;
     return 0;
 }
 
 int ncclCommUserRank(void* comm, int* rank) {
-    if (!comm || !rank) return fail("bad arguments to ncclCommUserRank");
+    if (!live(comm) || !rank) return fail("bad arguments to ncclCommUserRank");
     *rank = static_cast<Comm*>(comm)->rank;
     return 0;
 }
@@ -351,24 +411,27 @@ static size_t type_bytes(int type) {   // ncclDataType_t: 0 int8, 1 uint8, 2 int
     return type >= 0 && type <= 8 ? size[type] : 0;
 }
 
+// what a point-to-point call must look like before it is queued: a live communicator, a known type, a peer of the
+// communicator, a buffer -- and an open group (see the header: libbgs never posts outside one)
+static int post(bool send, void* buf, size_t count, int type, int peer, void* comm, hipStream_t stream) {
+    const char* who = send ? "ncclSend" : "ncclRecv";
+    static thread_local char text[128];
+    Comm* c = live(comm);
+    if (!c) { snprintf(text, sizeof text, "%s: not a live communicator", who); return fail(text); }
+    if (!type_bytes(type)) { snprintf(text, sizeof text, "%s: unknown data type %d", who, type); return fail(text); }
+    if (peer < 0 || peer >= c->world) { snprintf(text, sizeof text, "%s: peer %d is outside the communicator (%d ranks)", who, peer, c->world); return fail(text); }
+    if (!buf && count) { snprintf(text, sizeof text, "%s: NULL buffer with a non-zero count", who); return fail(text); }
+    if (g_depth <= 0) { snprintf(text, sizeof text, "%s outside ncclGroupStart / ncclGroupEnd", who); return fail(text); }
+    g_pending.push_back(Pending{send, buf, count * type_bytes(type), ((uint64_t)count << 8) | (uint64_t)type, peer, c, stream});
+    return 0;
+}
+
 int ncclSend(const void* buf, size_t count, int type, int peer, void* comm, hipStream_t stream) {
-    if (!comm || !type_bytes(type)) return fail("bad arguments to ncclSend");
-    Pending p{true, const_cast<void*>(buf), count * type_bytes(type), peer, static_cast<Comm*>(comm), stream};
-    if (g_depth > 0) {
-        g_pending.push_back(p);
-        return 0;
-    }
-    return execute(p);
+    return post(true, const_cast<void*>(buf), count, type, peer, comm, stream);
 }
 
 int ncclRecv(void* buf, size_t count, int type, int peer, void* comm, hipStream_t stream) {
-    if (!comm || !type_bytes(type)) return fail("bad arguments to ncclRecv");
-    Pending p{false, buf, count * type_bytes(type), peer, static_cast<Comm*>(comm), stream};
-    if (g_depth > 0) {
-        g_pending.push_back(p);
-        return 0;
-    }
-    return execute(p);
+    return post(false, buf, count, type, peer, comm, stream);
 }
 
 }  // extern "C"

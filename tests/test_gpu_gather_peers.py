@@ -122,3 +122,105 @@ def test_one_rank_fails_alone_and_nobody_is_left_waiting(tmp_path, bad_rank):
                                                     "PEER_BAD_STEP": "5", "BGS_GATHER_BATCH": "4"}, timeout=120)
     for r, out in enumerate(outs):
         assert f"INJECT_ONE_OK rank {r}" in out, out
+
+
+# ---- the stand-in refuses what RCCL refuses (or answers with a hang / silent corruption): one test per refusal ----
+class _Fake:
+    """The stand-in driven directly (ctypes): two communicators of ONE process on the one GPU (ncclCommInitAll), device
+    buffers from torch.  Run in a child process per case so that BGS_FAKE_RCCL_TIMEOUT_MS is read afresh."""
+
+    CODE = r'''
+import ctypes, os, sys
+import torch
+lib = ctypes.CDLL(sys.argv[1])
+lib.ncclGetErrorString.restype = ctypes.c_char_p
+for f in (lib.ncclSend, lib.ncclRecv):
+    f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+comms = (ctypes.c_void_p * 2)()
+assert lib.ncclCommInitAll(comms, 2, (ctypes.c_int * 2)(0, 0)) == 0
+a = torch.arange(64, dtype=torch.uint8, device="cuda")
+b = torch.zeros(64, dtype=torch.uint8, device="cuda")
+U8, I32 = 1, 2
+def err(rc):
+    return lib.ncclGetErrorString(rc).decode() if rc else "ok"
+case = sys.argv[2]
+if case == "good":
+    assert lib.ncclGroupStart() == 0
+    assert lib.ncclSend(a.data_ptr(), 64, U8, 1, comms[0], None) == 0
+    assert lib.ncclRecv(b.data_ptr(), 64, U8, 0, comms[1], None) == 0
+    rc = lib.ncclGroupEnd()
+    torch.cuda.synchronize()
+    print("RESULT", err(rc), bool((a == b).all()))
+elif case in ("count", "dtype"):
+    lib.ncclGroupStart()
+    lib.ncclSend(a.data_ptr(), 64, U8, 1, comms[0], None)
+    lib.ncclRecv(b.data_ptr(), 32 if case == "count" else 16, U8 if case == "count" else I32, 0, comms[1], None)
+    print("RESULT", err(lib.ncclGroupEnd()))
+elif case == "ungrouped_send":
+    print("RESULT", err(lib.ncclSend(a.data_ptr(), 64, U8, 1, comms[0], None)))
+elif case == "ungrouped_recv":
+    print("RESULT", err(lib.ncclRecv(b.data_ptr(), 64, U8, 0, comms[1], None)))
+elif case == "end_without_start":
+    print("RESULT", err(lib.ncclGroupEnd()))
+elif case == "peer_out_of_range":
+    lib.ncclGroupStart()
+    print("RESULT", err(lib.ncclSend(a.data_ptr(), 64, U8, 2, comms[0], None)))
+elif case == "null_buffer":
+    lib.ncclGroupStart()
+    print("RESULT", err(lib.ncclRecv(None, 64, U8, 0, comms[1], None)))
+elif case == "bad_type":
+    lib.ncclGroupStart()
+    print("RESULT", err(lib.ncclSend(a.data_ptr(), 64, 99, 1, comms[0], None)))
+elif case == "destroy_in_group":
+    lib.ncclGroupStart()
+    print("RESULT", err(lib.ncclCommDestroy(comms[0])))
+elif case == "destroyed_comm":
+    assert lib.ncclCommDestroy(comms[1]) == 0
+    n = ctypes.c_int(0)
+    r1 = lib.ncclCommCount(comms[1], ctypes.byref(n))
+    lib.ncclGroupStart()
+    print("RESULT", err(r1), "|", err(lib.ncclRecv(b.data_ptr(), 64, U8, 0, comms[1], None)))
+elif case == "silent_peer":
+    # the receive's peer never posts the matching send: the wait must end in an error, not in a hang
+    lib.ncclGroupStart()
+    lib.ncclRecv(b.data_ptr(), 64, U8, 0, comms[1], None)
+    print("RESULT", err(lib.ncclGroupEnd()))
+sys.stdout.flush()
+os._exit(0)
+'''
+
+    @staticmethod
+    def run(case, timeout_ms="1500"):
+        env = dict(os.environ, BGS_FAKE_RCCL_TIMEOUT_MS=timeout_ms)
+        proc = subprocess.run([sys.executable, "-c", _Fake.CODE, build_fake_rccl(), case], env=env, capture_output=True, text=True, timeout=180)
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT")]
+        assert proc.returncode == 0 and lines, proc.stderr[-2000:]
+        return lines[-1][len("RESULT "):]
+
+
+def test_stand_in_delivers_a_matched_message():
+    assert _Fake.run("good") == "ok True"
+
+
+@pytest.mark.parametrize("case,what", [
+    ("count", "count / data type mismatch"),
+    ("dtype", "count / data type mismatch"),
+    ("ungrouped_send", "ncclSend outside ncclGroupStart / ncclGroupEnd"),
+    ("ungrouped_recv", "ncclRecv outside ncclGroupStart / ncclGroupEnd"),
+    ("end_without_start", "ncclGroupEnd without ncclGroupStart"),
+    ("peer_out_of_range", "peer 2 is outside the communicator"),
+    ("null_buffer", "NULL buffer with a non-zero count"),
+    ("bad_type", "unknown data type 99"),
+    ("destroy_in_group", "inside an open group"),
+    ("silent_peer", "the peer never sent the message (timeout)"),
+])
+def test_stand_in_refuses(case, what):
+    """What RCCL answers with an error, a hang or silent corruption is an error code here (tests/c/fake_rccl.hip, header)."""
+    assert what in _Fake.run(case)
+
+
+def test_stand_in_refuses_a_destroyed_communicator():
+    out = _Fake.run("destroyed_comm")
+    assert "bad arguments to ncclCommCount" in out and "not a live communicator" in out

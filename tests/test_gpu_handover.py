@@ -689,7 +689,8 @@ def test_bench_multi_rank_rehearsal(gather, ranks):
     cannot run several ranks on one GPU): `shm` -- one host array in shared memory, every rank's sink delivers its rows,
     rank 0 consumes (futex hand-shake inside the native loop); `rccl` -- the IN-LIBRARY gather (bgs_gather_*, the code a
     real 8-GPU run executes) over the tests' shared-memory stand-in for RCCL; `both` -- the default of an N > 1 run: the
-    two one after the other, `value` from the shared array.  Rank 0's host array must verify against a replay of EVERY
+    two one after the other, `value` from the RCCL gather (the north-star's collective; round 6), `rccl_ranks` = what the
+    communicator itself reports.  Rank 0's host array must verify against a replay of EVERY
     rank's first games.  World sizes 2 and 4 of the metric's 1 / 2 / 4 / 8: the box allows at most 6 processes on the card and
     this test process is one of them (tools/r5_dist.sh runs 6 ranks outside pytest); the gather's N = 8 arithmetic runs as 4
     processes x 2 ranks in tests/test_gpu_gather_peers.py, the shared array's 8-rank hand-shake on the CPU in
@@ -710,8 +711,13 @@ def test_bench_multi_rank_rehearsal(gather, ranks):
     d = json.loads(line)
     assert d["n_gpus"] == ranks and d["config"]["gathered_rewards_verified"] is True
     assert d["config"]["rewards_to_host"] is True and d["config"]["global_batch"] == ranks << 16
-    assert ("shared memory" in d["config"]["sharding"]) == (gather != "rccl")
-    assert d["config"]["gather"] == ("rccl" if gather == "rccl" else "shm")
+    assert ("shared memory" in d["config"]["sharding"]) == (gather == "shm")
+    assert d["config"]["gather"] == ("shm" if gather == "shm" else "rccl")
+    assert d["rccl_ranks"] == (None if gather == "shm" else ranks)
+    assert 0 < d["ms_per_step_fastest_rank"] <= d["ms_per_step_slowest_rank"] and "failed_handovers" not in d
+    assert d["ms_per_step_slowest_rank"] == pytest.approx(d["ms_per_step"])
+    if gather == "both":
+        assert d["value"] == pytest.approx(d["gather_rccl"]["value"]) and d["config"]["gathers_measured"] == ["shm", "rccl"]
     for kind in (("shm", "rccl") if gather == "both" else (gather,)):
         blk = d[f"gather_{kind}"]
         assert blk["gathered_rewards_verified"] is True and blk["value"] > 0 and len(blk["values_of_3"]) == 3
@@ -737,12 +743,35 @@ def test_bench_starts_its_own_ranks():
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 3 and d["config"]["gathered_rewards_verified"] is True and d["config"]["gather"] == "shm"
+    assert d["n_gpus"] == 3 and d["config"]["gathered_rewards_verified"] is True and d["config"]["gather"] == "rccl"
+    assert d["rccl_ranks"] == 3 and d["value"] == pytest.approx(d["gather_rccl"]["value"])
     # the default N > 1 run measures both hand-overs, each verified on its own
     assert d["config"]["gathers_measured"] == ["shm", "rccl"]
     assert d["gather_shm"]["gathered_rewards_verified"] is True and d["gather_rccl"]["gathered_rewards_verified"] is True
     assert d["config"]["global_batch"] == 3 << 16 and d["value"] > 0 and d["steps"] == 20
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_bench_fails_loudly_when_the_gather_dies():
+    """Round-5 review: a driver that reads the exit code must not see success with the north-star collective dead.  Two
+    ranks over the stand-in, rank 1 goes silent after its first messages (BGS_FAKE_RCCL_MUTE_AFTER: its sends are dropped,
+    no error anywhere): rank 0's gather never completes, the watchdog gives it up after BGS_BENCH_GATHER_TIMEOUT -- the line
+    is still printed, with what the shared array measured and the gather's error, and the exit code is NOT 0."""
+    from tests.test_gpu_gather_peers import build_fake_rccl
+
+    env = dict(os.environ, BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", BGS_RCCL_LIB=build_fake_rccl(), BGS_FAKE_RCCL_MUTE_AFTER="1:3",
+               BGS_BENCH_GATHER_TIMEOUT="25", BGS_FAKE_RCCL_TIMEOUT_MS="120000")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
+                           "--batch", str(1 << 16), "--host-threads", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode != 0, proc.stderr[-3000:]
+    assert "hand-over did not finish within 25 s" in proc.stderr
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["failed_handovers"] == ["rccl"] and "error" in d["gather_rccl"] and d["rccl_ranks"] is None
+    assert d["config"]["gather"] == "shm" and d["gather_shm"]["gathered_rewards_verified"] is True and d["value"] > 0
 
 
 @pytest.mark.parametrize("gather", ["rccl", "shm"])

@@ -1011,3 +1011,115 @@ def test_transition_round_trip_matches_separate_calls(batch_mod):
     np.testing.assert_array_equal(winner, bo.winner)
     np.testing.assert_array_equal(plies, bo.plies)
     np.testing.assert_array_equal(masks, bd.targets)
+
+
+# ------------------------------------------------------------------------------------------------ the strict RNG contract
+# Round 6: Connect under BGS_RNG_PER_PLY (a philox word per ply, exactly Bounce's rule; the form SURVEY 7.3 wrote) -- every
+# kernel family that draws, against the oracle's ORC_RNG_PER_PLY mode.
+
+@pytest.mark.parametrize("h,w,k", CONNECT_GEOMETRIES + [(17, 5, 4), (4, 20, 3)])   # (the last two: the generic kernels)
+def test_connect_strict_contract_step_random_lockstep(batch_mod, h, w, k):
+    """K1s (one-word boards, even n), k_connect_step_random (the rest) and g_connect_play, one ply and several per launch."""
+    n = 1500
+    dev = batch_mod.ConnectBatch(h, w, k, n)
+    dev.set_rng_contract("per-ply")
+    orc = oracle.ConnectOracle(h, w, k, n, per_ply=True)
+    dev.set_first_game(4242)
+    total = 0
+    for plies in [1] * 6 + [3, 4, 5, 7, h * w]:
+        dev.step_random(SEED, plies=plies)
+        for _ in range(plies):
+            total += orc.step_random(SEED, first_game=4242)
+        assert_same(dev, orc, f"after {plies} more plies")
+        assert dev.steps == total
+    assert orc.ended.all()
+    # ... and the two contracts are different games (same seed): the default draws differently from ply 1 on
+    other = batch_mod.ConnectBatch(h, w, k, n)
+    other.set_first_game(4242)
+    other.step_random(SEED, plies=h * w)
+    if w > 1 and h * w > 2:
+        assert not np.array_equal(other.grid, dev.grid)
+
+
+@pytest.mark.parametrize("h,w,k", CONNECT_GEOMETRIES + [(17, 5, 4)])
+@pytest.mark.parametrize("how", ["initial", "memory", "capped", "flag"])
+def test_connect_strict_contract_rollout(batch_mod, h, w, k, how):
+    """The fused rollouts: K2o (one-word, from the start, no cap), K2a (from memory / capped), K2c + its opening launch
+    (12x13x5), K2b and the any-geometry kernel, the generic kernel; the contract set on the batch or asked for by flag."""
+    from simulator.game import _abi
+    import ctypes
+
+    n = 20000 if h * w <= 64 else 6000
+    dev = batch_mod.ConnectBatch(h, w, k, n)
+    orc = oracle.ConnectOracle(h, w, k, n, per_ply=True)
+    dev.set_first_game(1 << 35)
+    if how != "flag":
+        dev.set_rng_contract("per-ply")
+    cap = 2**31 - 1
+    if how == "memory":   # a few plies first (lanes then join in the middle of a block), then from memory
+        for _ in range(3):
+            dev.step_random(SEED ^ 5)
+            orc.step_random(SEED ^ 5, first_game=1 << 35)
+        dev.reset_steps()
+    if how == "capped":
+        cap = max(1, (h * w) // 2)
+    if how == "flag":
+        _abi.check(_abi.lib().bgs_rollout(dev._handle, ctypes.c_uint64(SEED), ctypes.c_int32(cap),
+                                          ctypes.c_uint32(_abi.ROLLOUT_FROM_INITIAL | _abi.ROLLOUT_DRAW_PER_PLY)))
+    else:
+        dev.rollout(SEED, max_plies=cap, from_initial=(how != "memory"))
+    total = orc.rollout(SEED, first_game=1 << 35, max_plies=cap)
+    assert_same(dev, orc, how)
+    assert dev.steps == total
+
+
+def test_connect_strict_contract_kernel_families_agree(batch_mod, monkeypatch):
+    """Connect4 under the strict contract through every one-word rollout family (K2o with 1-4 opening blocks, K2a, the
+    any-geometry kernel) and 12x13x5 through K2c / K2b / the any-geometry kernel: the same boards, and the oracle's."""
+    n = 30000
+    orc = oracle.ConnectOracle(6, 7, 4, n, per_ply=True)
+    total = orc.rollout(SEED + 9, first_game=5)
+    for setting in ({}, {"rollout_opening": "0"}, {"rollout_opening": "1"}, {"rollout_opening": "2"}, {"rollout_opening": "4"},
+                    {"rollout_generic": "1"}):
+        for name, value in setting.items():
+            monkeypatch.setitem(knobs, name, value)
+        dev = batch_mod.ConnectBatch(6, 7, 4, n)
+        dev.set_rng_contract("per-ply")
+        dev.set_first_game(5)
+        dev.rollout(SEED + 9, from_initial=True)
+        assert_same(dev, orc, str(setting))
+        assert dev.steps == total
+        dev.close()
+        for name in setting:
+            monkeypatch.delitem(knobs, name)
+    n = 6000
+    orc = oracle.ConnectOracle(12, 13, 5, n, per_ply=True)
+    total = orc.rollout(SEED + 9, first_game=5)
+    for setting in ({}, {"rollout_opening": "0"}, {"rollout_no_lds": "1"}, {"rollout_generic": "1"}):
+        for name, value in setting.items():
+            monkeypatch.setitem(knobs, name, value)
+        dev = batch_mod.ConnectBatch(12, 13, 5, n)
+        dev.set_rng_contract("per-ply")
+        dev.set_first_game(5)
+        dev.rollout(SEED + 9, from_initial=True)
+        assert_same(dev, orc, str(setting))
+        assert dev.steps == total
+        dev.close()
+        for name in setting:
+            monkeypatch.delitem(knobs, name)
+
+
+def test_connect_strict_contract_through_the_reward_sink(batch_mod):
+    """The hand-over (fused outcome codes) under the strict contract: host rewards == oracle."""
+    n = 1 << 16
+    dev = batch_mod.ConnectBatch(6, 7, 4, n)
+    dev.set_rng_contract("per-ply")
+    sink = batch_mod.RewardSink(n, slots=2, threads=2)
+    host = np.full((n, 2), 9, dtype=np.int8)
+    sink.wait(sink.rollout(dev, host, SEED + 3, from_initial=True))
+    orc = oracle.ConnectOracle(6, 7, 4, n, per_ply=True)
+    orc.rollout(SEED + 3)
+    np.testing.assert_array_equal(host, orc.reward)
+    sink.close()
+    with pytest.raises(ValueError):
+        dev.set_rng_contract("per-game")

@@ -30,10 +30,11 @@ int main(int argc, char** argv) {
     for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b) {
         uint64_t* p = calloc(n * n, sizeof(uint64_t));
         for (int c = 0; c < cells; ++c) { int d[4] = {c / (n*n*n), (c / (n*n)) % n, (c / n) % n, c % n}; p[d[a] * n + d[b]] += hist[c]; }
-        double e2 = 4294967296.0 / (n * n);
-        for (int c = 0; c < n * n; ++c) { double d = p[c] / e2 - 1.0; if (d < 0) d = -d; if (d > worst2) worst2 = d; }
+        const int mm[4] = {m0, m1, m2, m3};   // (mixed action counts: a pair's cells are m_a x m_b)
+        double e2 = 4294967296.0 / ((double)mm[a] * mm[b]);
+        for (int c = 0; c < n * n; ++c) { if (c / n >= mm[a] || c % n >= mm[b]) continue; double d = p[c] / e2 - 1.0; if (d < 0) d = -d; if (d > worst2) worst2 = d; }
         free(p);
     }
-    printf("A=%u n=%d cells=%d expected/cell=%.0f  max |rel dev| 4-tuple=%.3e  pairs=%.3e  chi2/cells=%.3f\n", A, n, cells, expct, worst, worst2, chi / cells);
+    printf("A=%u n=%d counts=%d,%d,%d,%d cells=%d expected/cell=%.0f  max |rel dev| 4-tuple=%.3e  pairs=%.3e  chi2/cells=%.3f\n", A, n, m0, m1, m2, m3, cells, expct, worst, worst2, chi / cells);
     return 0;
 }

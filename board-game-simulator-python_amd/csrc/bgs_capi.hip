@@ -326,6 +326,16 @@ int device_facts(bgs_batch* b) {
     if (const char* env = bgs::experiment("bounce_block")) b->bounce_block = atoi(env);
     b->bounce_pool = 1;
     if (const char* env = bgs::experiment("bounce_pool")) b->bounce_pool = atoi(env) != 0;
+    b->bounce_static_geom = 1;
+    if (const char* env = bgs::experiment("bounce_static_geom")) b->bounce_static_geom = atoi(env) != 0;
+    b->bounce_tail = 0;   // (round 6: built, measured, off -- see DESIGN 5.3)
+    if (const char* env = bgs::experiment("bounce_tail")) b->bounce_tail = atoi(env) != 0;
+    b->bounce_tail_handoff = -1;
+    if (const char* env = bgs::experiment("bounce_tail_handoff")) b->bounce_tail_handoff = atoi(env);
+    b->bounce_tail_limit = 0;
+    if (const char* env = bgs::experiment("bounce_tail_limit")) b->bounce_tail_limit = atoi(env);
+    b->tail_serial = 0;
+    b->tail_flags_dirty = 1;
     b->bounce_flat_chunk = kBounceFlatChunk;
     if (const char* env = bgs::experiment("bounce_chunk")) {
         const int v = atoi(env);

@@ -48,6 +48,12 @@ struct bgs_batch {
     int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board
     uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];
     int bounce_pass_group[BGS_BOUNCE_MAX_PASSES];
+    int bounce_static_geom;  // 1: the default board is played by the kernels instantiated on its compile-time geometry (experiment bounce_static_geom=0: the run-time record)
+    int bounce_tail;         // 1: K3p's launch finishes the games beyond its ply cap itself, its idle waves in K3w's role (experiment bounce_tail=0: separate passes)
+    int bounce_tail_handoff; // >= 0: a workgroup's last wave hands its boards to the tail queue at this many or fewer (experiment; -1: bounce_shape())
+    int bounce_tail_limit;   // > 0: tail waves that may wait for entries at a time (experiment; 0: bounce_shape())
+    mutable uint32_t tail_serial;     // the "entry complete" word of the last fused launch (the region of d_worklist holds such words)
+    mutable int tail_flags_dirty;     // 1: d_worklist holds something else (game indices of a compaction pass, nothing yet)
     int rollout_generic;     // 1: never take the block-aligned from-initial kernel (A/B timing, experiment rollout_generic)
     int rollout_chunk;       // games per wave of the fused rollout, 0 = derived from rollout_wps (experiment rollout_chunk)
     int rollout_opening;     // opening blocks of the from-initial one-word rollout: 0 = K2a, 1..4, default 3 (experiment rollout_opening)

@@ -107,7 +107,8 @@ __device__ __forceinline__ uint64_t reach(const BounceGeom& g, const Board& b, u
 }
 
 // pieces the side to move may pick: those in the occupied non-goal row nearest its own side (Appendix B rule 3)
-__device__ __forceinline__ uint64_t movable(const BounceGeom& g, uint64_t occ, uint32_t player) {
+template <class GEO>
+__device__ __forceinline__ uint64_t movable(const GEO& g, uint64_t occ, uint32_t player) {
     const uint64_t oi = occ & g.interior;
     if (!oi) return 0;
     const int cell = player ? 63 - __clzll((long long)oi) : __ffsll((unsigned long long)oi) - 1;
@@ -829,8 +830,8 @@ struct PieceBoard {
     uint64_t occ;
 };
 
-template <int PMAX>
-__device__ __forceinline__ void pieces_from_start(const BounceGeom& g, PieceBoard<PMAX>& b) {
+template <int PMAX, class GEO>
+__device__ __forceinline__ void pieces_from_start(const GEO& g, PieceBoard<PMAX>& b) {
 #pragma unroll
     for (int j = 0; j < PMAX / 4; ++j)
         b.pos[j] = (uint32_t)g.piece_cell[4 * j] | ((uint32_t)g.piece_cell[4 * j + 1] << 8) |
@@ -841,8 +842,8 @@ __device__ __forceinline__ void pieces_from_start(const BounceGeom& g, PieceBoar
 }
 
 // index planes and occupancy from the positions (adopted boards)
-template <int PMAX>
-__device__ __forceinline__ void pieces_rebuild(const BounceGeom& g, PieceBoard<PMAX>& b) {
+template <int PMAX, class GEO>
+__device__ __forceinline__ void pieces_rebuild(const GEO& g, PieceBoard<PMAX>& b) {
     b.idx[0] = b.idx[1] = b.idx[2] = b.idx[3] = 0;
     b.occ = 0;
 #pragma unroll
@@ -857,8 +858,8 @@ __device__ __forceinline__ void pieces_rebuild(const BounceGeom& g, PieceBoard<P
 }
 
 // value planes (the batch's memory format) from the positions
-template <int PMAX>
-__device__ __forceinline__ Board pieces_to_planes(const BounceGeom& g, const PieceBoard<PMAX>& b) {
+template <int PMAX, class GEO>
+__device__ __forceinline__ Board pieces_to_planes(const GEO& g, const PieceBoard<PMAX>& b) {
     Board out;
     out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
 #pragma unroll
@@ -932,8 +933,8 @@ struct Lands {
 };
 
 // phase A: the landing cells of every piece's segment for `player`, and who stands on them
-template <int PMAX>
-__device__ __forceinline__ void land_all(const BounceGeom& g, const PieceBoard<PMAX>& b, uint32_t player, Lands<PMAX>& L) {
+template <int PMAX, class GEO>
+__device__ __forceinline__ void land_all(const GEO& g, const PieceBoard<PMAX>& b, uint32_t player, Lands<PMAX>& L) {
     const uint64_t empty_interior = ~b.occ & g.interior;
     const uint32_t up = player ? 0u : (uint32_t)g.w, down = player ? (uint32_t)g.w : 0u;
     // every piece's cell, unpacked ONCE a ply: the "who stands there" test below reads each of them PMAX times (the
@@ -979,8 +980,8 @@ __device__ __forceinline__ void land_all(const BounceGeom& g, const PieceBoard<P
 
 // phase B, part 1: the transitive closure of "lands on" -- Warshall on the packed rows: for every pivot k, every row
 // that has bit k takes row k in.  A row lives in a 16-bit field, so (fields with bit k) x row_k is one multiply per dword.
-template <int PMAX>
-__device__ __forceinline__ void close_over_bounces(const BounceGeom& g, Lands<PMAX>& L) {
+template <int PMAX, class GEO>
+__device__ __forceinline__ void close_over_bounces(const GEO& g, Lands<PMAX>& L) {
 #pragma unroll
     for (int k = 0; k < PMAX; ++k)
         if (k < (int)g.piece_count) {
@@ -1003,8 +1004,8 @@ struct PieceMoves {
 // (one v_bfe_i32) ANDs the piece's mask in, (mask & sel) | acc is one v_and_or_b32 per half -- three instructions a piece.
 // (The select form -- `members & (1 << k) ? L.v[k] : 0` -- compiled to and + compare + two v_cndmask + or, and the
 // compare's SGPR result costs the v_cndmask behind it an s_nop: 650 of the ~930 instructions of a ply's counting.)
-template <int PMAX>
-__device__ __forceinline__ uint64_t landed_by(const BounceGeom& g, const Lands<PMAX>& L, uint32_t members) {
+template <int PMAX, class GEO>
+__device__ __forceinline__ uint64_t landed_by(const GEO& g, const Lands<PMAX>& L, uint32_t members) {
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int k = 0; k < PMAX; ++k)
@@ -1020,8 +1021,8 @@ __device__ __forceinline__ uint64_t landed_by(const BounceGeom& g, const Lands<P
 // phase B, part 2: per column of the active row, the source's closure and the number of its targets -- for the lanes
 // with `want` set (phases A and B1 must have run for this board and player).  No loop whose trip count depends on the
 // board: every lane does the same work for every column.
-template <int PMAX>
-__device__ __forceinline__ void count_from_lands(const BounceGeom& g, const PieceBoard<PMAX>& b, uint32_t player, bool want,
+template <int PMAX, class GEO>
+__device__ __forceinline__ void count_from_lands(const GEO& g, const PieceBoard<PMAX>& b, uint32_t player, bool want,
                                                  const Lands<PMAX>& L, PieceMoves& m) {
     const uint64_t occ = b.occ;
     const uint64_t landing = (~occ & g.interior) | (player ? g.goal_bottom : g.goal_top);
@@ -1050,8 +1051,8 @@ __device__ __forceinline__ void count_from_lands(const BounceGeom& g, const Piec
 }
 
 // the idx-th action of the canonical list: the column from the packed counts, its targets from the closure's landing masks
-template <int PMAX>
-__device__ __forceinline__ void pick_from_lands(const BounceGeom& g, const PieceBoard<PMAX>& b, uint32_t player,
+template <int PMAX, class GEO>
+__device__ __forceinline__ void pick_from_lands(const GEO& g, const PieceBoard<PMAX>& b, uint32_t player,
                                                 const PieceMoves& m, const Lands<PMAX>& L, uint32_t idx, int& src_cell,
                                                 int& dst_cell) {
     uint32_t col = 0;
@@ -1217,6 +1218,434 @@ k_bounce_book_links(const BookEntry* __restrict__ table, uint32_t level, uint32_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3w: ONE BOARD PER WAVE, a piece per lane -- the last pass of the rollout, for the handful of games per batch that
+// run for thousands of plies (one or two per 2^18 never end and stop at max_plies).  Such a game is a chain of dependent
+// plies; the launch is over when it is, so what counts is the LATENCY of its ply, i.e. how many instructions the wave
+// that holds it has to issue per ply.  The 8-lanes-per-board kernel walks a column's closure cell by cell (a lane runs
+// `reach`: ~1000 instructions a ply on the longest column).  Here the lanes ARE the pieces (lane k = the k-th occupied
+// cell, re-derived from the planes every ply, so the lanes are always in cell order):
+//   A   every lane runs its own piece's segment (the same code as K3p's phase A; the step loop runs to the largest value
+//       on the board, lanes drop out at their own);
+//   hit "which pieces does my segment land on": the cells of the other pieces come over v_readlane, one bit test each;
+//   B1  the closure of "lands on" -- Warshall with one ROW PER LANE: pivot p's row comes over v_readlane, every lane
+//       that has bit p takes it in (three instructions a pivot instead of K3p's multiply over six packed dwords);
+//   B2  a source's targets = the OR of its members' landing masks (masks over v_readlane, selected by sign-extended
+//       member bits), counts; the sources of the active row are neighbouring lanes in column order, so "actions before
+//       mine" is a prefix sum over 16 lanes (four DPP row shifts), the total is lane 15's;
+//   pick the lane whose range holds the index is the source (a ballot); its k-th target is found by the CELLS (lane c counts
+//       the targets below cell c with v_mbcnt; the target cell whose count is k is it): a dozen instructions.
+// ~320 VALU and ~50 v_readlane a ply against ~1000.  The board itself (four value planes) is wave-uniform, and so is all
+// the state of the wave's one game -- kept in scalar registers on purpose (see the ply loop: `same`, `word_at`).
+// Measured per ply of a wave that has its SIMD to itself (cycle counter, round 5): a full search 3 200 cycles, with the
+// memo's look-up, fill and link bookkeeping around it 4 400, a remembered position 1 300, a hop along a link 250.
+// Results cannot differ from the other kernels': the same rules, the same canonical action order (sources by column,
+// targets by cell index), the RNG keyed by game id and ply.
+// ------------------------------------------------------------------------------------------------
+#ifndef BGS_MEMO_BITS
+#define BGS_MEMO_BITS 5
+#endif
+#ifndef BGS_WAVE_LINKS
+#define BGS_WAVE_LINKS 32
+#endif
+constexpr uint32_t kWaveMemoBits = BGS_MEMO_BITS, kWaveMemoSlots = 1u << kWaveMemoBits;
+constexpr uint32_t kWaveLinks = BGS_WAVE_LINKS;   // actions per remembered position whose successor is remembered too (K3w, see the ply loop)
+// a link word is epoch << 16 | actions of the successor << 8 | the successor's slot, and lanes 0 .. kWaveLinks - 1 clear a row
+static_assert(kWaveMemoSlots <= 256 && kWaveLinks <= 64, "a link holds the slot in 8 bits; one wave clears a slot's row of links");
+constexpr uint32_t kWaveEpochLimit = 0xFFFFu;   // 16 bits of epoch in a link: at the limit the memo starts over empty
+
+struct WaveMoves {
+    uint64_t targets;    // this lane's piece, if it is a source: its legal landing cells
+    uint32_t count;      // popcount(targets)
+    uint32_t before;     // actions of the sources left of this lane's
+    uint32_t cell;       // this lane's piece stands here
+    uint32_t n;          // actions of the board (uniform)
+};
+
+__device__ __forceinline__ uint32_t row_shift_right(uint32_t x, int by) {   // lane i of a 16-lane row gets lane i - by's x, 0 below
+    switch (by) {
+        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+        case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+        default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    }
+}
+
+template <int PMAX, class GEO>
+__device__ __forceinline__ void enumerate_wave(const GEO& g, const Board& b, uint32_t player, WaveMoves& m) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t occ = occupancy(b);
+    const uint32_t pieces = (uint32_t)__popcll(occ);          // (uniform; <= PMAX: the host only sends such boards)
+    const bool alive = lane < pieces;
+    // the cell of the lane-th piece.  The board is the same on every lane, so lane c knows whether cell c is occupied and how
+    // many pieces stand below it (two v_mbcnt on the occupancy) -- the number of the lane that wants to know -- and tells it
+    // with ONE forward permute; the popcount-guided search for the lane-th set bit is forty instructions (round 5)
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(occ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)occ, 0u));
+    const bool occupied = ((occ >> lane) & 1ull) != 0ull;
+    static_assert(PMAX < 63, "lane 63 takes what the empty cells send");
+    const uint32_t told = (uint32_t)__builtin_amdgcn_ds_permute((int)((occupied ? below : 63u) << 2), (int)lane);
+    const uint32_t cell = alive ? told : 0u;
+    const uint32_t value = alive ? value_at(b, (int)cell) : 0u;
+    m.cell = cell;
+    const uint64_t empty_interior = ~occ & g.interior;
+    const uint64_t landing = empty_interior | (player ? g.goal_bottom : g.goal_top);
+    const uint32_t up = player ? 0u : (uint32_t)g.w, down = player ? (uint32_t)g.w : 0u;
+    // A: the landing cells of this lane's piece
+    uint64_t a0 = alive ? 1ull << cell : 0ull, al = 0, ar = 0, land = 0;
+    for (uint32_t s = 1; __builtin_amdgcn_ballot_w64(s <= value) != 0ull; ++s) {
+        if (s <= value) {
+            const uint64_t via_left = a0 | al, via_right = a0 | ar;
+            const uint64_t nf = ((via_left | ar) << up) >> down;
+            const uint64_t nl = (via_left & g.not_col0) >> 1;
+            const uint64_t nr = (via_right & g.not_collast) << 1;
+            if (s < value) {
+                a0 = nf & empty_interior;
+                al = nl & empty_interior;
+                ar = nr & empty_interior;
+            } else {
+                land = nf | nl | nr;
+            }
+        }
+    }
+    // who stands on them (bit j = the piece of lane j); a segment never returns to its own start cell
+    uint32_t row = 0;
+    // (no "is there a piece j" tests: a lane without a piece has no landing cells and an empty row, so whatever bit the
+    // others compute FOR it selects nothing -- and a branch costs a lone wave more than the three instructions it skips)
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) {
+        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cell, j);
+        row |= ((uint32_t)(land >> cj) & 1u) << j;
+    }
+    // B1: the closure over bounces, a row per lane
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+        const uint32_t rp = (uint32_t)__builtin_amdgcn_readlane((int)row, p);
+        row |= (uint32_t)__builtin_amdgcn_sbfe((int)row, p, 1) & rp;
+    }
+    // B2: a source's targets are the landing cells of its closure
+    const uint64_t sources = movable(g, occ, player);
+    const bool is_source = alive && ((sources >> cell) & 1ull);
+    const uint32_t members = row | (1u << lane);
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) {
+        const uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)land, j);
+        const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(land >> 32), j);
+        const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)members, j, 1);
+        lo |= lj & sel;
+        hi |= hj & sel;
+    }
+    const uint64_t targets = is_source ? ((((uint64_t)hi << 32) | lo) & landing) : 0ull;
+    const uint32_t count = (uint32_t)__popcll(targets);
+    uint32_t incl = count;   // the lanes are in cell order and the sources share a row: a prefix sum is "in column order"
+    incl += row_shift_right(incl, 1);
+    incl += row_shift_right(incl, 2);
+    incl += row_shift_right(incl, 4);
+    incl += row_shift_right(incl, 8);
+    m.targets = targets;
+    m.count = count;
+    m.before = incl - count;
+    m.n = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+}
+
+// the memo of one K3w wave (see wave_play_game): kWaveMemoSlots positions in sets of 2 ways, ~10 KB with the links (PMAX = 12)
+template <int PMAX>
+struct WaveMemo {
+    uint64_t key[kWaveMemoSlots][4];
+    uint64_t targets[kWaveMemoSlots][PMAX];
+    uint32_t lane[kWaveMemoSlots][PMAX];
+    uint32_t n[kWaveMemoSlots];
+    uint32_t tag[kWaveMemoSlots];
+    uint32_t last[kWaveMemoSlots / 2];   // per set: the way used last
+    // ... and where the remembered positions LEAD: link[slot][action] = epoch << 16 | actions of the successor << 8 | its slot.
+    // A link holds as long as no remembered position has been replaced since it was written (`epoch` counts those; a slot's
+    // row is cleared when the slot is filled).  A game that never ends hops along them -- one LDS look-up, a sample, no
+    // board -- for as long as the sampled action has a link: 0.13 us a ply where the look-up of the position costs 0.55.
+    // (a row has one more word than links, always 0: "no link" for an action beyond the row, read without a test)
+    uint32_t link[kWaveMemoSlots][kWaveLinks + 1u];
+};
+
+// orders the LDS accesses of ONE wave's lanes (the memo is wave-private: no other wave ever touches it).  The stand-alone
+// K3w kernel has one-wave workgroups; the tail role of the bulk kernel (round 6) runs this code on waves of a four-wave
+// workgroup, where a workgroup barrier would wait for waves that are somewhere else entirely.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int PMAX>
+__device__ __forceinline__ void wave_memo_reset(WaveMemo<PMAX>& memo, uint32_t lane) {
+    for (uint32_t e = lane; e < kWaveMemoSlots; e += BGS_WAVE) {
+        memo.tag[e] = 0xFFFFFFFFu;   // (no side is 0xFFFFFFFF)
+        memo.last[e >> 1] = 1u;
+        memo.link[e][kWaveLinks] = 0u;
+    }
+    wave_lds_sync();
+}
+
+// ONE game on ONE wave, from where it stands (b, st = running, plies) to its end or to max_plies: K3w's ply loop.  `b`, `st`,
+// `plies` are wave-uniform on entry and on return.
+template <int PMAX, class GEO>
+__device__ __forceinline__ void wave_play_game(const GEO& g, WaveMemo<PMAX>& memo, uint32_t& epoch, Board& b, uint32_t& st,
+                                               uint32_t& plies, uint64_t seed, uint64_t game_id, uint32_t max_plies,
+                                               uint32_t epoch_limit, uint32_t cold_limit, uint32_t bypass_plies) {
+    const uint32_t lane = threadIdx.x & 63u;
+    WaveMoves mv;
+    // The words of the plies to come.  The board is one, the lanes are 64: lane l keeps the word of ply `ahead_first` + l
+    // (its own philox call, for the block that ply lies in), so one call's latency buys the words of 64 plies, and a
+    // ply's word is ONE v_readlane away -- a scalar.  That matters beyond the philox calls it saves (one every four
+    // plies on all lanes alike, a third of a hop's dependent chain): bgs_common.h's philox_word selects its word
+    // through vector registers on purpose, which made the word -- and with it the sampled index, the link, the loop
+    // exits and the ply count of this whole loop -- divergent in the compiler's eyes: every hop ran as masked vector
+    // code.  With the word a scalar the hop is scalar arithmetic around one LDS look-up (round 5).
+    uint32_t ahead = 0u;
+    uint32_t ahead_first = 0x80000000u;   // (uniform; nothing computed yet: every ply -- at most 65535 -- is "64 or more past it")
+    auto word_at = [&](uint32_t ply) -> uint32_t {
+        if (ply - ahead_first >= (uint32_t)BGS_WAVE) {   // (unsigned: also a ply below the window)
+            ahead_first = ply & ~3u;
+            const Philox4 mine = philox4x32_10(seed, game_id, (ahead_first >> 2) + (lane >> 2));
+            ahead = philox_word(mine, lane);
+        }
+        return (uint32_t)__builtin_amdgcn_readlane((int)ahead, (int)(ply - ahead_first));
+    };
+    // One enumeration site.  `side` is whose action list is built next; after a move it is the other player's, and
+    // an empty list there means the game is over: the mover wins if HE could still move, else it is a draw -- one more
+    // enumeration, for the mover (`blocked`).  A board that arrives blocked is settled by the same rule with the
+    // roles of a move that never happened (settle_blocked).
+    uint32_t side = plies & 1u;
+    bool blocked = false;
+    uint32_t came_from = 0xFFFFFFFFu, came_by = 0;   // the slot and the action that led to the position about to be looked up
+    // The memo pays for games that stay among a few positions; a long game that WANDERS misses on every ply and pays for
+    // the look-up, the fill and the link bookkeeping all the same: a fifth of its ply (the longest such game, a few hundred
+    // plies, is what most launches of this kernel wait for -- an endless game hops through its 4000 plies in less).  So
+    // after `cold_limit` look-ups in a row that missed the wave plays `bypass_plies` plies without the memo, then looks
+    // again: a game that has settled into a cycle is found out within that many plies.  (Twice the limit for a game's first
+    // look-ups: the memo may know nothing of it yet, and a game that arrives cycling should not sit out a bypass first.)
+    uint32_t cold = 0, bypass = 0, slot = 0, cold_now = 2u * cold_limit;
+    auto same = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    for (;;) {
+        // (the state of the ONE game this wave plays is the same on every lane; saying so keeps it in scalar registers
+        // and its tests on the scalar unit -- the compiler cannot see it through the loop's memory and lane traffic)
+        plies = same(plies);
+        side = same(side);
+        epoch = same(epoch);
+        // The games this pass exists for do not wander: the one endless game of a 2^18-board batch of the default start
+        // visits 27 positions in 4096 plies, four of them in its last 2000 (tools/bounce_endless.py).  The action list of a
+        // position is a function of the position, so the wave keeps the lists it has built in LDS, keyed by the board and
+        // the side (compared in full: a hit IS the list enumerate_wave would build, for any board of the batch), and a ply
+        // on a known position costs a look-up instead of the search.  32 sets of two ways, the way not used last is
+        // replaced: direct-mapped, two of a game's handful of hot positions shared a slot in one launch of ten and every
+        // ply of that game missed (4.7 ms against 2.5).
+        const bool with_memo = bypass == 0u;
+        if (!with_memo) {
+            --bypass;
+            enumerate_wave<PMAX>(g, b, side, mv);
+        } else {
+        uint32_t set;
+        {
+            uint32_t h = (uint32_t)b.v[0] * 0x9E3779B1u ^ (uint32_t)(b.v[0] >> 32) * 0x85EBCA77u;
+            h ^= ((uint32_t)b.v[1] * 0xC2B2AE3Du) ^ ((uint32_t)(b.v[1] >> 32) * 0x27D4EB2Fu);
+            h ^= ((uint32_t)b.v[2] * 0x165667B1u) ^ ((uint32_t)(b.v[2] >> 32) * 0xD3A2646Cu);
+            h ^= ((uint32_t)b.v[3] * 0xFD7046C5u) ^ ((uint32_t)(b.v[3] >> 32) * 0xB55A4F09u);
+            set = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((h ^ (h >> 15)) * 0x2C1B3C6Du) >> (33 - kWaveMemoBits))) ^ side;
+            set &= kWaveMemoSlots / 2u - 1u;
+        }
+        // (both ways' keys and tags are read at once and compared afterwards: one LDS round trip, then the records of
+        // the way that hit.  Written with && the compiler reads tag, then the key word by word: six round trips of ~110
+        // cycles each, 40 % of a remembered ply.)
+        const uint32_t w0 = 2u * set, w1 = w0 + 1u;
+        const uint32_t tag0 = memo.tag[w0], tag1 = memo.tag[w1], last = memo.last[set];
+        uint32_t differ0 = tag0 ^ side, differ1 = tag1 ^ side;   // (32-bit xor / or chains: 17 instructions a way)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t ka = memo.key[w0][j], kc = memo.key[w1][j];
+            differ0 |= ((uint32_t)ka ^ (uint32_t)b.v[j]) | ((uint32_t)(ka >> 32) ^ (uint32_t)(b.v[j] >> 32));
+            differ1 |= ((uint32_t)kc ^ (uint32_t)b.v[j]) | ((uint32_t)(kc >> 32) ^ (uint32_t)(b.v[j] >> 32));
+        }
+        const uint32_t found = (uint32_t)__builtin_amdgcn_readfirstlane((int)((differ0 == 0u ? 1u : 0u) | (differ1 == 0u ? 2u : 0u)));
+        const uint32_t way = found ? found >> 1 : ((uint32_t)__builtin_amdgcn_readfirstlane((int)last) ^ 1u) & 1u;   // hit, or the victim
+        slot = w0 + way;
+        if (found) {
+            cold = 0;
+            const uint32_t at = lane < (uint32_t)PMAX ? lane : 0u;
+            const uint32_t packed = memo.lane[slot][at];
+            mv.targets = lane < (uint32_t)PMAX ? memo.targets[slot][at] : 0ull;
+            mv.cell = packed & 255u;
+            mv.count = lane < (uint32_t)PMAX ? (packed >> 8) & 255u : 0u;
+            mv.before = packed >> 16;
+            mv.n = (uint32_t)__builtin_amdgcn_readfirstlane((int)memo.n[slot]);
+            if (way != ((uint32_t)__builtin_amdgcn_readfirstlane((int)last) & 1u)) {
+                if (lane == 0u) memo.last[set] = way;
+                wave_lds_sync();
+            }
+        } else {
+            enumerate_wave<PMAX>(g, b, side, mv);
+            // the victim way: if it held a position, every link written so far may point at it -- a new epoch
+            const uint32_t victim_tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)(way ? tag1 : tag0));
+            if (victim_tag != 0xFFFFFFFFu && ++epoch >= epoch_limit) {   // (16 bits in a link: start over with an empty memo)
+                for (uint32_t e = lane; e < kWaveMemoSlots; e += BGS_WAVE) memo.tag[e] = 0xFFFFFFFFu;
+                epoch = 1;
+                wave_lds_sync();
+            }
+            if (lane < (uint32_t)PMAX) {
+                memo.targets[slot][lane] = mv.targets;
+                memo.lane[slot][lane] = mv.cell | (mv.count << 8) | (mv.before << 16);
+            }
+            if (lane < kWaveLinks) memo.link[slot][lane] = 0u;
+            if (lane == 0u) {
+                memo.key[slot][0] = b.v[0];
+                memo.key[slot][1] = b.v[1];
+                memo.key[slot][2] = b.v[2];
+                memo.key[slot][3] = b.v[3];
+                memo.n[slot] = mv.n;
+                memo.tag[slot] = side;
+                memo.last[set] = way;
+            }
+            wave_lds_sync();   // (uniform branch, one wave: lane 0's stores before anybody's next look-up)
+            if (++cold >= cold_now) {
+                cold = 0;
+                cold_now = cold_limit;
+                bypass = bypass_plies;
+            }
+        }
+        }
+        if (came_from != 0xFFFFFFFFu) {
+            // the move played last led HERE: remember it (unless this very look-up evicted the position it was played from)
+            if (came_from != slot && came_by < kWaveLinks) {
+                // (a successor without actions -- the game ends there -- or with more than a byte holds gets no link: 0)
+                if (lane == 0u) memo.link[came_from][came_by] = mv.n - 1u < 255u ? (epoch << 16) | (mv.n << 8) | slot : 0u;
+                wave_lds_sync();
+            }
+            came_from = 0xFFFFFFFFu;
+        }
+        if (blocked) {
+            st = mv.n ? side + 1u : BGS_ST_DRAW;
+            break;
+        }
+        if (mv.n == 0) {
+            blocked = true;
+            side = 1u - side;
+            continue;
+        }
+        if (plies >= max_plies) break;
+        const uint32_t idx = sample_index(word_at(plies), mv.n);
+        if (with_memo) {
+            // does the sampled action have a link?  Then hop: the successor's slot and the number of its actions are in
+            // the link, its own links are one look-up away -- the board stays behind until a hop has no link (or the
+            // ply cap is reached), and is then taken from the memo's key of the position the hops ended on.  A hop is a
+            // chain of dependent steps on a wave that has the SIMD to itself, so it is written for few of them: one test
+            // per link (a link is valid iff it carries the current epoch: 0, the empty word, never does), the row's extra
+            // word instead of "is the action inside the row".
+            uint32_t at = slot, next = idx;
+            const uint32_t ply0 = plies;
+            for (;;) {
+                const uint32_t link = same(memo.link[at][next < kWaveLinks ? next : kWaveLinks]);
+                if ((link >> 16) != epoch) break;
+                at = link & 255u;
+                ++plies;
+                if (plies >= max_plies) break;
+                next = sample_index(word_at(plies), (link >> 8) & 255u);
+            }
+            if (plies != ply0) {
+                cold = 0;
+                side ^= (plies - ply0) & 1u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t word = memo.key[at][j];
+                    b.v[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(word >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
+                }
+                continue;   // the look-up at the top finds this position, and the ply goes on from its lists
+            }
+        }
+        const bool here = idx - mv.before < mv.count;   // (unsigned: idx < before wraps; count is 0 on every lane that is no source)
+        const uint64_t owner = __builtin_amdgcn_ballot_w64(here);   // exactly one lane: the source
+        const int from = (__ffsll((unsigned long long)owner) - 1) & 63;
+        // its k-th target, found by the CELLS: lane c counts the targets below cell c; the one target cell whose count is k
+        // is it (a dozen instructions, most of them scalar, against the forty of the search for the k-th set bit)
+        const uint32_t k = idx - (uint32_t)__builtin_amdgcn_readlane((int)mv.before, from);
+        const uint32_t t_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv.targets, from);
+        const uint32_t t_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv.targets >> 32), from);
+        const uint64_t kth = __builtin_amdgcn_ballot_w64(__builtin_amdgcn_mbcnt_hi(t_hi, __builtin_amdgcn_mbcnt_lo(t_lo, 0u)) == k) &
+                             (((uint64_t)t_hi << 32) | t_lo);
+        const int s = __builtin_amdgcn_readlane((int)mv.cell, from), t = __ffsll((unsigned long long)kth) - 1;
+        move_piece(b, s, t);
+        ++plies;
+        if ((1ull << t) & (g.goal_top | g.goal_bottom)) {
+            st = side + 1u;
+            break;
+        }
+        side = 1u - side;
+        came_from = with_memo ? slot : 0xFFFFFFFFu;
+        came_by = idx;
+    }
+}
+
+
+// ---- the TAIL QUEUE (round 6): K3p's waves hand the games that outlive the bulk pass to K3w's code IN THE SAME LAUNCH.
+// Until round 5 a rollout was K3p to a ply cap -> positions to planes -> a compaction of the boards still running -> K3w,
+// one after the other on the batch's stream: a lone launch spent a third of its time in a nearly empty K3w, which could
+// only start when K3p's last wave had left.  Now a K3p wave that has nothing left to do in the bulk loop does not leave the
+// kernel: it turns into a K3w wave (one game per wave, the memo in the LDS its chunk no longer needs) and takes games from a
+// device-wide queue that the waves still in the bulk loop feed -- a game that reaches the bulk cap goes there at once, and so
+// do the last boards of a workgroup's last wave (`handoff_at`: K3p pays 2 400 instructions an iteration whatever its lanes
+// hold; at a handful of boards K3w's 400 a ply are cheaper, and its ply is five times shorter).  Nobody in the bulk loop
+// ever waits for the tail; a tail wave waits for entries only while a bulk wave that could still produce one exists.
+//   counters  tq[0] entries allocated   tq[1] entries claimed   tq[2] waves that have left the bulk loop   tq[3] tail waves admitted
+//             tq[4] workgroups of the launch that have started
+//   ready[e]  = the launch's serial once entry e is complete (written last, release at agent scope)
+//   entry e   = 8 dwords: positions (4), game, plies, -, -
+constexpr uint32_t kTailEntryWords = 8;
+
+// value planes (wave-uniform, scalar registers) from the piece list of a queue entry
+template <int PMAX, class GEO>
+__device__ __forceinline__ Board planes_from_positions(const GEO& g, const uint32_t (&pos)[4]) {
+    Board out;
+    out.v[0] = out.v[1] = out.v[2] = out.v[3] = 0;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        if (k < (int)g.piece_count) {
+            const uint64_t bit = 1ull << ((pos[k >> 2] >> (8 * (k & 3))) & 63u);
+            const uint32_t v = g.piece_value[k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((v >> q) & 1u) out.v[q] |= bit;
+        }
+    return out;
+}
+
+// ... and back, where a tail wave's game has ended: the board goes to memory in K3p's format (k_bounce_positions_to_planes
+// runs behind the kernel for every board).  Pieces are numbered by ascending (value, cell) at the start and keep their
+// values, so ANY numbering that is ascending in the value reproduces the planes: rank = pieces of smaller value + pieces of
+// the same value on lower cells.  Lane k holds the k-th occupied cell (as in enumerate_wave).
+template <int PMAX>
+__device__ __forceinline__ void wave_store_positions(const Board& b, uint64_t* __restrict__ planes, int64_t n, int64_t i) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t occ = occupancy(b);
+    const uint32_t pieces = (uint32_t)__popcll(occ);
+    const bool alive = lane < pieces;
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(occ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)occ, 0u));
+    const bool occupied = ((occ >> lane) & 1ull) != 0ull;
+    const uint32_t told = (uint32_t)__builtin_amdgcn_ds_permute((int)((occupied ? below : 63u) << 2), (int)lane);
+    const uint32_t cell = alive ? told : 0u;
+    const uint32_t value = alive ? value_at(b, (int)cell) : 0xFFu;
+    uint32_t rank = 0;
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) {
+        const uint32_t vj = (uint32_t)__builtin_amdgcn_readlane((int)value, j);
+        rank += (vj < value || (vj == value && (uint32_t)j < lane)) ? 1u : 0u;
+    }
+    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)((alive ? rank : 63u) << 2), (int)cell);
+    const uint32_t part = alive ? (got & 63u) << (8u * (lane & 3u)) : 0u;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k) w[k >> 2] |= (uint32_t)__builtin_amdgcn_readlane((int)part, k);
+    if (lane == 0u) {
+        planes[i] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        if (PMAX > 8) planes[n + i] = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    }
+}
+
 // the device-wide pool of parked boards (see the kernel): boards a workgroup parks, dwords per entry (positions, game, plies)
 constexpr uint32_t kPoolCap = 64, kPoolWords = 6;
 
@@ -1244,13 +1673,36 @@ struct ParkedPieces {
 #else
 #define BGS_K3P_OCCUPANCY
 #endif
-template <int PMAX, int BLOCK>
+// what the tail role of a launch needs (TAIL; see "the TAIL QUEUE" above)
+struct TailArgs {
+    uint32_t* counters;       // tq[0..3]
+    uint32_t* ready;          // [capacity]
+    uint32_t* entries;        // [capacity][kTailEntryWords]
+    uint32_t capacity;
+    uint32_t serial;          // this launch's "entry complete" word
+    uint32_t final_cap;       // the rollout's ply cap (the bulk loop stops at max_plies)
+    uint32_t handoff_at;      // a workgroup's last wave hands its boards over at this many or fewer (0: plays them to the bulk cap)
+    uint32_t limit;           // tail waves that may wait for entries at a time (the last bulk wave always stays)
+    uint32_t epoch_limit, cold_limit, bypass_plies;   // K3w's memo policy
+};
+
+template <int PMAX, bool TAIL>
+union WaveRegion {   // per wave: the chunk's book lines while it is in the bulk loop, K3w's memo once it has left it
+    uint4 opened[4][BGS_WAVE];
+    WaveMemo<PMAX> memo;
+};
+template <int PMAX>
+union WaveRegion<PMAX, false> {
+    uint4 opened[4][BGS_WAVE];
+};
+
+template <int PMAX, int BLOCK, bool TAIL, class GEO>
 __global__ void __launch_bounds__(BLOCK) BGS_K3P_OCCUPANCY
-k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                         uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
                         unsigned long long* __restrict__ steps, uint32_t chunk, uint32_t* __restrict__ queue, uint32_t park_at,
                         uint32_t* gpool, const uint32_t* __restrict__ book_links, const BookEntry* __restrict__ book_table,
-                        uint32_t book_depth, uint32_t book_n0) {
+                        uint32_t book_depth, uint32_t book_n0, TailArgs tail) {
     __shared__ ParkedPieces<PMAX, BLOCK> parked;
     __shared__ uint32_t book_lds[kBookLdsLinks];   // the opening book's links of levels 1 and 2 (4.25 KB)
     // ... and the boards of the wave's current chunk as the book hands them out: a chunk (at most 64 games) is walked through
@@ -1258,7 +1710,7 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
     // -- and parked here, a 64-byte line a game; a lane that takes a game reads its line.  (Walked where the lane takes the
     // game, the walk ran in almost every iteration -- some lane of 64 always finishes -- for two or three lanes: ~100 VALU
     // an iteration, 4 % of a ply.)
-    __shared__ uint4 opened_lds[BLOCK / BGS_WAVE][4][BGS_WAVE];
+    __shared__ WaveRegion<PMAX, TAIL> wave_lds[BLOCK / BGS_WAVE];
     if (book_depth >= 2u)
         for (uint32_t i = threadIdx.x; i < kBookLdsLinks; i += BLOCK) book_lds[i] = book_links[i];
     Lands<PMAX> lands;   // (registers; valid from a ply's search to its move)
@@ -1270,6 +1722,7 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
         parked.head[threadIdx.x] = 0u;
     }
     if (threadIdx.x == 0) parked.active = WAVES;
+    if (TAIL && threadIdx.x == 0) (void)__hip_atomic_fetch_add(tail.counters + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // workgroups started
     __syncthreads();
     // (the drain -- parked boards, `active`, the last wave sweeping up -- is k_bounce_rollout_flat's, see there)
     bool last = false;
@@ -1308,6 +1761,22 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
             old = acq_rel ? __hip_atomic_fetch_add(word, by, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
                           : __hip_atomic_fetch_add(word, by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return (uint32_t)__builtin_amdgcn_readfirstlane(old);
+    };
+
+    // the lanes with `mine` set hand their boards (positions, game, plies) to the tail queue: one allocation a wave
+    auto push_tail = [&](bool mine, const PieceBoard<PMAX>& board, uint32_t the_game, uint32_t the_plies) {
+        const uint64_t who = __builtin_amdgcn_ballot_w64(mine);
+        if (!who) return;
+        const uint32_t base = gbump(tail.counters, (uint32_t)__popcll(who), false);
+        if (mine) {
+            const uint32_t e = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(who >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)who, 0u));
+            uint32_t* slot = tail.entries + (size_t)e * kTailEntryWords;   // (e < capacity: a game is handed over at most once)
+            *reinterpret_cast<uint4*>(slot) = make_uint4(board.pos[0], PMAX > 4 ? board.pos[PMAX > 4 ? 1 : 0] : 0u,
+                                                         PMAX > 8 ? board.pos[PMAX > 8 ? 2 : 0] : 0u, PMAX > 12 ? board.pos[PMAX > 12 ? 3 : 0] : 0u);
+            *reinterpret_cast<uint2*>(slot + 4) = make_uint2(the_game, the_plies);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(tail.ready + e, tail.serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
 
     PieceBoard<PMAX> b;
@@ -1361,10 +1830,10 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
                 }
                 const uint4* line = reinterpret_cast<const uint4*>(book_table + at);
                 const uint4 q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3];
-                opened_lds[w][0][lane] = q0;
-                opened_lds[w][1][lane] = q1;
-                opened_lds[w][2][lane] = q2;
-                opened_lds[w][3][lane] = q3;
+                wave_lds[w].opened[0][lane] = q0;
+                wave_lds[w].opened[1][lane] = q1;
+                wave_lds[w].opened[2][lane] = q2;
+                wave_lds[w].opened[3][lane] = q3;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1376,8 +1845,8 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
                 if (book_depth) {
                     const uint32_t slot = taken + rank;   // (a chunk is at most 64 games: bounce_rollout)
                     have_block = false;
-                    const uint4 q0 = opened_lds[w][0][slot], q1 = opened_lds[w][1][slot], q2 = opened_lds[w][2][slot],
-                                q3 = opened_lds[w][3][slot];
+                    const uint4 q0 = wave_lds[w].opened[0][slot], q1 = wave_lds[w].opened[1][slot], q2 = wave_lds[w].opened[2][slot],
+                                q3 = wave_lds[w].opened[3][slot];
                     const uint32_t where[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
                     for (int j = 0; j < PMAX / 4; ++j) b.pos[j] = where[j];
@@ -1529,6 +1998,16 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
         const bool run = has && !pending && st == BGS_ST_RUNNING && plies < max_plies;
 
         // ---- boards that stopped go to memory and free their lane (from the start position: every board is written)
+        if (TAIL) {
+            // a game that goes on beyond the bulk cap: to the tail queue (its action list, if one was just counted, is left behind)
+            const bool over = has && !run && !pending && st == BGS_ST_RUNNING && plies < tail.final_cap;
+            push_tail(over, b, game, plies);
+            if (over) {
+                stepped += plies - first_ply;
+                has = false;
+                search = false;
+            }
+        }
         if (has && !run && !pending) {
             const int64_t i = game;
             store_positions<PMAX>(planes, n, i, b);
@@ -1555,6 +2034,17 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
             if (leave() > 1u) break;    // others are still running: whatever gets parked later is theirs
             last = true;                // everybody else has left: sweep up what they parked
             continue;
+        }
+        if (TAIL && draining && last && tail.handoff_at && lds_exhausted) {
+            // ---- the workgroup's last wave hands its last boards to the tail queue and follows them (same condition as the
+            // device-wide pool's below: only in an iteration whose adoption attempt has emptied the workgroup's LDS pool)
+            const uint32_t left = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has));
+            if (left <= tail.handoff_at) {
+                push_tail(has, b, game, plies);
+                if (has) stepped += plies - first_ply;
+                has = false;
+                break;
+            }
         }
         if (draining && last && !glast && gpool && park_at && lds_exhausted) {
             // ---- the workgroup's last wave parks its last boards for the other workgroups' last waves -- but only in an
@@ -1644,6 +2134,79 @@ k_bounce_rollout_pieces(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __
                 has = false;
             } else {
                 search = true;
+            }
+        }
+    }
+    if constexpr (TAIL) {
+        // ---- this wave's part of the bulk loop is over: it becomes a K3w wave (see "the TAIL QUEUE")
+        constexpr uint32_t kWavesPerGroup = BLOCK / BGS_WAVE;
+        const uint32_t bulk_waves = gridDim.x * kWavesPerGroup;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (this wave's entries before its departure)
+        const uint32_t gone = gbump(tail.counters + 2, 1u, true) + 1u;
+        const uint32_t seat = gbump(tail.counters + 3, 1u, false);
+        // A wave takes the tail role only when every workgroup of the launch has started: the bulk waves it will wait for are
+        // then all resident and run whatever the tail waves do.  With workgroups still to be dispatched a waiting wave could
+        // hold the very slot they need (20 launches in flight do that to each other): such a wave leaves; what the queue
+        // holds is taken by the waves that come later -- the launch's last bulk wave always stays until the queue is empty.
+        uint32_t started = 0;
+        if (lane == 0u) started = __hip_atomic_load(tail.counters + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        started = (uint32_t)__builtin_amdgcn_readfirstlane((int)started);
+        if (gone == bulk_waves || (started == gridDim.x && seat < tail.limit)) {
+            __builtin_amdgcn_s_setprio(3);   // (as K3w: these waves are the launch's critical path)
+            WaveMemo<PMAX>& memo = wave_lds[w].memo;
+            uint32_t epoch = 1;
+            bool memo_ready = false;
+            for (;;) {
+                // a ticket, then the wait for ITS entry (a word of its own: the waiting waves do not meet on one address) --
+                // or for the end: every bulk wave gone and the ticket at or beyond what was ever allocated
+                const uint32_t t = gbump(tail.counters + 1, 1u, false);
+                bool there = false;
+                for (;;) {
+                    uint32_t flag = 0, left_bulk = 0, allocated = 0;
+                    if (lane == 0u) {
+                        if (t < tail.capacity) flag = __hip_atomic_load(tail.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        left_bulk = __hip_atomic_load(tail.counters + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag);
+                    left_bulk = (uint32_t)__builtin_amdgcn_readfirstlane((int)left_bulk);
+                    if (t < tail.capacity && flag == tail.serial) {
+                        there = true;
+                        break;
+                    }
+                    if (left_bulk == bulk_waves) {
+                        // (the bulk waves' allocations are ordered before their departure: read behind an acquire of that count)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        if (lane == 0u) allocated = __hip_atomic_load(tail.counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        allocated = (uint32_t)__builtin_amdgcn_readfirstlane((int)allocated);
+                        if (t >= allocated) break;
+                        // (an entry that was allocated is complete by now: the flag is read again)
+                    }
+                    __builtin_amdgcn_s_sleep(40);
+                }
+                if (!there) break;
+                if (!memo_ready) {
+                    wave_memo_reset(memo, lane);
+                    memo_ready = true;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const uint32_t* e = tail.entries + (size_t)t * kTailEntryWords;
+                uint32_t where[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) where[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[j]);
+                const uint32_t the_game = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[4]);
+                uint32_t the_plies = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[5]);
+                const uint32_t came_with = the_plies;
+                Board board = planes_from_positions<PMAX>(g, where);
+                uint32_t the_st = BGS_ST_RUNNING;
+                wave_play_game<PMAX>(g, memo, epoch, board, the_st, the_plies, seed, first_game + (uint64_t)the_game, tail.final_cap,
+                                     tail.epoch_limit, tail.cold_limit, tail.bypass_plies);
+                wave_store_positions<PMAX>(board, planes, n, (int64_t)the_game);
+                if (lane == 0u) {
+                    status[the_game] = (uint8_t)the_st;
+                    plies_buf[the_game] = (uint16_t)the_plies;
+                    reward[the_game] = reward_pair(the_st);
+                    stepped += the_plies - came_with;
+                }
             }
         }
     }
@@ -1885,159 +2448,20 @@ k_bounce_compact(const uint8_t* __restrict__ status, const uint16_t* __restrict_
         worklist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)i;
 }
 
-// ------------------------------------------------------------------------------------------------
-// K3w: ONE BOARD PER WAVE, a piece per lane -- the last pass of the rollout, for the handful of games per batch that
-// run for thousands of plies (one or two per 2^18 never end and stop at max_plies).  Such a game is a chain of dependent
-// plies; the launch is over when it is, so what counts is the LATENCY of its ply, i.e. how many instructions the wave
-// that holds it has to issue per ply.  The 8-lanes-per-board kernel walks a column's closure cell by cell (a lane runs
-// `reach`: ~1000 instructions a ply on the longest column).  Here the lanes ARE the pieces (lane k = the k-th occupied
-// cell, re-derived from the planes every ply, so the lanes are always in cell order):
-//   A   every lane runs its own piece's segment (the same code as K3p's phase A; the step loop runs to the largest value
-//       on the board, lanes drop out at their own);
-//   hit "which pieces does my segment land on": the cells of the other pieces come over v_readlane, one bit test each;
-//   B1  the closure of "lands on" -- Warshall with one ROW PER LANE: pivot p's row comes over v_readlane, every lane
-//       that has bit p takes it in (three instructions a pivot instead of K3p's multiply over six packed dwords);
-//   B2  a source's targets = the OR of its members' landing masks (masks over v_readlane, selected by sign-extended
-//       member bits), counts; the sources of the active row are neighbouring lanes in column order, so "actions before
-//       mine" is a prefix sum over 16 lanes (four DPP row shifts), the total is lane 15's;
-//   pick the lane whose range holds the index is the source (a ballot); its k-th target is found by the CELLS (lane c counts
-//       the targets below cell c with v_mbcnt; the target cell whose count is k is it): a dozen instructions.
-// ~320 VALU and ~50 v_readlane a ply against ~1000.  The board itself (four value planes) is wave-uniform, and so is all
-// the state of the wave's one game -- kept in scalar registers on purpose (see the ply loop: `same`, `word_at`).
-// Measured per ply of a wave that has its SIMD to itself (cycle counter, round 5): a full search 3 200 cycles, with the
-// memo's look-up, fill and link bookkeeping around it 4 400, a remembered position 1 300, a hop along a link 250.
-// Results cannot differ from the other kernels': the same rules, the same canonical action order (sources by column,
-// targets by cell index), the RNG keyed by game id and ply.
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t kWaveMemoBits = 5, kWaveMemoSlots = 1u << kWaveMemoBits;
-constexpr uint32_t kWaveLinks = 32;   // actions per remembered position whose successor is remembered too (K3w, see the ply loop)
-// a link word is epoch << 16 | actions of the successor << 8 | the successor's slot, and lanes 0 .. kWaveLinks - 1 clear a row
-static_assert(kWaveMemoSlots <= 256 && kWaveLinks <= 64, "a link holds the slot in 8 bits; one wave clears a slot's row of links");
-constexpr uint32_t kWaveEpochLimit = 0xFFFFu;   // 16 bits of epoch in a link: at the limit the memo starts over empty
-
-struct WaveMoves {
-    uint64_t targets;    // this lane's piece, if it is a source: its legal landing cells
-    uint32_t count;      // popcount(targets)
-    uint32_t before;     // actions of the sources left of this lane's
-    uint32_t cell;       // this lane's piece stands here
-    uint32_t n;          // actions of the board (uniform)
-};
-
-__device__ __forceinline__ uint32_t row_shift_right(uint32_t x, int by) {   // lane i of a 16-lane row gets lane i - by's x, 0 below
-    switch (by) {
-        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
-        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
-        case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
-        default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
-    }
-}
-
-template <int PMAX>
-__device__ __forceinline__ void enumerate_wave(const BounceGeom& g, const Board& b, uint32_t player, WaveMoves& m) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t occ = occupancy(b);
-    const uint32_t pieces = (uint32_t)__popcll(occ);          // (uniform; <= PMAX: the host only sends such boards)
-    const bool alive = lane < pieces;
-    // the cell of the lane-th piece.  The board is the same on every lane, so lane c knows whether cell c is occupied and how
-    // many pieces stand below it (two v_mbcnt on the occupancy) -- the number of the lane that wants to know -- and tells it
-    // with ONE forward permute; the popcount-guided search for the lane-th set bit is forty instructions (round 5)
-    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(occ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)occ, 0u));
-    const bool occupied = ((occ >> lane) & 1ull) != 0ull;
-    static_assert(PMAX < 63, "lane 63 takes what the empty cells send");
-    const uint32_t told = (uint32_t)__builtin_amdgcn_ds_permute((int)((occupied ? below : 63u) << 2), (int)lane);
-    const uint32_t cell = alive ? told : 0u;
-    const uint32_t value = alive ? value_at(b, (int)cell) : 0u;
-    m.cell = cell;
-    const uint64_t empty_interior = ~occ & g.interior;
-    const uint64_t landing = empty_interior | (player ? g.goal_bottom : g.goal_top);
-    const uint32_t up = player ? 0u : (uint32_t)g.w, down = player ? (uint32_t)g.w : 0u;
-    // A: the landing cells of this lane's piece
-    uint64_t a0 = alive ? 1ull << cell : 0ull, al = 0, ar = 0, land = 0;
-    for (uint32_t s = 1; __builtin_amdgcn_ballot_w64(s <= value) != 0ull; ++s) {
-        if (s <= value) {
-            const uint64_t via_left = a0 | al, via_right = a0 | ar;
-            const uint64_t nf = ((via_left | ar) << up) >> down;
-            const uint64_t nl = (via_left & g.not_col0) >> 1;
-            const uint64_t nr = (via_right & g.not_collast) << 1;
-            if (s < value) {
-                a0 = nf & empty_interior;
-                al = nl & empty_interior;
-                ar = nr & empty_interior;
-            } else {
-                land = nf | nl | nr;
-            }
-        }
-    }
-    // who stands on them (bit j = the piece of lane j); a segment never returns to its own start cell
-    uint32_t row = 0;
-    // (no "is there a piece j" tests: a lane without a piece has no landing cells and an empty row, so whatever bit the
-    // others compute FOR it selects nothing -- and a branch costs a lone wave more than the three instructions it skips)
-#pragma unroll
-    for (int j = 0; j < PMAX; ++j) {
-        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cell, j);
-        row |= ((uint32_t)(land >> cj) & 1u) << j;
-    }
-    // B1: the closure over bounces, a row per lane
-#pragma unroll
-    for (int p = 0; p < PMAX; ++p) {
-        const uint32_t rp = (uint32_t)__builtin_amdgcn_readlane((int)row, p);
-        row |= (uint32_t)__builtin_amdgcn_sbfe((int)row, p, 1) & rp;
-    }
-    // B2: a source's targets are the landing cells of its closure
-    const uint64_t sources = movable(g, occ, player);
-    const bool is_source = alive && ((sources >> cell) & 1ull);
-    const uint32_t members = row | (1u << lane);
-    uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int j = 0; j < PMAX; ++j) {
-        const uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)land, j);
-        const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(land >> 32), j);
-        const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)members, j, 1);
-        lo |= lj & sel;
-        hi |= hj & sel;
-    }
-    const uint64_t targets = is_source ? ((((uint64_t)hi << 32) | lo) & landing) : 0ull;
-    const uint32_t count = (uint32_t)__popcll(targets);
-    uint32_t incl = count;   // the lanes are in cell order and the sources share a row: a prefix sum is "in column order"
-    incl += row_shift_right(incl, 1);
-    incl += row_shift_right(incl, 2);
-    incl += row_shift_right(incl, 4);
-    incl += row_shift_right(incl, 8);
-    m.targets = targets;
-    m.count = count;
-    m.before = incl - count;
-    m.n = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
-}
-
-template <int PMAX>
+// (K3w's enumeration, memo and ply loop -- enumerate_wave, WaveMemo, wave_play_game -- are defined in front of K3p, whose waves
+// run them too when they have left the bulk loop: see there)
+template <int PMAX, class GEO>
 __global__ void __launch_bounds__(BGS_WAVE)
-k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+k_bounce_rollout_wave(GEO g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
                       uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, uint32_t max_plies,
                       unsigned long long* __restrict__ steps, const uint32_t* __restrict__ worklist,
                       const uint32_t* __restrict__ work_count, uint32_t epoch_limit, uint32_t cold_limit, uint32_t bypass_plies) {
     static_assert(PMAX <= 16, "the prefix sum runs over one 16-lane row");
     __builtin_amdgcn_s_setprio(3);   // (see k_bounce_rollout: these waves are the launch's critical path)
     const uint32_t lane = threadIdx.x & 63u;
-    // the wave's memo of action lists (see the ply loop): kWaveMemoSlots = 32 positions in 16 sets of 2 ways, ~11 KB with the links (PMAX = 16)
-    __shared__ uint64_t memo_key[kWaveMemoSlots][4];
-    __shared__ uint64_t memo_targets[kWaveMemoSlots][PMAX];
-    __shared__ uint32_t memo_lane[kWaveMemoSlots][PMAX];
-    __shared__ uint32_t memo_n[kWaveMemoSlots];
-    __shared__ uint32_t memo_tag[kWaveMemoSlots];
-    __shared__ uint32_t memo_last[kWaveMemoSlots / 2];   // per set: the way used last
-    // ... and where the remembered positions LEAD: links[slot][action] = epoch << 16 | actions of the successor << 8 | its slot.
-    // A link holds as long as no remembered position has been replaced since it was written (`epoch` counts those; a slot's
-    // row is cleared when the slot is filled).  A game that never ends hops along them -- one LDS look-up, a sample, no
-    // board -- for as long as the sampled action has a link: 0.13 us a ply where the look-up of the position costs 0.55.
-    // (a row has one more word than links, always 0: "no link" for an action beyond the row, read without a test)
-    __shared__ uint32_t memo_link[kWaveMemoSlots][kWaveLinks + 1u];
+    __shared__ WaveMemo<PMAX> memo;   // the wave's memo of action lists (see wave_play_game)
     uint32_t epoch = 1;
-    for (uint32_t e = lane; e < kWaveMemoSlots; e += BGS_WAVE) {
-        memo_tag[e] = 0xFFFFFFFFu;   // (no side is 0xFFFFFFFF)
-        memo_last[e >> 1] = 1u;
-        memo_link[e][kWaveLinks] = 0u;
-    }
-    __syncthreads();   // (one wave: orders the LDS accesses of its lanes)
+    wave_memo_reset(memo, lane);
     const uint32_t total = *work_count;
     uint32_t stepped = 0;
     for (uint32_t entry = blockIdx.x; entry < total; entry += gridDim.x) {
@@ -2053,7 +2477,9 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
         if (st != BGS_ST_RUNNING || plies >= max_plies) continue;
         if ((uint32_t)__popcll(occupancy(b)) > (uint32_t)PMAX) {
             // more pieces than lanes provided for (a batch loaded from memory may hold anything): lane 0 plays the board with
-            // the thread-per-board code -- correct, slow, and rare (the host does not send batches CONFIGURED with that many)
+            // the thread-per-board code -- correct, slow, and rare (the host does not send batches CONFIGURED with that many;
+            // the compile-time geometry is only used for boards that descend from its own start position: never)
+            if constexpr (std::is_same<GEO, BounceGeom>::value)
             if (lane == 0u) {
                 const uint32_t before = plies;
                 (void)play<false>(g, b, st, plies, seed, first_game + (uint64_t)game, max_plies);
@@ -2066,195 +2492,7 @@ k_bounce_rollout_wave(BounceGeom g, uint64_t* __restrict__ planes, uint8_t* __re
             continue;
         }
         const uint32_t first_ply = plies;
-        WaveMoves mv;
-        // The words of the plies to come.  The board is one, the lanes are 64: lane l keeps the word of ply `ahead_first` + l
-        // (its own philox call, for the block that ply lies in), so one call's latency buys the words of 64 plies, and a
-        // ply's word is ONE v_readlane away -- a scalar.  That matters beyond the philox calls it saves (one every four
-        // plies on all lanes alike, a third of a hop's dependent chain): bgs_common.h's philox_word selects its word
-        // through vector registers on purpose, which made the word -- and with it the sampled index, the link, the loop
-        // exits and the ply count of this whole loop -- divergent in the compiler's eyes: every hop ran as masked vector
-        // code.  With the word a scalar the hop is scalar arithmetic around one LDS look-up (round 5).
-        uint32_t ahead = 0u;
-        uint32_t ahead_first = 0x80000000u;   // (uniform; nothing computed yet: every ply -- at most 65535 -- is "64 or more past it")
-        auto word_at = [&](uint32_t ply) -> uint32_t {
-            if (ply - ahead_first >= (uint32_t)BGS_WAVE) {   // (unsigned: also a ply below the window)
-                ahead_first = ply & ~3u;
-                const Philox4 mine = philox4x32_10(seed, first_game + (uint64_t)game, (ahead_first >> 2) + (lane >> 2));
-                ahead = philox_word(mine, lane);
-            }
-            return (uint32_t)__builtin_amdgcn_readlane((int)ahead, (int)(ply - ahead_first));
-        };
-        // One enumeration site.  `side` is whose action list is built next; after a move it is the other player's, and
-        // an empty list there means the game is over: the mover wins if HE could still move, else it is a draw -- one more
-        // enumeration, for the mover (`blocked`).  A board that arrives blocked is settled by the same rule with the
-        // roles of a move that never happened (settle_blocked).
-        uint32_t side = plies & 1u;
-        bool blocked = false;
-        uint32_t came_from = 0xFFFFFFFFu, came_by = 0;   // the slot and the action that led to the position about to be looked up
-        // The memo pays for games that stay among a few positions; a long game that WANDERS misses on every ply and pays for
-        // the look-up, the fill and the link bookkeeping all the same: a fifth of its ply (the longest such game, a few hundred
-        // plies, is what most launches of this kernel wait for -- an endless game hops through its 4000 plies in less).  So
-        // after `cold_limit` look-ups in a row that missed the wave plays `bypass_plies` plies without the memo, then looks
-        // again: a game that has settled into a cycle is found out within that many plies.  (Twice the limit for a game's first
-        // look-ups: the memo may know nothing of it yet, and a game that arrives cycling should not sit out a bypass first.)
-        uint32_t cold = 0, bypass = 0, slot = 0, cold_now = 2u * cold_limit;
-        auto same = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
-        for (;;) {
-            // (the state of the ONE game this wave plays is the same on every lane; saying so keeps it in scalar registers
-            // and its tests on the scalar unit -- the compiler cannot see it through the loop's memory and lane traffic)
-            plies = same(plies);
-            side = same(side);
-            epoch = same(epoch);
-            // The games this pass exists for do not wander: the one endless game of a 2^18-board batch of the default start
-            // visits 27 positions in 4096 plies, four of them in its last 2000 (tools/bounce_endless.py).  The action list of a
-            // position is a function of the position, so the wave keeps the lists it has built in LDS, keyed by the board and
-            // the side (compared in full: a hit IS the list enumerate_wave would build, for any board of the batch), and a ply
-            // on a known position costs a look-up instead of the search.  32 sets of two ways, the way not used last is
-            // replaced: direct-mapped, two of a game's handful of hot positions shared a slot in one launch of ten and every
-            // ply of that game missed (4.7 ms against 2.5).
-            const bool with_memo = bypass == 0u;
-            if (!with_memo) {
-                --bypass;
-                enumerate_wave<PMAX>(g, b, side, mv);
-            } else {
-            uint32_t set;
-            {
-                uint32_t h = (uint32_t)b.v[0] * 0x9E3779B1u ^ (uint32_t)(b.v[0] >> 32) * 0x85EBCA77u;
-                h ^= ((uint32_t)b.v[1] * 0xC2B2AE3Du) ^ ((uint32_t)(b.v[1] >> 32) * 0x27D4EB2Fu);
-                h ^= ((uint32_t)b.v[2] * 0x165667B1u) ^ ((uint32_t)(b.v[2] >> 32) * 0xD3A2646Cu);
-                h ^= ((uint32_t)b.v[3] * 0xFD7046C5u) ^ ((uint32_t)(b.v[3] >> 32) * 0xB55A4F09u);
-                set = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((h ^ (h >> 15)) * 0x2C1B3C6Du) >> (33 - kWaveMemoBits))) ^ side;
-                set &= kWaveMemoSlots / 2u - 1u;
-            }
-            // (both ways' keys and tags are read at once and compared afterwards: one LDS round trip, then the records of
-            // the way that hit.  Written with && the compiler reads tag, then the key word by word: six round trips of ~110
-            // cycles each, 40 % of a remembered ply.)
-            const uint32_t w0 = 2u * set, w1 = w0 + 1u;
-            const uint32_t tag0 = memo_tag[w0], tag1 = memo_tag[w1], last = memo_last[set];
-            uint32_t differ0 = tag0 ^ side, differ1 = tag1 ^ side;   // (32-bit xor / or chains: 17 instructions a way)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint64_t ka = memo_key[w0][j], kc = memo_key[w1][j];
-                differ0 |= ((uint32_t)ka ^ (uint32_t)b.v[j]) | ((uint32_t)(ka >> 32) ^ (uint32_t)(b.v[j] >> 32));
-                differ1 |= ((uint32_t)kc ^ (uint32_t)b.v[j]) | ((uint32_t)(kc >> 32) ^ (uint32_t)(b.v[j] >> 32));
-            }
-            const uint32_t found = (uint32_t)__builtin_amdgcn_readfirstlane((int)((differ0 == 0u ? 1u : 0u) | (differ1 == 0u ? 2u : 0u)));
-            const uint32_t way = found ? found >> 1 : ((uint32_t)__builtin_amdgcn_readfirstlane((int)last) ^ 1u) & 1u;   // hit, or the victim
-            slot = w0 + way;
-            if (found) {
-                cold = 0;
-                const uint32_t at = lane < (uint32_t)PMAX ? lane : 0u;
-                const uint32_t packed = memo_lane[slot][at];
-                mv.targets = lane < (uint32_t)PMAX ? memo_targets[slot][at] : 0ull;
-                mv.cell = packed & 255u;
-                mv.count = lane < (uint32_t)PMAX ? (packed >> 8) & 255u : 0u;
-                mv.before = packed >> 16;
-                mv.n = (uint32_t)__builtin_amdgcn_readfirstlane((int)memo_n[slot]);
-                if (way != ((uint32_t)__builtin_amdgcn_readfirstlane((int)last) & 1u)) {
-                    if (lane == 0u) memo_last[set] = way;
-                    __syncthreads();
-                }
-            } else {
-                enumerate_wave<PMAX>(g, b, side, mv);
-                // the victim way: if it held a position, every link written so far may point at it -- a new epoch
-                const uint32_t victim_tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)(way ? tag1 : tag0));
-                if (victim_tag != 0xFFFFFFFFu && ++epoch >= epoch_limit) {   // (16 bits in a link: start over with an empty memo)
-                    for (uint32_t e = lane; e < kWaveMemoSlots; e += BGS_WAVE) memo_tag[e] = 0xFFFFFFFFu;
-                    epoch = 1;
-                    __syncthreads();
-                }
-                if (lane < (uint32_t)PMAX) {
-                    memo_targets[slot][lane] = mv.targets;
-                    memo_lane[slot][lane] = mv.cell | (mv.count << 8) | (mv.before << 16);
-                }
-                if (lane < kWaveLinks) memo_link[slot][lane] = 0u;
-                if (lane == 0u) {
-                    memo_key[slot][0] = b.v[0];
-                    memo_key[slot][1] = b.v[1];
-                    memo_key[slot][2] = b.v[2];
-                    memo_key[slot][3] = b.v[3];
-                    memo_n[slot] = mv.n;
-                    memo_tag[slot] = side;
-                    memo_last[set] = way;
-                }
-                __syncthreads();   // (uniform branch, one wave: lane 0's stores before anybody's next look-up)
-                if (++cold >= cold_now) {
-                    cold = 0;
-                    cold_now = cold_limit;
-                    bypass = bypass_plies;
-                }
-            }
-            }
-            if (came_from != 0xFFFFFFFFu) {
-                // the move played last led HERE: remember it (unless this very look-up evicted the position it was played from)
-                if (came_from != slot && came_by < kWaveLinks) {
-                    // (a successor without actions -- the game ends there -- or with more than a byte holds gets no link: 0)
-                    if (lane == 0u) memo_link[came_from][came_by] = mv.n - 1u < 255u ? (epoch << 16) | (mv.n << 8) | slot : 0u;
-                    __syncthreads();
-                }
-                came_from = 0xFFFFFFFFu;
-            }
-            if (blocked) {
-                st = mv.n ? side + 1u : BGS_ST_DRAW;
-                break;
-            }
-            if (mv.n == 0) {
-                blocked = true;
-                side = 1u - side;
-                continue;
-            }
-            if (plies >= max_plies) break;
-            const uint32_t idx = sample_index(word_at(plies), mv.n);
-            if (with_memo) {
-                // does the sampled action have a link?  Then hop: the successor's slot and the number of its actions are in
-                // the link, its own links are one look-up away -- the board stays behind until a hop has no link (or the
-                // ply cap is reached), and is then taken from the memo's key of the position the hops ended on.  A hop is a
-                // chain of dependent steps on a wave that has the SIMD to itself, so it is written for few of them: one test
-                // per link (a link is valid iff it carries the current epoch: 0, the empty word, never does), the row's extra
-                // word instead of "is the action inside the row".
-                uint32_t at = slot, next = idx;
-                const uint32_t ply0 = plies;
-                for (;;) {
-                    const uint32_t link = same(memo_link[at][next < kWaveLinks ? next : kWaveLinks]);
-                    if ((link >> 16) != epoch) break;
-                    at = link & 255u;
-                    ++plies;
-                    if (plies >= max_plies) break;
-                    next = sample_index(word_at(plies), (link >> 8) & 255u);
-                }
-                if (plies != ply0) {
-                    cold = 0;
-                    side ^= (plies - ply0) & 1u;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint64_t word = memo_key[at][j];
-                        b.v[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(word >> 32)) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
-                    }
-                    continue;   // the look-up at the top finds this position, and the ply goes on from its lists
-                }
-            }
-            const bool here = idx - mv.before < mv.count;   // (unsigned: idx < before wraps; count is 0 on every lane that is no source)
-            const uint64_t owner = __builtin_amdgcn_ballot_w64(here);   // exactly one lane: the source
-            const int from = (__ffsll((unsigned long long)owner) - 1) & 63;
-            // its k-th target, found by the CELLS: lane c counts the targets below cell c; the one target cell whose count is k
-            // is it (a dozen instructions, most of them scalar, against the forty of the search for the k-th set bit)
-            const uint32_t k = idx - (uint32_t)__builtin_amdgcn_readlane((int)mv.before, from);
-            const uint32_t t_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv.targets, from);
-            const uint32_t t_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mv.targets >> 32), from);
-            const uint64_t kth = __builtin_amdgcn_ballot_w64(__builtin_amdgcn_mbcnt_hi(t_hi, __builtin_amdgcn_mbcnt_lo(t_lo, 0u)) == k) &
-                                 (((uint64_t)t_hi << 32) | t_lo);
-            const int s = __builtin_amdgcn_readlane((int)mv.cell, from), t = __ffsll((unsigned long long)kth) - 1;
-            move_piece(b, s, t);
-            ++plies;
-            if ((1ull << t) & (g.goal_top | g.goal_bottom)) {
-                st = side + 1u;
-                break;
-            }
-            side = 1u - side;
-            came_from = with_memo ? slot : 0xFFFFFFFFu;
-            came_by = idx;
-        }
+        wave_play_game<PMAX>(g, memo, epoch, b, st, plies, seed, first_game + (uint64_t)game, max_plies, epoch_limit, cold_limit, bypass_plies);
         if (lane == 0u) {
             store_board(planes, n, i, b);
             status[i] = (uint8_t)st;
@@ -2399,8 +2637,9 @@ void bounce_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
 
 // One launch of the fused rollout: over the whole batch (worklist == nullptr) or over a work list.
 // group = lanes per board (1 or 8), wps = waves per SIMD the grid is sized for.
+// final_cap > cap: the bulk pass of a plan whose tail is K3w's code INSIDE the same launch (K3p only; see "the TAIL QUEUE")
 static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool from_initial, int group, int wps,
-                           const uint32_t* worklist, const uint32_t* work_count, uint32_t* queue) {
+                           const uint32_t* worklist, const uint32_t* work_count, uint32_t* queue, uint32_t final_cap = 0) {
     if (group == 64) {   // K3w: a work list of a few very long games, one wave each (a wave strides over the list)
         auto launch_wave = [&](auto pmax_tag) {
             constexpr int PMAX = decltype(pmax_tag)::value;
@@ -2409,11 +2648,16 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
             // 8192 / 16384 waves read 2.39 / 2.61 / 2.78 / 2.83 x 10^9 one launch at a time, and the same with 4 and 20 in flight)
             static const int grid_env = [] { const char* e = bgs::experiment("bounce_wave_grid"); return e ? atoi(e) : 0; }();
             const unsigned wave_grid = grid_env > 0 ? (unsigned)grid_env : 8192u;
-            hipLaunchKernelGGL((k_bounce_rollout_wave<PMAX>), dim3(wave_grid), dim3(BGS_WAVE), 0,
-                               b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
-                               seed, b->first_game, cap, b->d_steps, worklist, work_count,
-                               b->bounce_epoch_limit >= 2 && b->bounce_epoch_limit < (int)kWaveEpochLimit ? (uint32_t)b->bounce_epoch_limit : kWaveEpochLimit,
-                               (uint32_t)b->bounce_memo_cold, (uint32_t)b->bounce_memo_bypass);
+            auto go = [&](auto geo) {
+                hipLaunchKernelGGL((k_bounce_rollout_wave<PMAX, decltype(geo)>), dim3(wave_grid), dim3(BGS_WAVE), 0,
+                                   b->stream, geo, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
+                                   seed, b->first_game, cap, b->d_steps, worklist, work_count,
+                                   b->bounce_epoch_limit >= 2 && b->bounce_epoch_limit < (int)kWaveEpochLimit ? (uint32_t)b->bounce_epoch_limit : kWaveEpochLimit,
+                                   (uint32_t)b->bounce_memo_cold, (uint32_t)b->bounce_memo_bypass);
+            };
+            // (the default board from its own start position: the compile-time geometry, see bounce_unit.h)
+            if (PMAX == 12 && from_initial && b->bounce_static_geom && bounce_is_default(b->bg)) go(DefaultBounceGeom{});
+            else go(b->bg);
         };
         // (from_initial here: every board of the rollout descends from the configured start position, so none holds more
         // pieces than it; otherwise 16 lanes, and a board with more than that is played by lane 0)
@@ -2457,9 +2701,10 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
                            b->stream, b->bg, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
                            seed, b->first_game, cap, b->d_steps, chunk, worklist, work_count, queue, (uint32_t)b->bounce_park);
     };
-    auto launch_pieces = [&](auto pmax_tag, auto block_tag) {
+    auto launch_pieces = [&](auto pmax_tag, auto block_tag, auto tail_tag) {
         constexpr int PMAX = decltype(pmax_tag)::value;
         constexpr int BLOCK = decltype(block_tag)::value;
+        constexpr bool TAIL = decltype(tail_tag)::value;
         const size_t tile = 0;  // (the landing masks live in registers; LDS only holds the parked boards)
         const uint32_t chunk0 = (uint32_t)b->bounce_flat_chunk;
         // Every ply costs a wave the same whatever the number of its lanes that still hold a game, so what counts is how
@@ -2476,7 +2721,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         if (tile > 48 * 1024) {  // beyond the default dynamic-LDS limit (gfx950 has 160 KB per CU)
             static bool raised = false;  // (per instantiation; the attribute belongs to the function, not the launch)
             if (!raised) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bounce_rollout_pieces<PMAX, BLOCK>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bounce_rollout_pieces<PMAX, BLOCK, TAIL, BounceGeom>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);
                 raised = true;
             }
@@ -2487,23 +2732,57 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         // (with the book a chunk is walked by the 64 lanes of the wave that draws it: a whole wave's worth, never more)
         const uint32_t chunk = book_depth ? 64u : chunk0;
         // the device-wide pool of parked boards: counters zeroed per launch (one small fill on the stream)
-        uint32_t* pool = b->bounce_pool && b->bounce_pieces_park > 0 && groups >= 2 && groups <= (unsigned)BGS_BOUNCE_POOL_GROUPS ? b->d_pool : nullptr;
+        uint32_t* pool = !TAIL && b->bounce_pool && b->bounce_pieces_park > 0 && groups >= 2 && groups <= (unsigned)BGS_BOUNCE_POOL_GROUPS ? b->d_pool : nullptr;
         if (pool) (void)hipMemsetAsync(pool, 0, sizeof(uint32_t) * (4 + 2 * (size_t)groups), b->stream);
+        TailArgs tail{};
+        if (TAIL) {
+            // the tail queue: counters in the (otherwise unused) pool region, "entry complete" words in the work list's region
+            // (one per game; they hold launch serials, so they are cleared only when something else has written there), the
+            // entries in the staging region (32 bytes a game; nothing else of this batch runs beside its rollout)
+            const BounceShape shape = bounce_shape(b->launches_in_flight);
+            (void)hipMemsetAsync(b->d_pool, 0, sizeof(uint32_t) * 8, b->stream);
+            if (b->tail_flags_dirty || b->tail_serial == 0xFFFFFFFFu) {
+                (void)hipMemsetAsync(b->d_worklist, 0, sizeof(uint32_t) * (size_t)b->n, b->stream);
+                b->tail_flags_dirty = 0;
+                b->tail_serial = 0;
+            }
+            tail.counters = b->d_pool;
+            tail.ready = b->d_worklist;
+            tail.entries = reinterpret_cast<uint32_t*>(b->d_staging);
+            tail.capacity = (uint32_t)b->n;
+            tail.serial = ++b->tail_serial;
+            tail.final_cap = final_cap;
+            tail.handoff_at = b->bounce_tail_handoff >= 0 ? (uint32_t)b->bounce_tail_handoff : (uint32_t)shape.handoff_at;
+            tail.limit = b->bounce_tail_limit > 0 ? (uint32_t)b->bounce_tail_limit : (uint32_t)shape.tail_waves;
+            tail.epoch_limit = b->bounce_epoch_limit >= 2 && b->bounce_epoch_limit < (int)kWaveEpochLimit ? (uint32_t)b->bounce_epoch_limit : kWaveEpochLimit;
+            tail.cold_limit = (uint32_t)b->bounce_memo_cold;
+            tail.bypass_plies = (uint32_t)b->bounce_memo_bypass;
+        }
         // (Tried, round 4: a kernel specialised on "exactly PMAX pieces" -- every "is there a piece k" test decided at compile
         // time.  18 % fewer static instructions, one basic block a phase, and 174 VGPRs; held to 128 it spills 43 and reads
         // 1.14 against 1.26 x 10^10 with 20 launches in flight.)
-        hipLaunchKernelGGL((k_bounce_rollout_pieces<PMAX, BLOCK>), dim3(groups),
-                           dim3(BLOCK), tile, b->stream, b->bg, b->d_planes, b->d_status, b->d_plies,
-                           reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps, chunk, queue,
-                           (uint32_t)b->bounce_pieces_park, pool, b->book_links,
-                           reinterpret_cast<const BookEntry*>(b->book_table), book_depth, b->book_n0);
+        auto go = [&](auto geo) {
+            hipLaunchKernelGGL((k_bounce_rollout_pieces<PMAX, BLOCK, TAIL, decltype(geo)>), dim3(groups),
+                               dim3(BLOCK), tile, b->stream, geo, b->d_planes, b->d_status, b->d_plies,
+                               reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps, chunk, queue,
+                               (uint32_t)b->bounce_pieces_park, pool, b->book_links,
+                               reinterpret_cast<const BookEntry*>(b->book_table), book_depth, b->book_n0, tail);
+        };
+        // (the default board: the compile-time geometry, see bounce_unit.h -- 256-thread workgroups only, the shape every plan uses)
+        if constexpr (PMAX == 12 && BLOCK == 256) {
+            if (b->bounce_static_geom && bounce_is_default(b->bg)) go(DefaultBounceGeom{});
+            else go(b->bg);
+        } else {
+            go(b->bg);
+        }
         // every board was written as the positions of its pieces: the value planes for all of them, at full lanes
         hipLaunchKernelGGL(k_bounce_positions_to_planes, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->n);
     };
     auto with_block = [&](auto pmax_tag) {
-        if (b->bounce_block >= 1024) launch_pieces(pmax_tag, std::integral_constant<int, 1024>{});
-        else if (b->bounce_block >= 512) launch_pieces(pmax_tag, std::integral_constant<int, 512>{});
-        else launch_pieces(pmax_tag, std::integral_constant<int, 256>{});
+        if (final_cap > cap) launch_pieces(pmax_tag, std::integral_constant<int, 256>{}, std::true_type{});
+        else if (b->bounce_block >= 1024) launch_pieces(pmax_tag, std::integral_constant<int, 1024>{}, std::false_type{});
+        else if (b->bounce_block >= 512) launch_pieces(pmax_tag, std::integral_constant<int, 512>{}, std::false_type{});
+        else launch_pieces(pmax_tag, std::integral_constant<int, 256>{}, std::false_type{});
     };
     // K3p: from the start position, no work list, at most 16 pieces
     if (group == 1 && b->bounce_flat && b->bounce_pieces && from_initial && !worklist && b->bg.piece_count >= 1 &&
@@ -2602,8 +2881,18 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
             const uint32_t pass_cap = (last || pass_cap_of[pass] > cap) ? cap : pass_cap_of[pass];
             const int group = pass_group_of[pass];
             if (pass == 0) {
+                // K3p with K3w as the second and last pass: ONE launch, the tail inside it ("the TAIL QUEUE"; experiment bounce_tail=0:
+                // the passes one after the other as until round 5)
+                const bool fused = b->bounce_tail && passes == 2 && group == 1 && pass_group_of[1] == 64 && piece_list && from_initial &&
+                                   b->bounce_block < 512 && b->bg.piece_count <= BGS_BOUNCE_MAX_PIECES && b->d_pool != nullptr &&
+                                   b->n < (int64_t)0xFFFFFFFFu && b->staging_bytes >= (size_t)b->n * kTailEntryWords * sizeof(uint32_t);
+                if (fused) {
+                    launch_rollout(b, seed, pass_cap, from_initial, group, b->rollout_wps, nullptr, nullptr, queues, cap);
+                    return;
+                }
                 launch_rollout(b, seed, pass_cap, from_initial, group, group == 1 ? b->rollout_wps : 8, nullptr, nullptr, queues);
             } else {
+                b->tail_flags_dirty = 1;   // (the work list's region is about to hold game indices)
                 // boards still running below the final cap after the previous pass -> this pass's list
                 hipLaunchKernelGGL(k_bounce_compact, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->d_status, b->d_plies,
                                    b->n, cap, list, counts + pass);

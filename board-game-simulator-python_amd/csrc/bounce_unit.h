@@ -30,6 +30,85 @@ struct BounceGeom {
     uint64_t piece_idx[4];   // index planes of the start position: bit c of plane p = bit p of the index of the piece on cell c
 };
 
+// ---- the DEFAULT board as a compile-time geometry (round 6).  The reference's own Bounce game -- 9 x 6, rows 1 and 7 hold the
+// pieces 1 2 3 3 2 1 (textual/bounce.py:66-78) -- is BASELINE config 4; what Geo<1, 6, 7, 4> is for Connect, this is for
+// Bounce: every mask a literal (round 5's K3p reloaded the geometry's masks, pointers and piece values from spilled scalar
+// registers 290 times an iteration: BounceGeom is 50 dwords of kernel argument), the piece count and every piece's value
+// constants (the segment loops unroll to their own length, the "is there a piece k" tests vanish).  The constants are
+// COMPUTED by the same rule as bgs_capi.hip's bounce_geom() builds the run-time record, and a batch is served by the static
+// instantiation exactly when its record equals default_bounce_geom() member for member (bounce_is_default()).
+constexpr BounceGeom make_bounce_geom(const int8_t (&cfg)[64], int h, int w) {
+    BounceGeom g{};
+    g.h = h;
+    g.w = w;
+    g.inv_w = (65536u + (uint32_t)w - 1u) / (uint32_t)w;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int c = y * w + x;
+            const uint64_t bit = 1ull << c;
+            g.all |= bit;
+            if (y == 0) g.goal_bottom |= bit;
+            else if (y == h - 1) g.goal_top |= bit;
+            else g.interior |= bit;
+            if (x > 0) g.not_col0 |= bit;
+            if (x < w - 1) g.not_collast |= bit;
+            for (int p = 0; p < 4; ++p)
+                if ((cfg[c] >> p) & 1) g.init[p] |= bit;
+        }
+    int k = 0;
+    for (int v = 1; v <= 15; ++v)
+        for (int c = 0; c < h * w; ++c)
+            if (cfg[c] == v && k < 16) {
+                g.piece_value[k] = (uint8_t)v;
+                g.piece_cell[k] = (uint8_t)c;
+                for (int p = 0; p < 4; ++p)
+                    if ((k >> p) & 1) g.piece_idx[p] |= 1ull << c;
+                ++k;
+            }
+    g.piece_count = (uint32_t)k;
+    return g;
+}
+constexpr BounceGeom default_bounce_geom() {
+    int8_t cfg[64] = {};
+    const int8_t row[6] = {1, 2, 3, 3, 2, 1};
+    for (int x = 0; x < 6; ++x) cfg[1 * 6 + x] = cfg[7 * 6 + x] = row[x];
+    return make_bounce_geom(cfg, 9, 6);
+}
+constexpr BounceGeom kDefaultBounce = default_bounce_geom();
+static_assert(kDefaultBounce.piece_count == 12 && kDefaultBounce.piece_value[0] == 1 && kDefaultBounce.piece_value[11] == 3 &&
+              kDefaultBounce.piece_cell[0] == 7 - 1 && kDefaultBounce.init_status == 0, "the default board: twelve pieces");
+
+#define BGS_DB(m) kDefaultBounce.m
+struct DefaultBounceGeom {
+    static constexpr int h = BGS_DB(h), w = BGS_DB(w);
+    static constexpr uint32_t inv_w = BGS_DB(inv_w);
+    static constexpr uint64_t all = BGS_DB(all), interior = BGS_DB(interior), goal_top = BGS_DB(goal_top), goal_bottom = BGS_DB(goal_bottom);
+    static constexpr uint64_t not_col0 = BGS_DB(not_col0), not_collast = BGS_DB(not_collast);
+    static constexpr uint64_t init[4] = {BGS_DB(init[0]), BGS_DB(init[1]), BGS_DB(init[2]), BGS_DB(init[3])};
+    static constexpr uint32_t init_status = 0;
+    static constexpr uint32_t piece_count = BGS_DB(piece_count);
+    static constexpr uint8_t piece_value[16] = {BGS_DB(piece_value[0]), BGS_DB(piece_value[1]), BGS_DB(piece_value[2]), BGS_DB(piece_value[3]),
+                                                BGS_DB(piece_value[4]), BGS_DB(piece_value[5]), BGS_DB(piece_value[6]), BGS_DB(piece_value[7]),
+                                                BGS_DB(piece_value[8]), BGS_DB(piece_value[9]), BGS_DB(piece_value[10]), BGS_DB(piece_value[11]),
+                                                BGS_DB(piece_value[12]), BGS_DB(piece_value[13]), BGS_DB(piece_value[14]), BGS_DB(piece_value[15])};
+    static constexpr uint8_t piece_cell[16] = {BGS_DB(piece_cell[0]), BGS_DB(piece_cell[1]), BGS_DB(piece_cell[2]), BGS_DB(piece_cell[3]),
+                                               BGS_DB(piece_cell[4]), BGS_DB(piece_cell[5]), BGS_DB(piece_cell[6]), BGS_DB(piece_cell[7]),
+                                               BGS_DB(piece_cell[8]), BGS_DB(piece_cell[9]), BGS_DB(piece_cell[10]), BGS_DB(piece_cell[11]),
+                                               BGS_DB(piece_cell[12]), BGS_DB(piece_cell[13]), BGS_DB(piece_cell[14]), BGS_DB(piece_cell[15])};
+    static constexpr uint64_t piece_idx[4] = {BGS_DB(piece_idx[0]), BGS_DB(piece_idx[1]), BGS_DB(piece_idx[2]), BGS_DB(piece_idx[3])};
+};
+#undef BGS_DB
+// the batch's record IS the default board's (every member the kernels read)
+inline bool bounce_is_default(const BounceGeom& g) {
+    const BounceGeom& d = kDefaultBounce;
+    bool same = g.h == d.h && g.w == d.w && g.inv_w == d.inv_w && g.all == d.all && g.interior == d.interior && g.goal_top == d.goal_top &&
+                g.goal_bottom == d.goal_bottom && g.not_col0 == d.not_col0 && g.not_collast == d.not_collast &&
+                g.init_status == d.init_status && g.piece_count == d.piece_count;
+    for (int k = 0; k < 4; ++k) same = same && g.init[k] == d.init[k] && g.piece_idx[k] == d.piece_idx[k];
+    for (int k = 0; k < 16; ++k) same = same && g.piece_value[k] == d.piece_value[k] && g.piece_cell[k] == d.piece_cell[k];
+    return same;
+}
+
 constexpr int kBouncePiecesPark = 32;       // K3p with the device-wide pool, 20 in flight / one launch at a time, x 10^9: round 4 32 / 40 / 48 / 56 / 63 = 11.8 / 12.2 / 11.9 / 11.8 / 3.0;
                                             // round 5 (opening book): 17.57 / 17.47 / 17.48 / 17.30 / 3.85 pipelined, 3.17 / 3.00 / 2.69 / 0.30 / 0.09 alone
 constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBoards (0 = every wave drains alone)
@@ -57,10 +136,12 @@ constexpr int kBounceMemoBypass = 28;       // ... for this many plies, then loo
 //   {64, 128}      4.77   7.54   8.02   8.21   8.36   8.43   8.50
 //   {128, 256}     4.88   8.88  12.24  13.98  14.11  14.29  14.44
 //   {160, 512}     3.65   6.89   9.55  12.17  15.72  15.79  15.86
-struct BounceShape { int tail_cap; int boards_per_wave; };
+// Round 6 (the tail inside the bulk launch): handoff_at = a workgroup's last wave hands its last boards to the tail queue at
+// this many or fewer; tail_waves = waves that may wait for tail entries at a time.
+struct BounceShape { int tail_cap; int boards_per_wave; int handoff_at; int tail_waves; };
 inline BounceShape bounce_shape(int launches_in_flight) {
-    if (launches_in_flight >= 12) return {160, 512};
-    if (launches_in_flight >= 4) return {128, 256};
-    return {80, 128};   // (one launch at a time, K3w on 8192 waves: caps of 64 / 80 / 96 / 112 / 128 read 2.78 / 2.86 / 2.80 / 2.69 / 2.62 x 10^9)
+    if (launches_in_flight >= 12) return {160, 512, 4, 512};
+    if (launches_in_flight >= 4) return {128, 256, 8, 1024};
+    return {80, 128, 16, 2048};   // (one launch at a time, K3w on 8192 waves: caps of 64 / 80 / 96 / 112 / 128 read 2.78 / 2.86 / 2.80 / 2.69 / 2.62 x 10^9)
 }
 

@@ -348,7 +348,7 @@ int device_facts(bgs_batch* b) {
     }
     b->launches_in_flight = 1;
     b->bounce_flat_waves = 0;
-    b->bounce_pieces_park = bgs::experiment("bounce_park") ? b->bounce_park : kBouncePiecesPark;
+    b->bounce_pieces_park = bgs::experiment("bounce_park") ? b->bounce_park : -1;   // (-1: what bounce_shape() says for the launches in flight)
     if (const char* env = bgs::experiment("bounce_pieces_park")) {
         const int v = atoi(env);
         if (v >= 0 && v <= 63) b->bounce_pieces_park = v;

@@ -37,7 +37,7 @@ struct bgs_batch {
     int bounce_flat_wps;     // waves per SIMD of a flat Bounce rollout launch (experiment bounce_flat_wps)
     int bounce_flat_waves;   // > 0: that many waves per launch instead (experiment bounce_flat_waves)
     int bounce_pool;         // K3p: the last wave of a workgroup parks its boards for other workgroups (experiment bounce_pool=0: off)
-    int bounce_pieces_park;  // K3p: a draining wave parks its boards at this many or fewer (0..63; experiment bounce_pieces_park, default: experiment bounce_park)
+    int bounce_pieces_park;  // K3p: a draining wave parks its boards at this many or fewer (0..63; experiment bounce_pieces_park, else experiment bounce_park, else -1 = bounce_shape().park)
     int bounce_park;         // flat rollout: a draining wave parks its boards for its workgroup at this many or fewer (0..32; experiment bounce_park)
     int bounce_flat_chunk;   // boards a wave draws from the work queue at a time (experiment bounce_chunk)
     int launches_in_flight;  // the caller's hint (bgs_set_launches_in_flight), 1 = one launch at a time: see bounce_shape()

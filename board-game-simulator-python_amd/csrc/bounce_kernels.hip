@@ -2008,6 +2008,16 @@ k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restric
                 search = false;
             }
         }
+        if (!TAIL && tail.entries) {
+            // the games the NEXT pass has to finish -- still running at this pass's cap, below the rollout's -- go on its work
+            // list here (round 6; until then a compaction kernel read every board's status behind this one: 44 us for a lone launch)
+            const bool more = has && !run && !pending && st == BGS_ST_RUNNING && plies < tail.final_cap;
+            const uint64_t who = __builtin_amdgcn_ballot_w64(more);
+            if (who) {
+                const uint32_t base = gbump(tail.counters, (uint32_t)__popcll(who), false);
+                if (more) tail.entries[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(who >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)who, 0u))] = game;
+            }
+        }
         if (has && !run && !pending) {
             const int64_t i = game;
             store_positions<PMAX>(planes, n, i, b);
@@ -2638,8 +2648,10 @@ void bounce_step_random(const bgs_batch* b, uint64_t seed, uint32_t count) {
 // One launch of the fused rollout: over the whole batch (worklist == nullptr) or over a work list.
 // group = lanes per board (1 or 8), wps = waves per SIMD the grid is sized for.
 // final_cap > cap: the bulk pass of a plan whose tail is K3w's code INSIDE the same launch (K3p only; see "the TAIL QUEUE")
+// next_list / next_count (K3p without the tail inside): where the bulk pass leaves the work list of the pass behind it
 static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool from_initial, int group, int wps,
-                           const uint32_t* worklist, const uint32_t* work_count, uint32_t* queue, uint32_t final_cap = 0) {
+                           const uint32_t* worklist, const uint32_t* work_count, uint32_t* queue, uint32_t final_cap = 0,
+                           uint32_t* next_list = nullptr, uint32_t* next_count = nullptr) {
     if (group == 64) {   // K3w: a work list of a few very long games, one wave each (a wave strides over the list)
         auto launch_wave = [&](auto pmax_tag) {
             constexpr int PMAX = decltype(pmax_tag)::value;
@@ -2732,7 +2744,8 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         // (with the book a chunk is walked by the 64 lanes of the wave that draws it: a whole wave's worth, never more)
         const uint32_t chunk = book_depth ? 64u : chunk0;
         // the device-wide pool of parked boards: counters zeroed per launch (one small fill on the stream)
-        uint32_t* pool = !TAIL && b->bounce_pool && b->bounce_pieces_park > 0 && groups >= 2 && groups <= (unsigned)BGS_BOUNCE_POOL_GROUPS ? b->d_pool : nullptr;
+        const int park_at = b->bounce_pieces_park >= 0 ? b->bounce_pieces_park : bounce_shape(b->launches_in_flight).park;
+        uint32_t* pool = !TAIL && b->bounce_pool && park_at > 0 && groups >= 2 && groups <= (unsigned)BGS_BOUNCE_POOL_GROUPS ? b->d_pool : nullptr;
         if (pool) (void)hipMemsetAsync(pool, 0, sizeof(uint32_t) * (4 + 2 * (size_t)groups), b->stream);
         TailArgs tail{};
         if (TAIL) {
@@ -2757,6 +2770,10 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
             tail.epoch_limit = b->bounce_epoch_limit >= 2 && b->bounce_epoch_limit < (int)kWaveEpochLimit ? (uint32_t)b->bounce_epoch_limit : kWaveEpochLimit;
             tail.cold_limit = (uint32_t)b->bounce_memo_cold;
             tail.bypass_plies = (uint32_t)b->bounce_memo_bypass;
+        } else if (next_list && next_count && final_cap > cap) {
+            tail.entries = next_list;
+            tail.counters = next_count;
+            tail.final_cap = final_cap;
         }
         // (Tried, round 4: a kernel specialised on "exactly PMAX pieces" -- every "is there a piece k" test decided at compile
         // time.  18 % fewer static instructions, one basic block a phase, and 174 VGPRs; held to 128 it spills 43 and reads
@@ -2765,7 +2782,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
             hipLaunchKernelGGL((k_bounce_rollout_pieces<PMAX, BLOCK, TAIL, decltype(geo)>), dim3(groups),
                                dim3(BLOCK), tile, b->stream, geo, b->d_planes, b->d_status, b->d_plies,
                                reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps, chunk, queue,
-                               (uint32_t)b->bounce_pieces_park, pool, b->book_links,
+                               (uint32_t)park_at, pool, b->book_links,
                                reinterpret_cast<const BookEntry*>(b->book_table), book_depth, b->book_n0, tail);
         };
         // (the default board: the compile-time geometry, see bounce_unit.h -- 256-thread workgroups only, the shape every plan uses)
@@ -2779,7 +2796,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         hipLaunchKernelGGL(k_bounce_positions_to_planes, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->bg, b->d_planes, b->n);
     };
     auto with_block = [&](auto pmax_tag) {
-        if (final_cap > cap) launch_pieces(pmax_tag, std::integral_constant<int, 256>{}, std::true_type{});
+        if (final_cap > cap && !next_list) launch_pieces(pmax_tag, std::integral_constant<int, 256>{}, std::true_type{});
         else if (b->bounce_block >= 1024) launch_pieces(pmax_tag, std::integral_constant<int, 1024>{}, std::false_type{});
         else if (b->bounce_block >= 512) launch_pieces(pmax_tag, std::integral_constant<int, 512>{}, std::false_type{});
         else launch_pieces(pmax_tag, std::integral_constant<int, 256>{}, std::false_type{});
@@ -2876,6 +2893,7 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
             launch_rollout(b, seed, cap, from_initial, lanes, lanes == 1 ? b->rollout_wps : 8, nullptr, nullptr, queues);
             return;
         }
+        bool listed = false;   // pass 0 left pass 1's work list behind
         for (int pass = 0; pass < passes; ++pass) {
             const bool last = pass + 1 == passes;
             const uint32_t pass_cap = (last || pass_cap_of[pass] > cap) ? cap : pass_cap_of[pass];
@@ -2890,10 +2908,16 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
                     launch_rollout(b, seed, pass_cap, from_initial, group, b->rollout_wps, nullptr, nullptr, queues, cap);
                     return;
                 }
-                launch_rollout(b, seed, pass_cap, from_initial, group, group == 1 ? b->rollout_wps : 8, nullptr, nullptr, queues);
+                // (K3p writes the next pass's work list itself: no compaction kernel behind it)
+                listed = group == 1 && piece_list && from_initial && b->bg.piece_count <= BGS_BOUNCE_MAX_PIECES && b->n < (int64_t)0xFFFFFFFFu &&
+                         pass_cap < cap;
+                if (listed) b->tail_flags_dirty = 1;
+                launch_rollout(b, seed, pass_cap, from_initial, group, group == 1 ? b->rollout_wps : 8, nullptr, nullptr, queues,
+                               listed ? cap : 0u, listed ? list : nullptr, listed ? counts + 1 : nullptr);
             } else {
                 b->tail_flags_dirty = 1;   // (the work list's region is about to hold game indices)
                 // boards still running below the final cap after the previous pass -> this pass's list
+                if (!(pass == 1 && listed))
                 hipLaunchKernelGGL(k_bounce_compact, dim3(grid_for(b->n)), dim3(BGS_BLOCK), 0, b->stream, b->d_status, b->d_plies,
                                    b->n, cap, list, counts + pass);
                 launch_rollout(b, seed, pass_cap, group == 64 && from_initial, group, 0, list, counts + pass, queues + pass);

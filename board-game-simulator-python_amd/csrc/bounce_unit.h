@@ -109,8 +109,10 @@ inline bool bounce_is_default(const BounceGeom& g) {
     return same;
 }
 
-constexpr int kBouncePiecesPark = 32;       // K3p with the device-wide pool, 20 in flight / one launch at a time, x 10^9: round 4 32 / 40 / 48 / 56 / 63 = 11.8 / 12.2 / 11.9 / 11.8 / 3.0;
-                                            // round 5 (opening book): 17.57 / 17.47 / 17.48 / 17.30 / 3.85 pipelined, 3.17 / 3.00 / 2.69 / 0.30 / 0.09 alone
+// K3p's park threshold is part of the launch shape since round 6 (BounceShape::park): with the device-wide pool, 20 in flight /
+// one launch at a time, x 10^9: round 4 32 / 40 / 48 / 56 / 63 = 11.8 / 12.2 / 11.9 / 11.8 / 3.0; round 5 (opening book): 17.57 /
+// 17.47 / 17.48 / 17.30 / 3.85 pipelined, 3.17 / 3.00 / 2.69 / 0.30 / 0.09 alone; round 6 (compile-time geometry): 8 / 16 / 32 =
+// 20.4 / 21.6 / 22.8 with 20 in flight, 16.9 / 18.7 / 20.3 with 8 (16 hardware queues), 5.10 / 5.07 / 4.84 alone (1024 waves)
 constexpr int kBouncePark = 32;             // flat Bounce rollout: see ParkedBoards (0 = every wave drains alone)
 // defaults that change what a launch executes (here and not in bgs_capi.hip so that the unit's id moves with them)
 constexpr int kBounceBlock = 256;           // threads a workgroup of the flat / piece-list rollouts
@@ -138,10 +140,13 @@ constexpr int kBounceMemoBypass = 28;       // ... for this many plies, then loo
 //   {160, 512}     3.65   6.89   9.55  12.17  15.72  15.79  15.86
 // Round 6 (the tail inside the bulk launch): handoff_at = a workgroup's last wave hands its last boards to the tail queue at
 // this many or fewer; tail_waves = waves that may wait for tail entries at a time.
-struct BounceShape { int tail_cap; int boards_per_wave; int handoff_at; int tail_waves; };
+// Round 6 (compile-time geometry, the bulk pass writes the tail's work list itself): alone, 2^18 boards, ms a launch --
+//   waves 768 / 1024 / 1280 / 1536 / 2048 / 3072 at park 16: 1.60 / 1.48 / 1.54 / 1.54 / 1.62 / 1.90; caps 64 / 80 / 96 / 112 / 128 /
+//   160 (1536 waves): 1.66 / 1.58 / 1.61 / 1.66 / 1.73 / 1.83; park 4 / 8 / 16 / 32 (1024 waves): 1.454 / 1.448 / 1.456 / 1.524.
+struct BounceShape { int tail_cap; int boards_per_wave; int handoff_at; int tail_waves; int park; };
 inline BounceShape bounce_shape(int launches_in_flight) {
-    if (launches_in_flight >= 12) return {160, 512, 4, 512};
-    if (launches_in_flight >= 4) return {128, 256, 8, 1024};
-    return {80, 128, 16, 2048};   // (one launch at a time, K3w on 8192 waves: caps of 64 / 80 / 96 / 112 / 128 read 2.78 / 2.86 / 2.80 / 2.69 / 2.62 x 10^9)
+    if (launches_in_flight >= 12) return {160, 512, 4, 512, 32};
+    if (launches_in_flight >= 4) return {128, 256, 8, 1024, 32};
+    return {80, 256, 16, 2048, 8};   // (one launch at a time, K3w on 8192 waves: caps of 64 / 80 / 96 / 112 / 128 read 2.78 / 2.86 / 2.80 / 2.69 / 2.62 x 10^9)
 }
 

@@ -28,6 +28,7 @@ thread_local char g_error[512] = "";
 }
 
 namespace bgs {
+#ifdef BGS_TEST_HOOKS
 const char* experiment(const char* name) {
     const char* all = getenv("BGS_EXPERIMENT");
     if (!all || !name) return nullptr;
@@ -49,6 +50,7 @@ const char* experiment(const char* name) {
     }
     return nullptr;
 }
+#endif
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -326,6 +328,10 @@ int device_facts(bgs_batch* b) {
     if (const char* env = bgs::experiment("bounce_block")) b->bounce_block = atoi(env);
     b->bounce_pool = 1;
     if (const char* env = bgs::experiment("bounce_pool")) b->bounce_pool = atoi(env) != 0;
+    b->bounce_wave_grid = 0;
+    if (const char* env = bgs::experiment("bounce_wave_grid")) b->bounce_wave_grid = atoi(env);
+    b->transition_wave = 1;
+    if (const char* env = bgs::experiment("transition_wave")) b->transition_wave = env[0] != '0';
     b->bounce_static_geom = 1;
     if (const char* env = bgs::experiment("bounce_static_geom")) b->bounce_static_geom = atoi(env) != 0;
     b->bounce_tail = 0;   // (round 6: built, measured, off -- see DESIGN 5.3)

@@ -48,6 +48,8 @@ struct bgs_batch {
     int bounce_passes;       // multi-pass Bounce rollout: number of passes, their ply caps and lanes per board
     uint32_t bounce_pass_cap[BGS_BOUNCE_MAX_PASSES];
     int bounce_pass_group[BGS_BOUNCE_MAX_PASSES];
+    int bounce_wave_grid;    // > 0: one-wave workgroups of a K3w launch (experiment bounce_wave_grid; 0: 8192)
+    int transition_wave;     // 1: the object API's one-board transition runs on one wave, a piece per lane (experiment transition_wave=0: thread per board)
     int bounce_static_geom;  // 1: the default board is played by the kernels instantiated on its compile-time geometry (experiment bounce_static_geom=0: the run-time record)
     int bounce_tail;         // 1: K3p's launch finishes the games beyond its ply cap itself, its idle waves in K3w's role (experiment bounce_tail=0: separate passes)
     int bounce_tail_handoff; // >= 0: a workgroup's last wave hands its boards to the tail queue at this many or fewer (experiment; -1: bounce_shape())
@@ -94,7 +96,16 @@ namespace bgs {
 // live behind ONE environment variable: BGS_EXPERIMENT="name=value;name=value" (names as in tools/README.md; a value may
 // hold commas and colons).  Returns the value of `name` (valid until the calling thread's next call) or NULL.  What a user
 // of the library may want to set has a variable of its own and is listed in INTEGRATION.md section G.
+// The PRODUCT library (libbgs.so) is built without them (round 6): experiment() is an inline nullptr there, the names of
+// the switches do not exist in the binary, the fault-injection code is not compiled, and BGS_EXPERIMENT is never read.  The
+// TEST build (libbgs_test.so: the host-side units compiled with -DBGS_TEST_HOOKS, linked with the SAME kernel objects -- same
+// kernel unit ids) is what tests/ and tools/ load when they force a kernel family or inject a fault (tests/conftest.py,
+// tests/knobs.py).  The kernel translation units never call experiment(): every switch reaches them as a field of the batch.
+#ifdef BGS_TEST_HOOKS
 const char* experiment(const char* name);
+#else
+inline const char* experiment(const char*) { return nullptr; }
+#endif
 
 // ---- Connect (connect_kernels.hip) ----
 void connect_reset(const bgs_batch* b);

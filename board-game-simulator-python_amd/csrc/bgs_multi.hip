@@ -664,10 +664,12 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
     NEED(b->n == g->n, "batch of %lld games, the gather was made for %lld per rank", (long long)b->n, (long long)g->n);
     NEED(g->rank != 0 || host_reward != nullptr, "rank 0 needs the host array int8[world * n][2]");
     NEED(max_plies >= 0, "max_plies must be >= 0");
-    // fault injection for the tests (BGS_GATHER_INJECT_FAILURE=<step>): that step "cannot be enqueued" after its ticket
-    // was claimed -- the path a device error would take
+#ifdef BGS_TEST_HOOKS
+    // fault injection (TEST build only; experiment gather_inject_failure=<step>): that step "cannot be enqueued" after its
+    // ticket was claimed -- the path a device error would take
     static const long long inject = bgs::experiment("gather_inject_failure") ? atoll(bgs::experiment("gather_inject_failure")) : -1;
     static const int inject_rank = bgs::experiment("gather_inject_rank") ? atoi(bgs::experiment("gather_inject_rank")) : -1;  // -1: every rank
+#endif
     if (g->world == 1) return bgs_sink_rollout(g->sink, b, seed, max_plies, flags, host_reward, ticket);
     HIP_TRY(hipSetDevice(g->device));
     int64_t t;
@@ -725,10 +727,12 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
     }
     // From here on the step is submitted whatever happens -- a step that could not be enqueued travels through the
     // communication thread with its flag down, so that rank 0's sink ticket is published in order and nothing stalls.
+#ifdef BGS_TEST_HOOKS
     if (ok && t == inject && (inject_rank < 0 || inject_rank == g->rank)) {
         ok = false;
         rc = fail(BGS_ERR_RUNTIME, "injected failure at step %lld (BGS_GATHER_INJECT_FAILURE)", (long long)t);
     }
+#endif
     if (ok && (rc = bgs::rollout_with_codes(b, seed, max_plies, flags, codes_out)) != BGS_OK) ok = false;
     if (ok && (he = hipEventRecord(g->rolled[slot], b->stream)) != hipSuccess) ok = false;
     if (!ok && rc == BGS_OK) rc = fail(BGS_ERR_RUNTIME, "the step could not be enqueued: %s", hipGetErrorString(he));

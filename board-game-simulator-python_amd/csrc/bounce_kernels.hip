@@ -2658,8 +2658,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
             // one-wave workgroups; a wave without a list entry leaves at once, so the grid is sized for the longest list the
             // automatic plan produces (5 % of 2^18 boards after a short bulk pass: one or two entries a wave; 2048 / 4096 /
             // 8192 / 16384 waves read 2.39 / 2.61 / 2.78 / 2.83 x 10^9 one launch at a time, and the same with 4 and 20 in flight)
-            static const int grid_env = [] { const char* e = bgs::experiment("bounce_wave_grid"); return e ? atoi(e) : 0; }();
-            const unsigned wave_grid = grid_env > 0 ? (unsigned)grid_env : 8192u;
+            const unsigned wave_grid = b->bounce_wave_grid > 0 ? (unsigned)b->bounce_wave_grid : 8192u;
             auto go = [&](auto geo) {
                 hipLaunchKernelGGL((k_bounce_rollout_wave<PMAX, decltype(geo)>), dim3(wave_grid), dim3(BGS_WAVE), 0,
                                    b->stream, geo, b->d_planes, b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n,
@@ -3064,7 +3063,7 @@ void bounce_step_actions(const bgs_batch* b, const int32_t* d_moves, int32_t* d_
 void bounce_transition(const bgs_batch* b, const int32_t* d_moves, int32_t* d_status_out, int8_t* d_grid, int8_t* d_player,
                        int8_t* d_winner, int32_t* d_plies, uint64_t* d_targets, int8_t* d_reward_out, uint32_t* d_done,
                        uint32_t ticket) {
-    static const bool wave_wanted = [] { const char* e = bgs::experiment("transition_wave"); return !(e && e[0] == '0'); }();
+    const bool wave_wanted = b->transition_wave != 0;
     if (b->n == 1 && wave_wanted && b->bg.h * b->bg.w <= 64) {   // the object API's engines: one board, one wave, a piece per lane
         hipLaunchKernelGGL((k_bounce_transition_wave<BGS_BOUNCE_MAX_PIECES>), dim3(1), dim3(BGS_WAVE), 0, b->stream, b->bg, b->d_planes,
                            b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), d_moves, d_status_out, b->d_steps, d_grid,

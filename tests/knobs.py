@@ -10,6 +10,22 @@ that force a kernel family or inject a fault:
 import os
 from collections.abc import MutableMapping
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRODUCT_LIB = os.path.join(ROOT, "board-game-simulator-python_amd", "libbgs.so")
+TEST_LIB = os.path.join(ROOT, "board-game-simulator-python_amd", "libbgs_test.so")
+# BGS_EXPERIMENT only means something to the TEST build of the library (csrc/Makefile: libbgs_test.so); a script that imports
+# this module before the package (tools/*.py) gets it unless it chose a library itself
+if "BGS_LIBRARY" not in os.environ and os.path.exists(TEST_LIB):
+    os.environ["BGS_LIBRARY"] = TEST_LIB
+
+
+def product_env(**extra) -> dict:
+    """The environment of a child process that must run on the PRODUCT library (bench.py, smoke): no BGS_LIBRARY, no
+    BGS_EXPERIMENT."""
+    env = {k: v for k, v in os.environ.items() if k not in ("BGS_LIBRARY", "BGS_EXPERIMENT")}
+    env.update(extra)
+    return env
+
 
 def experiment(**settings) -> str:
     """The BGS_EXPERIMENT string of `settings` (values may hold commas and colons, not semicolons)."""

@@ -4,6 +4,7 @@ drop-in package (JSON, value semantics, argument validation); loud failure witho
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -17,14 +18,18 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(bgs_[a-z_]+)\s*\(", text)))
 
 
+LIBS = [os.path.join(ROOT, "board-game-simulator-python_amd", name) for name in ("libbgs.so", "libbgs_test.so")]
+
+
 def test_library_exports_every_declared_symbol():
     from simulator.game import _abi
 
     names = declared_symbols()
     assert len(names) >= 30
-    handle = ctypes.CDLL(_abi.LIB_PATH)
-    for name in names:
-        assert hasattr(handle, name), f"libbgs.so does not export {name}"
+    for path in LIBS:
+        handle = ctypes.CDLL(path)
+        for name in names:
+            assert hasattr(handle, name), f"{os.path.basename(path)} does not export {name}"
     # the Python binding table covers exactly the header
     assert sorted(_abi.SIGNATURES) == names
     assert _abi.lib().bgs_version() >= 100
@@ -37,13 +42,32 @@ def test_dynamic_symbol_table_is_the_header():
 
     from simulator.game import _abi
 
-    out = subprocess.check_output(["nm", "-D", "--defined-only", _abi.LIB_PATH], text=True)
-    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
-    assert exported == declared_symbols()
+    for path in LIBS:   # the product library and the test build alike
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+        assert exported == declared_symbols(), path
     with open(os.path.join(ROOT, "include", "bgs.h")) as fh:
         header = fh.read()
     # the one number the documents quote is derived from the header (DESIGN.md says "see include/bgs.h", not a count)
     assert len(exported) == len(re.findall(r"^BGS_API ", header, flags=re.M))
+
+
+def test_product_library_is_lean():
+    """Round-5 review: the A/B switches and the fault injection do not ship.  The product library has no BGS_EXPERIMENT parser
+    (the variable's name, the switches' names and the injection messages are not in the binary), the test build has; both
+    are linked from the SAME kernel objects: the kernel unit ids agree."""
+    import subprocess
+
+    product, test = (subprocess.check_output(["strings", path], text=True) for path in LIBS)
+    for word in ("inject", "bounce_plan", "BGS_EXPERIMENT", "rollout_opening", "bounce_tail", "gather_comm_alone", "drain_serial_sync"):
+        assert word.lower() not in product.lower(), word
+        assert word.lower() in test.lower(), word
+    ids = []
+    for path in LIBS:
+        code = ("import ctypes, sys; l = ctypes.CDLL(sys.argv[1]); l.bgs_kernel_unit_id.restype = ctypes.c_char_p; "
+                "l.bgs_build_id.restype = ctypes.c_char_p; print(l.bgs_build_id().decode(), *[l.bgs_kernel_unit_id(u).decode() for u in range(3)])")
+        ids.append(subprocess.check_output([sys.executable, "-c", code, path], text=True).split())
+    assert ids[0] == ids[1] and len(ids[0]) == 4
 
 
 def test_header_is_plain_c():

@@ -31,3 +31,19 @@ def test_c_host_program(tmp_path):
     steps = orc.rollout(0x0123456789ABCDEF, first_game=1000)
     want = [n, steps, int((orc.winner == 0).sum()), int((orc.winner == 1).sum()), int((orc.winner == 2).sum()), 0]
     assert got == want
+
+
+def test_smoke_on_the_product_library():
+    """The suite itself runs on the TEST build (tests/conftest.py); what ships is libbgs.so.  __graft_entry__.smoke() -- Connect4
+    and Bounce rollouts, the reward sink, the native loop, each against the oracle -- in a child process on the PRODUCT library,
+    with a BGS_EXPERIMENT in the environment that the product must not even read."""
+    import sys
+
+    from tests.knobs import product_env
+
+    code = ("import __graft_entry__ as g; g.smoke(); import sys; sys.path.insert(0, 'board-game-simulator-python_amd'); "
+            "from simulator.game import _abi; print('LIB', _abi.LIB_PATH)")
+    proc = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=product_env(BGS_EXPERIMENT="force_generic=1;bounce_plan=single"),
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert "LIB" in proc.stdout and proc.stdout.strip().splitlines()[-1].endswith("libbgs.so")

@@ -12,6 +12,8 @@ import sys
 import numpy as np
 import pytest
 
+from tests.knobs import product_env
+
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -700,7 +702,7 @@ def test_bench_multi_rank_rehearsal(gather, ranks):
     port = _free_port()
     procs = []
     for rank in range(ranks):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(ranks), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+        env = product_env( RANK=str(rank), WORLD_SIZE=str(ranks), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", BGS_RCCL_LIB=build_fake_rccl())
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "25", "--warmup", "2", "--batch",
                str(1 << 16), "--no-cpu-baseline", "--gather", gather, "--host-threads", "2"]
@@ -734,7 +736,7 @@ def test_bench_starts_its_own_ranks():
     it touches the GPU itself), relays rank 0's line and exits 0.  (gloo: the ranks share this box's one GPU.)"""
     from tests.test_gpu_gather_peers import build_fake_rccl
 
-    env = dict(os.environ, BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", BGS_RCCL_LIB=build_fake_rccl())
+    env = product_env( BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", BGS_RCCL_LIB=build_fake_rccl())
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "20", "--warmup", "2",
@@ -759,7 +761,7 @@ def test_bench_fails_loudly_when_the_gather_dies():
     is still printed, with what the shared array measured and the gather's error, and the exit code is NOT 0."""
     from tests.test_gpu_gather_peers import build_fake_rccl
 
-    env = dict(os.environ, BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", BGS_RCCL_LIB=build_fake_rccl(), BGS_FAKE_RCCL_MUTE_AFTER="1:3",
+    env = product_env( BGS_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", BGS_RCCL_LIB=build_fake_rccl(), BGS_FAKE_RCCL_MUTE_AFTER="1:3",
                BGS_BENCH_GATHER_TIMEOUT="25", BGS_FAKE_RCCL_TIMEOUT_MS="120000")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -780,7 +782,7 @@ def test_bench_sharded_path_with_one_rank_over_rccl(gather):
     run of them: `rccl` = the in-library gather (bgs_gather_*: ncclCommInitRank, communication thread, send / receive
     group per step, rank 0's sink), `shm` = the shared host array with the consumer hand-shake (RCCL then only carries
     the barriers and the step count); verified host array."""
-    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+    env = product_env( RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                BGS_FORCE_DIST="1")
     env.pop("BGS_DIST_BACKEND", None)
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "3",
@@ -798,7 +800,7 @@ def test_bench_single_gpu_line():
     """The default hand-over on one GPU at a small batch: contract fields, host rewards verified against the oracle,
     the other BASELINE configs measured and parity-checked by their child processes."""
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--batch",
-                           str(1 << 16)], capture_output=True, text=True, timeout=900)
+                           str(1 << 16)], env=product_env(), capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-2000:]
     d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["rewards_to_host"] is True and d["cpu_baseline"]["parity_with_host_rewards"] is True

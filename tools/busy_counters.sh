@@ -8,6 +8,8 @@
 # usage (GPU box): bash tools/busy_counters.sh ; then python3 tools/busy_counters.py -> profiles/r05_valu_busy.json
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+# BGS_EXPERIMENT only reaches the TEST build of the library (csrc/Makefile: libbgs_test.so, same kernel objects); without it the product library is measured
+if [ -n "${BGS_EXPERIMENT:-}" ]; then export BGS_LIBRARY=${BGS_LIBRARY:-$R/board-game-simulator-python_amd/libbgs_test.so}; fi
 cd /tmp && export TMPDIR=/tmp
 PMC="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE GRBM_COUNT"
 pass() {  # pass <tag> <program> <args...>   (environment of the caller); skipped when the case's kernel unit did not move

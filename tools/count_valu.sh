@@ -4,6 +4,8 @@
 set -u
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+# BGS_EXPERIMENT only reaches the TEST build of the library (csrc/Makefile: libbgs_test.so, same kernel objects); without it the product library is measured
+if [ -n "${BGS_EXPERIMENT:-}" ]; then export BGS_LIBRARY=${BGS_LIBRARY:-$R/board-game-simulator-python_amd/libbgs_test.so}; fi
 here=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/valu_$tag

@@ -6,6 +6,8 @@ set -u
 # a pass that fails (rocprofv3 itself occasionally aborts at start-up) is reported and skipped, the others still run
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+# BGS_EXPERIMENT only reaches the TEST build of the library (csrc/Makefile: libbgs_test.so, same kernel objects); without it the product library is measured
+if [ -n "${BGS_EXPERIMENT:-}" ]; then export BGS_LIBRARY=${BGS_LIBRARY:-$R/board-game-simulator-python_amd/libbgs_test.so}; fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_${tag}_stats $R/gpurun_out/prof_${tag}_sq $R/gpurun_out/prof_${tag}_fetch $R/gpurun_out/prof_${tag}_write
 prog=$1; shift

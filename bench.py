@@ -390,8 +390,10 @@ def valu_issue_block(counters, why_not, seconds_per_launch, build):
 # ------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs 3 and 4: `bench.py --only NAME` (a child process of the main run) prints one JSON object
 # ------------------------------------------------------------------------------------------------------------------
-def run_other_config(name: str, steps: int) -> int:
+def run_other_config(name: str, steps: int, depth_override: int = 0) -> int:
     label, n, depth, max_plies, bytes_per_step, stem, kernel = OTHER_CONFIGS[name]
+    if depth_override > 0:
+        depth = depth_override
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(32, max(4, 2 * depth))))  # HIP maps a process's streams onto 4 hardware queues by default
     import numpy as np
     import torch
@@ -510,6 +512,24 @@ def other_configs():
                 "error": f"exit code {proc.returncode}: {proc.stderr.strip()[-400:]}"}
         except (subprocess.TimeoutExpired, ValueError) as exc:
             results[name] = {"error": str(exc)}
+    # Bounce with EIGHT batches in flight -- what a caller who never touches GPU_MAX_HW_QUEUES gets (HIP's default: four
+    # hardware queues, two streams to a queue) and the same with sixteen queues; each a child process of its own (the runtime
+    # reads the variable once, when it starts)
+    if "error" not in results.get("bounce_default", {"error": 1}):
+        eight = {}
+        for queues in ("4", "16"):
+            cmd = [sys.executable, os.path.abspath(__file__), "--only", "bounce_default", "--only-depth", "8", "--steps", "80"]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BGS_FORCE_DIST", "BGS_ROLLOUT_WPS")}
+            env["GPU_MAX_HW_QUEUES"] = queues
+            try:
+                proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+                lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+                d = json.loads(lines[-1])
+                eight[f"hardware_queues_{queues}"] = {"value": d["value"], "device_resident": d["device_resident"], "ms_per_step": d["ms_per_step"],
+                                                      "parity_with_oracle": d["parity_with_oracle"]}
+            except (subprocess.TimeoutExpired, ValueError, IndexError, KeyError) as exc:
+                eight[f"hardware_queues_{queues}"] = {"error": str(exc)}
+        results["bounce_default"]["eight_in_flight"] = eight
     return results
 
 
@@ -612,13 +632,14 @@ def main() -> int:
                     "default, a philox word per four plies.  per-ply: the strict contract, a word per ply.  Whichever is chosen, a "
                     "one-GPU run also times the OTHER contract on the same batches (`rng_other` block: its value and the ratio), so "
                     "the cost of the strict contract is on the line")
+    ap.add_argument("--only-depth", type=int, default=0, help="with --only: batches in flight instead of the config's own")
     ap.add_argument("--only", choices=sorted(OTHER_CONFIGS), help="measure one of the other BASELINE configs and print its JSON object")
     args = ap.parse_args()
     if args.gather not in ("shm", "rccl", "both"):
         print("bench.py: --gather must be shm, rccl or both", file=sys.stderr)
         return 2
     if args.only:
-        return run_other_config(args.only, max(2, args.steps))
+        return run_other_config(args.only, max(2, args.steps), args.only_depth)
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         print("bench.py: need --gpus >= 1, --steps >= 1, --warmup >= 0", file=sys.stderr)
         return 2

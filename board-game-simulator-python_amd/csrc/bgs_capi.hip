@@ -334,8 +334,10 @@ int device_facts(bgs_batch* b) {
     if (const char* env = bgs::experiment("transition_wave")) b->transition_wave = env[0] != '0';
     b->bounce_static_geom = 1;
     if (const char* env = bgs::experiment("bounce_static_geom")) b->bounce_static_geom = atoi(env) != 0;
-    b->bounce_tail = 0;   // (round 6: built, measured, off -- see DESIGN 5.3)
+    b->bounce_tail = 0;   // (round 6: built twice, measured, slower than the pass behind the bulk kernel both times: off; see bounce_kernels.hip)
     if (const char* env = bgs::experiment("bounce_tail")) b->bounce_tail = atoi(env) != 0;
+    b->tail_stream = nullptr;
+    b->tail_fork = b->tail_join = nullptr;
     b->bounce_tail_handoff = -1;
     if (const char* env = bgs::experiment("bounce_tail_handoff")) b->bounce_tail_handoff = atoi(env);
     b->bounce_tail_limit = 0;
@@ -824,6 +826,12 @@ int bgs_destroy(bgs_batch* b) {
         if (b->pinned_done[k]) (void)hipEventDestroy(b->pinned_done[k]);
     }
     if (b->order_event) (void)hipEventDestroy(b->order_event);
+    if (b->tail_stream) {   // (the Bounce rollout's tail kernel: joined into b->stream, which was synchronised above)
+        (void)hipStreamSynchronize(b->tail_stream);
+        (void)hipEventDestroy(b->tail_fork);
+        (void)hipEventDestroy(b->tail_join);
+        (void)hipStreamDestroy(b->tail_stream);
+    }
     delete b;
     return BGS_OK;
 }

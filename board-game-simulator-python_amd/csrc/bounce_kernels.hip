@@ -1582,17 +1582,26 @@ __device__ __forceinline__ void wave_play_game(const GEO& g, WaveMemo<PMAX>& mem
 }
 
 
-// ---- the TAIL QUEUE (round 6): K3p's waves hand the games that outlive the bulk pass to K3w's code IN THE SAME LAUNCH.
+// ---- the TAIL QUEUE (round 6): the games that outlive the bulk pass are finished WHILE the bulk pass runs.
 // Until round 5 a rollout was K3p to a ply cap -> positions to planes -> a compaction of the boards still running -> K3w,
 // one after the other on the batch's stream: a lone launch spent a third of its time in a nearly empty K3w, which could
-// only start when K3p's last wave had left.  Now a K3p wave that has nothing left to do in the bulk loop does not leave the
-// kernel: it turns into a K3w wave (one game per wave, the memo in the LDS its chunk no longer needs) and takes games from a
-// device-wide queue that the waves still in the bulk loop feed -- a game that reaches the bulk cap goes there at once, and so
-// do the last boards of a workgroup's last wave (`handoff_at`: K3p pays 2 400 instructions an iteration whatever its lanes
-// hold; at a handful of boards K3w's 400 a ply are cheaper, and its ply is five times shorter).  Nobody in the bulk loop
-// ever waits for the tail; a tail wave waits for entries only while a bulk wave that could still produce one exists.
-//   counters  tq[0] entries allocated   tq[1] entries claimed   tq[2] waves that have left the bulk loop   tq[3] tail waves admitted
-//             tq[4] workgroups of the launch that have started
+// only start when K3p's last wave had left -- although the games it waits for (the one that never ends: 4 000 plies along the
+// memo's links; the longest that wanders) mostly crossed the bulk cap in K3p's first third.  Now K3p hands a game that
+// reaches the bulk cap to a device-wide queue at once (and, `handoff_at`, the last boards of a workgroup's last wave), and a
+// second kernel -- k_bounce_tail: K3w's code on a few hundred one-wave workgroups, launched beside K3p on a stream of the
+// batch's own -- takes them from there as they come.  Nobody in the bulk kernel ever waits for the tail; the tail's waves
+// wait for entries only while the bulk kernel runs (its last wave's departure is the end signal), and they are few enough
+// (one a SIMD) that the bulk kernel's workgroups always find room beside them.  If the two kernels do not overlap (both
+// streams on one hardware queue) the tail simply runs behind the bulk pass, as the separate pass did.
+// A first form of this (the bulk kernel's own waves turning into K3w waves when they left the bulk loop) was built and
+// measured slower than the separate pass: no wave leaves the bulk loop before the queue has run dry, i.e. exactly when the
+// tail's games have long been waiting, and the merged kernel needed 129 VGPRs and 50 KB of LDS.
+// MEASURED (round 6, default board, 2^18 games, one launch at a time; the pass behind the bulk kernel: 1.44 ms): this form
+// 1.72 ms at its best (512 tail waves; 256: 2.27, 1024: 1.77-2.0, 2048: 2.6-2.8; hand-over thresholds 0 / 8 / 16 / 32 within 3 %
+// of each other), the first form 1.79-2.03 ms.  The waiting waves' polls and the tail's plies compete with the bulk waves for
+// the same SIMDs while the bulk pass is the part that binds; the experiment switch bounce_tail=1 (test build) keeps the code
+// reachable and its parity test running, no automatic plan selects it.
+//   counters  tq[0] entries allocated   tq[1] tickets drawn   tq[2] bulk waves that have left
 //   ready[e]  = the launch's serial once entry e is complete (written last, release at agent scope)
 //   entry e   = 8 dwords: positions (4), game, plies, -, -
 constexpr uint32_t kTailEntryWords = 8;
@@ -1686,16 +1695,6 @@ struct TailArgs {
     uint32_t epoch_limit, cold_limit, bypass_plies;   // K3w's memo policy
 };
 
-template <int PMAX, bool TAIL>
-union WaveRegion {   // per wave: the chunk's book lines while it is in the bulk loop, K3w's memo once it has left it
-    uint4 opened[4][BGS_WAVE];
-    WaveMemo<PMAX> memo;
-};
-template <int PMAX>
-union WaveRegion<PMAX, false> {
-    uint4 opened[4][BGS_WAVE];
-};
-
 template <int PMAX, int BLOCK, bool TAIL, class GEO>
 __global__ void __launch_bounds__(BLOCK) BGS_K3P_OCCUPANCY
 k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
@@ -1710,7 +1709,7 @@ k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restric
     // -- and parked here, a 64-byte line a game; a lane that takes a game reads its line.  (Walked where the lane takes the
     // game, the walk ran in almost every iteration -- some lane of 64 always finishes -- for two or three lanes: ~100 VALU
     // an iteration, 4 % of a ply.)
-    __shared__ WaveRegion<PMAX, TAIL> wave_lds[BLOCK / BGS_WAVE];
+    __shared__ uint4 opened_lds[BLOCK / BGS_WAVE][4][BGS_WAVE];
     if (book_depth >= 2u)
         for (uint32_t i = threadIdx.x; i < kBookLdsLinks; i += BLOCK) book_lds[i] = book_links[i];
     Lands<PMAX> lands;   // (registers; valid from a ply's search to its move)
@@ -1722,7 +1721,6 @@ k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restric
         parked.head[threadIdx.x] = 0u;
     }
     if (threadIdx.x == 0) parked.active = WAVES;
-    if (TAIL && threadIdx.x == 0) (void)__hip_atomic_fetch_add(tail.counters + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // workgroups started
     __syncthreads();
     // (the drain -- parked boards, `active`, the last wave sweeping up -- is k_bounce_rollout_flat's, see there)
     bool last = false;
@@ -1830,10 +1828,10 @@ k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restric
                 }
                 const uint4* line = reinterpret_cast<const uint4*>(book_table + at);
                 const uint4 q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3];
-                wave_lds[w].opened[0][lane] = q0;
-                wave_lds[w].opened[1][lane] = q1;
-                wave_lds[w].opened[2][lane] = q2;
-                wave_lds[w].opened[3][lane] = q3;
+                opened_lds[w][0][lane] = q0;
+                opened_lds[w][1][lane] = q1;
+                opened_lds[w][2][lane] = q2;
+                opened_lds[w][3][lane] = q3;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1845,8 +1843,8 @@ k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restric
                 if (book_depth) {
                     const uint32_t slot = taken + rank;   // (a chunk is at most 64 games: bounce_rollout)
                     have_block = false;
-                    const uint4 q0 = wave_lds[w].opened[0][slot], q1 = wave_lds[w].opened[1][slot], q2 = wave_lds[w].opened[2][slot],
-                                q3 = wave_lds[w].opened[3][slot];
+                    const uint4 q0 = opened_lds[w][0][slot], q1 = opened_lds[w][1][slot], q2 = opened_lds[w][2][slot],
+                                q3 = opened_lds[w][3][slot];
                     const uint32_t where[4] = {q0.x, q0.y, q0.z, q0.w};
 #pragma unroll
                     for (int j = 0; j < PMAX / 4; ++j) b.pos[j] = where[j];
@@ -2147,78 +2145,10 @@ k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restric
             }
         }
     }
-    if constexpr (TAIL) {
-        // ---- this wave's part of the bulk loop is over: it becomes a K3w wave (see "the TAIL QUEUE")
-        constexpr uint32_t kWavesPerGroup = BLOCK / BGS_WAVE;
-        const uint32_t bulk_waves = gridDim.x * kWavesPerGroup;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (this wave's entries before its departure)
-        const uint32_t gone = gbump(tail.counters + 2, 1u, true) + 1u;
-        const uint32_t seat = gbump(tail.counters + 3, 1u, false);
-        // A wave takes the tail role only when every workgroup of the launch has started: the bulk waves it will wait for are
-        // then all resident and run whatever the tail waves do.  With workgroups still to be dispatched a waiting wave could
-        // hold the very slot they need (20 launches in flight do that to each other): such a wave leaves; what the queue
-        // holds is taken by the waves that come later -- the launch's last bulk wave always stays until the queue is empty.
-        uint32_t started = 0;
-        if (lane == 0u) started = __hip_atomic_load(tail.counters + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        started = (uint32_t)__builtin_amdgcn_readfirstlane((int)started);
-        if (gone == bulk_waves || (started == gridDim.x && seat < tail.limit)) {
-            __builtin_amdgcn_s_setprio(3);   // (as K3w: these waves are the launch's critical path)
-            WaveMemo<PMAX>& memo = wave_lds[w].memo;
-            uint32_t epoch = 1;
-            bool memo_ready = false;
-            for (;;) {
-                // a ticket, then the wait for ITS entry (a word of its own: the waiting waves do not meet on one address) --
-                // or for the end: every bulk wave gone and the ticket at or beyond what was ever allocated
-                const uint32_t t = gbump(tail.counters + 1, 1u, false);
-                bool there = false;
-                for (;;) {
-                    uint32_t flag = 0, left_bulk = 0, allocated = 0;
-                    if (lane == 0u) {
-                        if (t < tail.capacity) flag = __hip_atomic_load(tail.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        left_bulk = __hip_atomic_load(tail.counters + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag);
-                    left_bulk = (uint32_t)__builtin_amdgcn_readfirstlane((int)left_bulk);
-                    if (t < tail.capacity && flag == tail.serial) {
-                        there = true;
-                        break;
-                    }
-                    if (left_bulk == bulk_waves) {
-                        // (the bulk waves' allocations are ordered before their departure: read behind an acquire of that count)
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        if (lane == 0u) allocated = __hip_atomic_load(tail.counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        allocated = (uint32_t)__builtin_amdgcn_readfirstlane((int)allocated);
-                        if (t >= allocated) break;
-                        // (an entry that was allocated is complete by now: the flag is read again)
-                    }
-                    __builtin_amdgcn_s_sleep(40);
-                }
-                if (!there) break;
-                if (!memo_ready) {
-                    wave_memo_reset(memo, lane);
-                    memo_ready = true;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const uint32_t* e = tail.entries + (size_t)t * kTailEntryWords;
-                uint32_t where[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) where[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[j]);
-                const uint32_t the_game = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[4]);
-                uint32_t the_plies = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[5]);
-                const uint32_t came_with = the_plies;
-                Board board = planes_from_positions<PMAX>(g, where);
-                uint32_t the_st = BGS_ST_RUNNING;
-                wave_play_game<PMAX>(g, memo, epoch, board, the_st, the_plies, seed, first_game + (uint64_t)the_game, tail.final_cap,
-                                     tail.epoch_limit, tail.cold_limit, tail.bypass_plies);
-                wave_store_positions<PMAX>(board, planes, n, (int64_t)the_game);
-                if (lane == 0u) {
-                    status[the_game] = (uint8_t)the_st;
-                    plies_buf[the_game] = (uint16_t)the_plies;
-                    reward[the_game] = reward_pair(the_st);
-                    stepped += the_plies - came_with;
-                }
-            }
-        }
+    if (TAIL) {
+        // this wave's part is over: its entries, then its departure (the tail kernel's end signal is the last one's)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        (void)gbump(tail.counters + 2, 1u, true);
     }
 #ifdef BGS_BOUNCE_STATS
     if (lane == 0) {  // words 1..4 of shard 0's cache line are free
@@ -2227,6 +2157,75 @@ k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restric
         atomicAdd(steps + 3, (unsigned long long)stat_drain_iters);
     }
 #endif
+    add_steps(steps, stepped);
+}
+
+// the tail kernel (see "the TAIL QUEUE"): K3w's code on one-wave workgroups that draw tickets from the queue K3p feeds.  A
+// wave waits for ITS entry (a word of its own: the waiting waves do not meet on one address) -- or for the end: every bulk wave
+// gone and its ticket at or beyond what was ever allocated.  `patience`: polls (~1 us each) after which a wave gives up -- a
+// bulk kernel that never came (a launch failure the host did not see) must not leave this one spinning for ever; the boards
+// it leaves behind stay "running" at the bulk cap, which the caller can see.
+template <int PMAX, class GEO>
+__global__ void __launch_bounds__(BGS_WAVE)
+k_bounce_tail(GEO g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
+              uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps,
+              TailArgs tail, uint32_t bulk_waves, uint32_t patience) {
+    __builtin_amdgcn_s_setprio(3);   // (as K3w: these waves are the launch's critical path)
+    const uint32_t lane = threadIdx.x & 63u;
+    __shared__ WaveMemo<PMAX> memo;
+    uint32_t epoch = 1, stepped = 0;
+    wave_memo_reset(memo, lane);
+    auto draw = [&](uint32_t* word) {
+        uint32_t old = 0;
+        if (lane == 0u) old = __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+    };
+    for (;;) {
+        const uint32_t t = draw(tail.counters + 1);
+        bool there = false;
+        for (uint32_t polls = 0; polls < patience; ++polls) {
+            uint32_t flag = 0, left_bulk = 0, allocated = 0;
+            if (lane == 0u) {
+                if (t < tail.capacity) flag = __hip_atomic_load(tail.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                left_bulk = __hip_atomic_load(tail.counters + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag);
+            left_bulk = (uint32_t)__builtin_amdgcn_readfirstlane((int)left_bulk);
+            if (t < tail.capacity && flag == tail.serial) {
+                there = true;
+                break;
+            }
+            if (left_bulk == bulk_waves) {
+                // (the bulk waves' allocations are ordered before their departure: read behind an acquire of that count)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (lane == 0u) allocated = __hip_atomic_load(tail.counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                allocated = (uint32_t)__builtin_amdgcn_readfirstlane((int)allocated);
+                if (t >= allocated) break;
+                // (an entry that was allocated is complete by now: the flag is read again)
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (!there) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t* e = tail.entries + (size_t)t * kTailEntryWords;
+        uint32_t where[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) where[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[j]);
+        const uint32_t game = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[4]);
+        uint32_t plies = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[5]);
+        const uint32_t came_with = plies;
+        Board b = planes_from_positions<PMAX>(g, where);
+        uint32_t st = BGS_ST_RUNNING;
+        wave_play_game<PMAX>(g, memo, epoch, b, st, plies, seed, first_game + (uint64_t)game, tail.final_cap, tail.epoch_limit,
+                             tail.cold_limit, tail.bypass_plies);
+        wave_store_positions<PMAX>(b, planes, n, (int64_t)game);
+        if (lane == 0u) {
+            status[game] = (uint8_t)st;
+            plies_buf[game] = (uint16_t)plies;
+            reward[game] = reward_pair(st);
+            stepped += plies - came_with;
+        }
+    }
     add_steps(steps, stepped);
 }
 
@@ -2744,21 +2743,21 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         const uint32_t chunk = book_depth ? 64u : chunk0;
         // the device-wide pool of parked boards: counters zeroed per launch (one small fill on the stream)
         const int park_at = b->bounce_pieces_park >= 0 ? b->bounce_pieces_park : bounce_shape(b->launches_in_flight).park;
-        uint32_t* pool = !TAIL && b->bounce_pool && park_at > 0 && groups >= 2 && groups <= (unsigned)BGS_BOUNCE_POOL_GROUPS ? b->d_pool : nullptr;
+        uint32_t* pool = b->bounce_pool && park_at > 0 && groups >= 2 && groups <= (unsigned)BGS_BOUNCE_POOL_GROUPS ? b->d_pool : nullptr;
         if (pool) (void)hipMemsetAsync(pool, 0, sizeof(uint32_t) * (4 + 2 * (size_t)groups), b->stream);
         TailArgs tail{};
         if (TAIL) {
-            // the tail queue: counters in the (otherwise unused) pool region, "entry complete" words in the work list's region
-            // (one per game; they hold launch serials, so they are cleared only when something else has written there), the
-            // entries in the staging region (32 bytes a game; nothing else of this batch runs beside its rollout)
+            // the tail queue: counters among the rollout's list counters (cleared at its start: words 4 .. 7, the lengths of passes
+            // no automatic plan has), "entry complete" words in the work list's region (one per game; they hold launch serials, so
+            // they are cleared only when something else has written there), the entries in the staging region (32 bytes a game;
+            // nothing else of this batch runs beside its rollout)
             const BounceShape shape = bounce_shape(b->launches_in_flight);
-            (void)hipMemsetAsync(b->d_pool, 0, sizeof(uint32_t) * 8, b->stream);
             if (b->tail_flags_dirty || b->tail_serial == 0xFFFFFFFFu) {
                 (void)hipMemsetAsync(b->d_worklist, 0, sizeof(uint32_t) * (size_t)b->n, b->stream);
                 b->tail_flags_dirty = 0;
                 b->tail_serial = 0;
             }
-            tail.counters = b->d_pool;
+            tail.counters = b->d_work_count + 4;
             tail.ready = b->d_worklist;
             tail.entries = reinterpret_cast<uint32_t*>(b->d_staging);
             tail.capacity = (uint32_t)b->n;
@@ -2777,12 +2776,37 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         // (Tried, round 4: a kernel specialised on "exactly PMAX pieces" -- every "is there a piece k" test decided at compile
         // time.  18 % fewer static instructions, one basic block a phase, and 174 VGPRs; held to 128 it spills 43 and reads
         // 1.14 against 1.26 x 10^10 with 20 launches in flight.)
+        // TAIL: the tail kernel runs BESIDE the bulk kernel on a stream of the batch's own -- behind everything the batch's stream
+        // holds so far (the fork event), and the batch's stream goes on behind it (the join event).  The bulk kernel is launched
+        // first: should the two end up one after the other, it is this order.
+        bool forked = false;
+        if (TAIL) {
+            if (!b->tail_stream) {
+                if (hipStreamCreateWithFlags(&b->tail_stream, hipStreamNonBlocking) != hipSuccess) b->tail_stream = nullptr;
+                if (b->tail_stream && (hipEventCreateWithFlags(&b->tail_fork, hipEventDisableTiming) != hipSuccess ||
+                                       hipEventCreateWithFlags(&b->tail_join, hipEventDisableTiming) != hipSuccess)) {
+                    (void)hipStreamDestroy(b->tail_stream);
+                    b->tail_stream = nullptr;
+                }
+            }
+            forked = b->tail_stream && hipEventRecord(b->tail_fork, b->stream) == hipSuccess &&
+                     hipStreamWaitEvent(b->tail_stream, b->tail_fork, 0) == hipSuccess;
+        }
+        hipStream_t tail_on = forked ? b->tail_stream : b->stream;   // (no stream of its own: the tail kernel follows the bulk kernel)
         auto go = [&](auto geo) {
             hipLaunchKernelGGL((k_bounce_rollout_pieces<PMAX, BLOCK, TAIL, decltype(geo)>), dim3(groups),
                                dim3(BLOCK), tile, b->stream, geo, b->d_planes, b->d_status, b->d_plies,
                                reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, cap, b->d_steps, chunk, queue,
                                (uint32_t)park_at, pool, b->book_links,
                                reinterpret_cast<const BookEntry*>(b->book_table), book_depth, b->book_n0, tail);
+            if (TAIL) {
+                hipLaunchKernelGGL((k_bounce_tail<PMAX, decltype(geo)>), dim3(tail.limit), dim3(BGS_WAVE), 0, tail_on, geo, b->d_planes,
+                                   b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, b->d_steps,
+                                   tail, (uint32_t)(groups * per_block), 4000000u);
+                if (forked && (hipEventRecord(b->tail_join, b->tail_stream) != hipSuccess ||
+                               hipStreamWaitEvent(b->stream, b->tail_join, 0) != hipSuccess))
+                    (void)hipStreamSynchronize(b->tail_stream);   // (the join could not be enqueued: wait for the tail here)
+            }
         };
         // (the default board: the compile-time geometry, see bounce_unit.h -- 256-thread workgroups only, the shape every plan uses)
         if constexpr (PMAX == 12 && BLOCK == 256) {
@@ -2898,9 +2922,9 @@ void bounce_rollout(const bgs_batch* b, uint64_t seed, int32_t max_plies, uint32
             const uint32_t pass_cap = (last || pass_cap_of[pass] > cap) ? cap : pass_cap_of[pass];
             const int group = pass_group_of[pass];
             if (pass == 0) {
-                // K3p with K3w as the second and last pass: ONE launch, the tail inside it ("the TAIL QUEUE"; experiment bounce_tail=0:
-                // the passes one after the other as until round 5)
-                const bool fused = b->bounce_tail && passes == 2 && group == 1 && pass_group_of[1] == 64 && piece_list && from_initial &&
+                // K3p with K3w as the second and last pass; experiment bounce_tail=1: the tail kernel BESIDE the bulk kernel ("the
+                // TAIL QUEUE" -- measured slower than the pass behind it, so no automatic plan takes it)
+                const bool fused = b->bounce_tail > 0 && passes == 2 && group == 1 && pass_group_of[1] == 64 && piece_list && from_initial &&
                                    b->bounce_block < 512 && b->bg.piece_count <= BGS_BOUNCE_MAX_PIECES && b->d_pool != nullptr &&
                                    b->n < (int64_t)0xFFFFFFFFu && b->staging_bytes >= (size_t)b->n * kTailEntryWords * sizeof(uint32_t);
                 if (fused) {

@@ -1123,3 +1123,24 @@ def test_connect_strict_contract_through_the_reward_sink(batch_mod):
     sink.close()
     with pytest.raises(ValueError):
         dev.set_rng_contract("per-game")
+
+
+def test_bounce_tail_kernel_beside_the_bulk_kernel(batch_mod, monkeypatch):
+    """Experiment bounce_tail=1 (round 6; measured slower, no automatic plan takes it): K3p hands the games that reach its ply cap
+    -- and the last boards of a workgroup's last wave -- to a device-wide queue, a second kernel on a stream of the batch's own
+    finishes them while the bulk kernel runs.  Same boards as the oracle's, whatever the hand-over threshold and the number
+    of tail waves; twice on the same batch (the queue's "entry complete" words are launch serials)."""
+    n = 1 << 17
+    orc = oracle.BounceOracle(DEFAULT_BOUNCE, n)
+    total = orc.rollout(SEED + 41, max_plies=4096)
+    for handoff, limit in (("0", "64"), ("16", "512"), ("32", "1024")):
+        monkeypatch.setitem(knobs, "bounce_tail", "1")
+        monkeypatch.setitem(knobs, "bounce_tail_handoff", handoff)
+        monkeypatch.setitem(knobs, "bounce_tail_limit", limit)
+        dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+        for _ in range(2):
+            dev.reset_steps()
+            dev.rollout(SEED + 41, max_plies=4096, from_initial=True)
+            assert_same(dev, orc, f"handoff {handoff}, {limit} tail waves")
+            assert dev.steps == total
+        dev.close()

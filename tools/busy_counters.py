@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/busy_* (tools/busy_counters.sh) -> profiles/<round>_valu_busy.json (BGS_PROFILE_ROUND, default r05): per case and kernel the mean counter values
+"""gpurun_out/busy_* (tools/busy_counters.sh) -> profiles/<round>_valu_busy.json (BGS_PROFILE_ROUND, default r06): per case and kernel the mean counter values
 per dispatch and what they say about the vector issue pipe.
 
 Units (rocprofv3 -L on gfx950): SQ_ACTIVE_INST_VALU, SQ_ACTIVE_INST_ANY, SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_BUSY_CU_CYCLES are
@@ -69,7 +69,7 @@ def main():
     }
     units = _abi.unit_ids()
     case_unit = {"k2o_solo": "connect", "k2o_3deep": "connect", "k2c_solo": "connect", "k2c_8deep": "connect", "k3p_solo": "bounce", "k3p_8x": "bounce"}
-    rnd = os.environ.get("BGS_PROFILE_ROUND", "r05")
+    rnd = os.environ.get("BGS_PROFILE_ROUND", "r06")
     path = os.path.join(ROOT, "profiles", f"{rnd}_valu_busy.json")
     # cases that were not re-taken in this pass (their unit did not move: busy_counters.sh skipped them) are carried over
     # from the newest file that holds them for the running unit id

@@ -5,7 +5,7 @@
 # rocprofv3 collects counters per dispatch and serialises the dispatches, so "N launches in flight" cannot be counted
 # as such: each pipelined case is counted as ONE launch of N times the boards with N times the waves per SIMD (the same
 # games per wave, the same waves resident per SIMD as N launches sharing the chip).
-# usage (GPU box): bash tools/busy_counters.sh ; then python3 tools/busy_counters.py -> profiles/r05_valu_busy.json
+# usage (GPU box): bash tools/busy_counters.sh ; then python3 tools/busy_counters.py -> profiles/r06_valu_busy.json
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 # BGS_EXPERIMENT only reaches the TEST build of the library (csrc/Makefile: libbgs_test.so, same kernel objects); without it the product library is measured
@@ -15,6 +15,8 @@ PMC="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_BUSY_CU_CYCLES SQ
 pass() {  # pass <tag> <program> <args...>   (environment of the caller); skipped when the case's kernel unit did not move
   local tag=$1; shift
   if ! ( cd $R && python3 tools/needs_profile.py case $tag ); then rm -rf $R/gpurun_out/busy_$tag; return; fi
+  # (a case that sets BGS_EXPERIMENT runs on the test build of the library: the product has no such switches)
+  if [ -n "${BGS_EXPERIMENT:-}" ]; then export BGS_LIBRARY=$R/board-game-simulator-python_amd/libbgs_test.so; else unset BGS_LIBRARY; fi
   rm -rf $R/gpurun_out/busy_$tag
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $R/gpurun_out/busy_$tag -- "$@" > $R/gpurun_out/busy_$tag.log 2>&1 || echo "pass failed: $tag"
   echo "counted $tag"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_* (tools/profile_all.sh) -> profiles/<round>_*.json (round: BGS_PROFILE_ROUND, default r05), including
+"""gpurun_out/prof_* (tools/profile_all.sh) -> profiles/<round>_*.json (round: BGS_PROFILE_ROUND, default r06), including
 profiles/<round>_rollout_counters.json, the per-launch PMC figures of the bench kernel that bench.py quotes when the id of
 the kernel UNIT they were taken on (connect / bounce / generic: bgs_kernel_unit_id) matches the running library's.  Only the
 tags whose passes exist under gpurun_out/ are (re)written: profile_all.sh skips the units that did not move."""
@@ -8,7 +8,7 @@ import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "board-game-simulator-python_amd")]
 OUT = os.path.join(ROOT, "profiles")
-ROUND = os.environ.get("BGS_PROFILE_ROUND", "r05")
+ROUND = os.environ.get("BGS_PROFILE_ROUND", "r06")
 TAG_UNIT = {"bench": "connect", "k1": "connect", "k2c": "connect", "k2b": "connect", "bounce": "bounce", "bounce_solo": "bounce",
             "bounce_k3f": "bounce", "bounce8": "bounce"}
 

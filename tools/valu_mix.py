@@ -56,8 +56,9 @@ if __name__ == "__main__":
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "connect.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
-                               os.path.join(csrc, "connect_kernels.hip"), "-o", out, "-Wno-unused-function"],
+                               os.path.join(csrc, "connect_kernels.hip"), "-o", out, "-Wno-unused-function", "-mllvm", "-enable-post-misched=0"],
                               stderr=subprocess.DEVNULL)
         # the bench kernel: Connect4(6,7,4), uncapped, from the initial state, 3 opening blocks, outcome codes fused
-        sym = "_ZN3bgs12_GLOBAL__N_124k_connect_rollout_openedINS0_3GeoILi1ELi6ELi7ELi4EEELi3ELb1EEE"
+        # (template arguments: geometry, opening blocks, codes, RNG contract [, drain merge]: a prefix of the mangled name)
+        sym = "_ZN3bgs12_GLOBAL__N_124k_connect_rollout_openedINS0_3GeoILi1ELi6ELi7ELi4EEELi3ELb1ELb0E"
         print(json.dumps(mix(out, sym), indent=1))

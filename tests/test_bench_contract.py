@@ -230,3 +230,39 @@ def test_bench_refuses_to_run_without_a_gpu():
                           capture_output=True, text=True, timeout=300)
     assert proc.returncode == 2
     assert "no GPU" in proc.stderr and not proc.stdout.strip()
+
+
+def test_round6_lines():
+    """Round 6: the line names its RNG contract and carries the other contract's rate beside `value` (the strict contract
+    costs < 10 %), Bounce's compile-time geometry shows in BASELINE config 4 (pipelined > 2.1e10, alone > 4.8e9, both queue
+    settings of eight in flight, <= 2.4e8 instructions a launch), the counters are this round's own."""
+    long, short, strict = _line("r06_bench.json"), _line("r06_bench_steps20.json"), _line("r06_bench_per_ply.json")
+    assert long["steps"] == 200 and short["steps"] == 20 and long["value_median_of_3"] > 8.0e11 and short["value_median_of_3"] > 7.3e11
+    assert long["config"]["rng"].startswith("per-block") and strict["config"]["rng"].startswith("per-ply")
+    for d in (long, short, strict):
+        other = d["rng_other"]
+        assert other["parity_with_oracle_first_4096"] is True and other["rewards_to_host"] is True
+        assert d["cpu_baseline"]["parity_with_host_rewards"] is True   # (the oracle under the line's own contract)
+    assert long["rng_other"]["rng"].startswith("per-ply") and 0.88 < long["rng_other"]["over_value"] < 1.0
+    assert strict["rng_other"]["rng"].startswith("per-block") and 1.0 < strict["rng_other"]["over_value"] < 1.15
+    assert long["rccl_ranks"] is None and long["ms_per_step_fastest_rank"] == pytest.approx(long["ms_per_step"])
+    roof = long["roofline"]
+    assert roof["counters_file"] == "r06_rollout_counters.json" and 0.55 < roof["frac"] < 0.62 and roof["valu_busy"]["counters_file"] == "r06_valu_busy.json"
+    bounce = long["other_configs"]["bounce_default"]
+    assert bounce["parity_with_oracle"] is True and bounce["value"] > 2.1e10 and bounce["solo"]["value"] > 4.8e9
+    assert bounce["valu_issue"]["counters_file"] == "r06_bounce.json" and bounce["valu_issue"]["wave_instr_per_launch"] <= 2.4e8
+    eight = bounce["eight_in_flight"]
+    assert eight["hardware_queues_16"]["value"] > 1.8e10 > eight["hardware_queues_4"]["value"] > 1.0e10
+    assert eight["hardware_queues_4"]["parity_with_oracle"] is True and eight["hardware_queues_16"]["parity_with_oracle"] is True
+    assert long["other_configs"]["connect_12x13x5"]["value"] > 2.3e11
+
+
+def test_round6_rehearsals_value_is_the_rccl_gathers():
+    """BASELINE config 5 rehearsed at 2, 4 and 6 processes sharing the GPU over the stand-in: since round 6 `value` is the RCCL
+    gather's (the north-star's collective), `rccl_ranks` = what the communicator counts, both hand-overs verified, nothing failed."""
+    for n in (2, 4, 6):
+        d = _line(f"r06_dist_{n}_ranks_standin.json")
+        assert d["n_gpus"] == n and d["config"]["global_batch"] == n << 20 and d["config"]["gather"] == "rccl" and d["rccl_ranks"] == n
+        assert d["value"] == pytest.approx(d["gather_rccl"]["value"]) and "failed_handovers" not in d
+        assert d["gather_shm"]["gathered_rewards_verified"] is True and d["gather_rccl"]["gathered_rewards_verified"] is True
+        assert 0 < d["ms_per_step_fastest_rank"] <= d["ms_per_step_slowest_rank"]

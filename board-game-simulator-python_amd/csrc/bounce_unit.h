@@ -145,7 +145,10 @@ constexpr int kBounceMemoBypass = 28;       // ... for this many plies, then loo
 //   160 (1536 waves): 1.66 / 1.58 / 1.61 / 1.66 / 1.73 / 1.83; park 4 / 8 / 16 / 32 (1024 waves): 1.454 / 1.448 / 1.456 / 1.524.
 struct BounceShape { int tail_cap; int boards_per_wave; int handoff_at; int tail_waves; int park; };
 inline BounceShape bounce_shape(int launches_in_flight) {
-    if (launches_in_flight >= 12) return {160, 512, 4, 512, 32};
+    // (20 in flight, 32 hardware queues, compile-time geometry, x 10^10: caps 128 / 160 / 192 / 224 / 256 / 320 at 256 waves -- / -- /
+    // 2.38 / 2.39 / 2.40 / 2.38; waves 256 / 320 / 384 / 512 / 768 / 1024 at cap 256: 2.40 / 2.33 / 2.37 / 2.34 / 2.27 / 2.21; round 5's
+    // {160, 512}: 2.29)
+    if (launches_in_flight >= 12) return {240, 1024, 4, 512, 32};
     if (launches_in_flight >= 4) return {128, 256, 8, 1024, 32};
     return {80, 256, 16, 2048, 8};   // (one launch at a time, K3w on 8192 waves: caps of 64 / 80 / 96 / 112 / 128 read 2.78 / 2.86 / 2.80 / 2.69 / 2.62 x 10^9)
 }

@@ -336,10 +336,15 @@ int device_facts(bgs_batch* b) {
     if (const char* env = bgs::experiment("bounce_static_geom")) b->bounce_static_geom = atoi(env) != 0;
     b->bounce_tail = 0;   // (round 6: built twice, measured, slower than the pass behind the bulk kernel both times: off; see bounce_kernels.hip)
     if (const char* env = bgs::experiment("bounce_tail")) b->bounce_tail = atoi(env) != 0;
-    b->tail_stream = nullptr;
-    b->tail_fork = b->tail_join = nullptr;
+    for (int k = 0; k < bgs_batch::kTailStages; ++k) {
+        b->tail_stream[k] = nullptr;
+        b->tail_join[k] = nullptr;
+    }
+    b->tail_fork = b->tail_bulk_done = nullptr;
     b->bounce_tail_handoff = -1;
     if (const char* env = bgs::experiment("bounce_tail_handoff")) b->bounce_tail_handoff = atoi(env);
+    b->bounce_tail_prio = 3;
+    if (const char* env = bgs::experiment("bounce_tail_prio")) b->bounce_tail_prio = atoi(env) & 3;
     b->bounce_tail_limit = 0;
     if (const char* env = bgs::experiment("bounce_tail_limit")) b->bounce_tail_limit = atoi(env);
     b->tail_serial = 0;
@@ -826,12 +831,15 @@ int bgs_destroy(bgs_batch* b) {
         if (b->pinned_done[k]) (void)hipEventDestroy(b->pinned_done[k]);
     }
     if (b->order_event) (void)hipEventDestroy(b->order_event);
-    if (b->tail_stream) {   // (the Bounce rollout's tail kernel: joined into b->stream, which was synchronised above)
-        (void)hipStreamSynchronize(b->tail_stream);
-        (void)hipEventDestroy(b->tail_fork);
-        (void)hipEventDestroy(b->tail_join);
-        (void)hipStreamDestroy(b->tail_stream);
+    for (int k = 0; k < bgs_batch::kTailStages; ++k) {   // (the Bounce rollout's staged tail launches: joined into b->stream, synchronised above)
+        if (b->tail_stream[k]) {
+            (void)hipStreamSynchronize(b->tail_stream[k]);
+            (void)hipStreamDestroy(b->tail_stream[k]);
+        }
+        if (b->tail_join[k]) (void)hipEventDestroy(b->tail_join[k]);
     }
+    if (b->tail_fork) (void)hipEventDestroy(b->tail_fork);
+    if (b->tail_bulk_done) (void)hipEventDestroy(b->tail_bulk_done);
     delete b;
     return BGS_OK;
 }

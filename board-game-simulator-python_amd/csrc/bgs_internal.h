@@ -53,9 +53,11 @@ struct bgs_batch {
     int bounce_static_geom;  // 1: the default board is played by the kernels instantiated on its compile-time geometry (experiment bounce_static_geom=0: the run-time record)
     int bounce_tail;         // 1: the games beyond K3p's ply cap are finished by a tail kernel that runs BESIDE it (experiment bounce_tail=0: a pass behind it); -1: by the launch shape
     int bounce_tail_handoff; // >= 0: a workgroup's last wave hands its boards to the tail queue at this many or fewer (experiment; -1: bounce_shape())
+    int bounce_tail_prio;    // s_setprio of the tail kernel's waves (experiment bounce_tail_prio, 0..3)
     int bounce_tail_limit;   // > 0: tail waves that may wait for entries at a time (experiment; 0: bounce_shape())
-    mutable hipStream_t tail_stream;   // the stream the tail kernel runs on beside the bulk kernel (created at the first such rollout)
-    mutable hipEvent_t tail_fork, tail_join;
+    enum { kTailStages = 4 };
+    mutable hipStream_t tail_stream[kTailStages];   // the streams of the staged tail launches beside the bulk kernel (created at the first such rollout)
+    mutable hipEvent_t tail_fork, tail_bulk_done, tail_join[kTailStages];
     mutable uint32_t tail_serial;     // the "entry complete" word of the last fused launch (the region of d_worklist holds such words)
     mutable int tail_flags_dirty;     // 1: d_worklist holds something else (game indices of a compaction pass, nothing yet)
     int rollout_generic;     // 1: never take the block-aligned from-initial kernel (A/B timing, experiment rollout_generic)

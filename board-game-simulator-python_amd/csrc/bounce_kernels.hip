@@ -1582,27 +1582,30 @@ __device__ __forceinline__ void wave_play_game(const GEO& g, WaveMemo<PMAX>& mem
 }
 
 
-// ---- the TAIL QUEUE (round 6): the games that outlive the bulk pass are finished WHILE the bulk pass runs.
+// ---- the TAIL QUEUE (round 6): the games that outlive the bulk pass, finished WHILE the bulk pass runs -- an experiment
+// (bounce_tail=1, test build), measured slower than the pass behind the bulk kernel in each of its three forms; no automatic
+// plan takes it.
 // Until round 5 a rollout was K3p to a ply cap -> positions to planes -> a compaction of the boards still running -> K3w,
-// one after the other on the batch's stream: a lone launch spent a third of its time in a nearly empty K3w, which could
-// only start when K3p's last wave had left -- although the games it waits for (the one that never ends: 4 000 plies along the
-// memo's links; the longest that wanders) mostly crossed the bulk cap in K3p's first third.  Now K3p hands a game that
-// reaches the bulk cap to a device-wide queue at once (and, `handoff_at`, the last boards of a workgroup's last wave), and a
-// second kernel -- k_bounce_tail: K3w's code on a few hundred one-wave workgroups, launched beside K3p on a stream of the
-// batch's own -- takes them from there as they come.  Nobody in the bulk kernel ever waits for the tail; the tail's waves
-// wait for entries only while the bulk kernel runs (its last wave's departure is the end signal), and they are few enough
-// (one a SIMD) that the bulk kernel's workgroups always find room beside them.  If the two kernels do not overlap (both
-// streams on one hardware queue) the tail simply runs behind the bulk pass, as the separate pass did.
-// A first form of this (the bulk kernel's own waves turning into K3w waves when they left the bulk loop) was built and
-// measured slower than the separate pass: no wave leaves the bulk loop before the queue has run dry, i.e. exactly when the
-// tail's games have long been waiting, and the merged kernel needed 129 VGPRs and 50 KB of LDS.
-// MEASURED (round 6, default board, 2^18 games, one launch at a time; the pass behind the bulk kernel: 1.44 ms): this form
-// 1.72 ms at its best (512 tail waves; 256: 2.27, 1024: 1.77-2.0, 2048: 2.6-2.8; hand-over thresholds 0 / 8 / 16 / 32 within 3 %
-// of each other), the first form 1.79-2.03 ms.  The waiting waves' polls and the tail's plies compete with the bulk waves for
-// the same SIMDs while the bulk pass is the part that binds; the experiment switch bounce_tail=1 (test build) keeps the code
-// reachable and its parity test running, no automatic plan selects it.
-//   counters  tq[0] entries allocated   tq[1] tickets drawn   tq[2] bulk waves that have left
-//   ready[e]  = the launch's serial once entry e is complete (written last, release at agent scope)
+// one after the other on the batch's stream: a lone launch spends a third of its time in a nearly empty K3w, which can
+// only start when K3p's last wave has left -- although the games it waits for (the one that never ends: 4 000 plies along the
+// memo's links; the longest that wanders) mostly crossed the bulk cap in K3p's first third.  With the queue K3p hands a game
+// that reaches the bulk cap over at once (and, `handoff_at`, the last boards of a workgroup's last wave): an entry of
+// positions / game / plies, then its "complete" word (the launch's serial, release at agent scope).
+//   Form 1: K3p's own waves turn into K3w waves when they leave the bulk loop.  No wave leaves before the queue is dry, i.e.
+//     when the tail's games have long been waiting; the merged kernel needs 129 VGPRs and 50 KB LDS.  1.79-2.03 ms a lone
+//     launch against 1.61 (compile-time geometry, before the shape was retuned).  Removed.
+//   Form 2: a second kernel (K3w's code on 256-2048 one-wave workgroups) on a stream of the batch's own, its waves WAITING for
+//     tickets' entries while the bulk kernel runs.  1.72 ms at its best against 1.44: the waiting waves' polls (agent-scope
+//     loads, a million a millisecond) and their plies compete with the bulk waves.  Removed.
+//   Form 3 (what is here): STAGED launches of that kernel, nobody waits on the device: stage k owns the entries [lo, hi) and
+//     sits on a stream of its own behind a hipStreamWaitValue32 on the queue's progress word -- the command processor holds
+//     the launch back until K3p has allocated `hi` entries (or has finished: its last wave stores the largest value) -- and the
+//     last stage, behind K3p itself, owns the rest.  1.51-1.56 ms against 1.44 (256-2048 waves a stage, hand-over at 0 / 16 / 32,
+//     wave priority 0 / 1 / 3 all within 5 %).  What the overlap saves -- the long games start at 0.35 ms instead of 0.9 -- the
+//     four cross-stream joins, the bulk waves' lost issue slots and the last stage (a long game that crossed the cap late is
+//     still the launch's end) take back.
+//   counters  tq[0] entries allocated   tq[2] bulk waves that have left   tq[3] the progress word the streams wait on
+//   ready[e]  = the launch's serial once entry e is complete
 //   entry e   = 8 dwords: positions (4), game, plies, -, -
 constexpr uint32_t kTailEntryWords = 8;
 
@@ -1693,6 +1696,7 @@ struct TailArgs {
     uint32_t handoff_at;      // a workgroup's last wave hands its boards over at this many or fewer (0: plays them to the bulk cap)
     uint32_t limit;           // tail waves that may wait for entries at a time (the last bulk wave always stays)
     uint32_t epoch_limit, cold_limit, bypass_plies;   // K3w's memo policy
+    uint32_t prio;            // s_setprio of the tail kernel's waves
 };
 
 template <int PMAX, int BLOCK, bool TAIL, class GEO>
@@ -1775,6 +1779,9 @@ k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restric
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __hip_atomic_store(tail.ready + e, tail.serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // the word the STREAMS of the staged tail launches wait on (hipStreamWaitValue32: the command processor watches it, no
+        // wave does): entries allocated so far
+        if (lane == 0u) (void)__hip_atomic_fetch_max(tail.counters + 3, base + (uint32_t)__popcll(who), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
 
     PieceBoard<PMAX> b;
@@ -2148,7 +2155,10 @@ k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restric
     if (TAIL) {
         // this wave's part is over: its entries, then its departure (the tail kernel's end signal is the last one's)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        (void)gbump(tail.counters + 2, 1u, true);
+        const uint32_t gone = gbump(tail.counters + 2, 1u, true) + 1u;
+        // the launch's last bulk wave releases every staged tail launch that is still waiting for its threshold
+        if (gone == gridDim.x * (BLOCK / BGS_WAVE) && lane == 0u)
+            __hip_atomic_store(tail.counters + 3, 0x7FFFFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #ifdef BGS_BOUNCE_STATS
     if (lane == 0) {  // words 1..4 of shard 0's cache line are free
@@ -2160,52 +2170,48 @@ k_bounce_rollout_pieces(GEO g, uint64_t* __restrict__ planes, uint8_t* __restric
     add_steps(steps, stepped);
 }
 
-// the tail kernel (see "the TAIL QUEUE"): K3w's code on one-wave workgroups that draw tickets from the queue K3p feeds.  A
-// wave waits for ITS entry (a word of its own: the waiting waves do not meet on one address) -- or for the end: every bulk wave
-// gone and its ticket at or beyond what was ever allocated.  `patience`: polls (~1 us each) after which a wave gives up -- a
-// bulk kernel that never came (a launch failure the host did not see) must not leave this one spinning for ever; the boards
-// it leaves behind stay "running" at the bulk cap, which the caller can see.
+// the tail kernel (see "the TAIL QUEUE"): K3w's code on one-wave workgroups.  Nobody waits for K3p: the launches of this
+// kernel are STAGED -- stage k owns the queue's entries [lo, hi) and sits on a stream of its own behind a
+// hipStreamWaitValue32 on the queue's progress word, i.e. the command processor holds the launch back until K3p has allocated
+// `hi` entries (or has finished: its last wave stores the largest value); the last stage, behind K3p itself, owns everything
+// from its `lo` on.  So when a stage runs, every entry of its range exists (or never will): its waves draw tickets from the
+// stage's own counter and leave when the range is used up -- no wave ever holds a ticket for an entry that is still to come,
+// and no two waves meet on a compare-and-swap (a first version claimed the queue's head that way: 2048 waves, 5000 entries,
+// 200 ms a launch).
 template <int PMAX, class GEO>
 __global__ void __launch_bounds__(BGS_WAVE)
 k_bounce_tail(GEO g, uint64_t* __restrict__ planes, uint8_t* __restrict__ status, uint16_t* __restrict__ plies_buf,
               uint16_t* __restrict__ reward, int64_t n, uint64_t seed, uint64_t first_game, unsigned long long* __restrict__ steps,
-              TailArgs tail, uint32_t bulk_waves, uint32_t patience) {
-    __builtin_amdgcn_s_setprio(3);   // (as K3w: these waves are the launch's critical path)
+              TailArgs tail, uint32_t lo, uint32_t hi, uint32_t* __restrict__ stage_counter) {
+    // (K3w raises its waves' priority: they are its launch's critical path.  Beside the bulk kernel that is a choice: tail.prio)
+    if (tail.prio == 3u) __builtin_amdgcn_s_setprio(3);
+    else if (tail.prio == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (tail.prio == 1u) __builtin_amdgcn_s_setprio(1);
     const uint32_t lane = threadIdx.x & 63u;
     __shared__ WaveMemo<PMAX> memo;
     uint32_t epoch = 1, stepped = 0;
-    wave_memo_reset(memo, lane);
-    auto draw = [&](uint32_t* word) {
-        uint32_t old = 0;
-        if (lane == 0u) old = __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
-    };
+    bool memo_ready = false;
+    // (the stage was released because `hi` entries exist, or because the bulk kernel is over: either way what is allocated now
+    // is all this stage will ever own)
+    uint32_t allocated = 0;
+    if (lane == 0u) allocated = __hip_atomic_load(tail.counters, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    allocated = (uint32_t)__builtin_amdgcn_readfirstlane((int)allocated);
+    const uint32_t end = hi < allocated ? hi : allocated;
     for (;;) {
-        const uint32_t t = draw(tail.counters + 1);
-        bool there = false;
-        for (uint32_t polls = 0; polls < patience; ++polls) {
-            uint32_t flag = 0, left_bulk = 0, allocated = 0;
-            if (lane == 0u) {
-                if (t < tail.capacity) flag = __hip_atomic_load(tail.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                left_bulk = __hip_atomic_load(tail.counters + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag);
-            left_bulk = (uint32_t)__builtin_amdgcn_readfirstlane((int)left_bulk);
-            if (t < tail.capacity && flag == tail.serial) {
-                there = true;
-                break;
-            }
-            if (left_bulk == bulk_waves) {
-                // (the bulk waves' allocations are ordered before their departure: read behind an acquire of that count)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (lane == 0u) allocated = __hip_atomic_load(tail.counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                allocated = (uint32_t)__builtin_amdgcn_readfirstlane((int)allocated);
-                if (t >= allocated) break;
-                // (an entry that was allocated is complete by now: the flag is read again)
-            }
-            __builtin_amdgcn_s_sleep(32);
+        uint32_t t = 0;
+        if (lane == 0u) t = __hip_atomic_fetch_add(stage_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= end) break;
+        if (!memo_ready) {
+            wave_memo_reset(memo, lane);
+            memo_ready = true;
         }
-        if (!there) break;
+        for (;;) {   // (the entry's last word is written a few instructions after its allocation)
+            uint32_t flag = 0;
+            if (lane == 0u) flag = __hip_atomic_load(tail.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)flag) == tail.serial) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const uint32_t* e = tail.entries + (size_t)t * kTailEntryWords;
         uint32_t where[4];
@@ -2768,6 +2774,7 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
             tail.epoch_limit = b->bounce_epoch_limit >= 2 && b->bounce_epoch_limit < (int)kWaveEpochLimit ? (uint32_t)b->bounce_epoch_limit : kWaveEpochLimit;
             tail.cold_limit = (uint32_t)b->bounce_memo_cold;
             tail.bypass_plies = (uint32_t)b->bounce_memo_bypass;
+            tail.prio = (uint32_t)b->bounce_tail_prio;
         } else if (next_list && next_count && final_cap > cap) {
             tail.entries = next_list;
             tail.counters = next_count;
@@ -2776,23 +2783,26 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
         // (Tried, round 4: a kernel specialised on "exactly PMAX pieces" -- every "is there a piece k" test decided at compile
         // time.  18 % fewer static instructions, one basic block a phase, and 174 VGPRs; held to 128 it spills 43 and reads
         // 1.14 against 1.26 x 10^10 with 20 launches in flight.)
-        // TAIL: the tail kernel runs BESIDE the bulk kernel on a stream of the batch's own -- behind everything the batch's stream
-        // holds so far (the fork event), and the batch's stream goes on behind it (the join event).  The bulk kernel is launched
-        // first: should the two end up one after the other, it is this order.
+        // TAIL: the staged launches of the tail kernel, each on a stream of the batch's own behind (1) everything the batch's
+        // stream holds so far (the fork event) and (2) a wait for the queue's progress word to reach the stage's threshold; the
+        // last one behind the bulk kernel itself.  The batch's stream goes on behind them all (the join events).  The bulk kernel
+        // is enqueued FIRST: on whatever hardware queue a stage's wait ends up, the kernel that satisfies it is ahead of it.
+        constexpr int kStages = bgs_batch::kTailStages;   // (the last stage is the one behind the bulk kernel)
         bool forked = false;
         if (TAIL) {
-            if (!b->tail_stream) {
-                if (hipStreamCreateWithFlags(&b->tail_stream, hipStreamNonBlocking) != hipSuccess) b->tail_stream = nullptr;
-                if (b->tail_stream && (hipEventCreateWithFlags(&b->tail_fork, hipEventDisableTiming) != hipSuccess ||
-                                       hipEventCreateWithFlags(&b->tail_join, hipEventDisableTiming) != hipSuccess)) {
-                    (void)hipStreamDestroy(b->tail_stream);
-                    b->tail_stream = nullptr;
+            if (!b->tail_stream[0]) {
+                bool ok = true;
+                for (int k = 0; k < kStages && ok; ++k) {
+                    ok = hipStreamCreateWithFlags(&b->tail_stream[k], hipStreamNonBlocking) == hipSuccess &&
+                         hipEventCreateWithFlags(&b->tail_join[k], hipEventDisableTiming) == hipSuccess;
                 }
+                ok = ok && hipEventCreateWithFlags(&b->tail_fork, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&b->tail_bulk_done, hipEventDisableTiming) == hipSuccess;
+                if (!ok) b->tail_stream[0] = nullptr;   // (no staged launches: one tail launch behind the bulk kernel, on its stream)
             }
-            forked = b->tail_stream && hipEventRecord(b->tail_fork, b->stream) == hipSuccess &&
-                     hipStreamWaitEvent(b->tail_stream, b->tail_fork, 0) == hipSuccess;
+            forked = b->tail_stream[0] && hipEventRecord(b->tail_fork, b->stream) == hipSuccess;
+            for (int k = 0; k < kStages && forked; ++k) forked = hipStreamWaitEvent(b->tail_stream[k], b->tail_fork, 0) == hipSuccess;
         }
-        hipStream_t tail_on = forked ? b->tail_stream : b->stream;   // (no stream of its own: the tail kernel follows the bulk kernel)
         auto go = [&](auto geo) {
             hipLaunchKernelGGL((k_bounce_rollout_pieces<PMAX, BLOCK, TAIL, decltype(geo)>), dim3(groups),
                                dim3(BLOCK), tile, b->stream, geo, b->d_planes, b->d_status, b->d_plies,
@@ -2800,12 +2810,37 @@ static void launch_rollout(const bgs_batch* b, uint64_t seed, uint32_t cap, bool
                                (uint32_t)park_at, pool, b->book_links,
                                reinterpret_cast<const BookEntry*>(b->book_table), book_depth, b->book_n0, tail);
             if (TAIL) {
-                hipLaunchKernelGGL((k_bounce_tail<PMAX, decltype(geo)>), dim3(tail.limit), dim3(BGS_WAVE), 0, tail_on, geo, b->d_planes,
-                                   b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game, b->d_steps,
-                                   tail, (uint32_t)(groups * per_block), 4000000u);
-                if (forked && (hipEventRecord(b->tail_join, b->tail_stream) != hipSuccess ||
-                               hipStreamWaitEvent(b->stream, b->tail_join, 0) != hipSuccess))
-                    (void)hipStreamSynchronize(b->tail_stream);   // (the join could not be enqueued: wait for the tail here)
+                // (a stage's ticket counter: words 12 .. 15 of the rollout's counters, cleared with them; the sweep-up launch of a
+                // failed enqueue shares the last stage's)
+                auto tail_launch = [&](hipStream_t on, unsigned waves, uint32_t lo, uint32_t hi, int stage) {
+                    hipLaunchKernelGGL((k_bounce_tail<PMAX, decltype(geo)>), dim3(waves), dim3(BGS_WAVE), 0, on, geo, b->d_planes,
+                                       b->d_status, b->d_plies, reinterpret_cast<uint16_t*>(b->d_reward), b->n, seed, b->first_game,
+                                       b->d_steps, tail, lo, hi, b->d_work_count + 12 + stage);
+                };
+                if (!forked) {
+                    tail_launch(b->stream, 8192u, 0u, 0xFFFFFFFFu, kStages - 1);
+                } else {
+                    // stage k is released when the bulk kernel has handed over threshold[k] games (2 % of a batch outlive an
+                    // 80-ply bulk pass: ~5 000 of 2^18)
+                    const uint32_t expected = (uint32_t)(b->n / 50) + 1u;
+                    bool ok = hipEventRecord(b->tail_bulk_done, b->stream) == hipSuccess;
+                    uint32_t lo = 0;
+                    int k = 0;
+                    for (; k < kStages && ok; ++k) {
+                        // stage k owns [lo, hi): released at `hi` entries; the last stage owns the rest and follows the bulk kernel
+                        const uint32_t hi = k + 1 < kStages ? (k == 0 ? 32u : expected * (uint32_t)k / (uint32_t)(kStages - 1)) : 0xFFFFFFFFu;
+                        if (k + 1 < kStages) ok = hipStreamWaitValue32(b->tail_stream[k], tail.counters + 3, hi, hipStreamWaitValueGte, 0xFFFFFFFFu) == hipSuccess;
+                        else ok = hipStreamWaitEvent(b->tail_stream[k], b->tail_bulk_done, 0) == hipSuccess;
+                        if (!ok) break;
+                        tail_launch(b->tail_stream[k], k + 1 < kStages ? tail.limit : 8192u, lo, hi, k);
+                        ok = hipEventRecord(b->tail_join[k], b->tail_stream[k]) == hipSuccess && hipStreamWaitEvent(b->stream, b->tail_join[k], 0) == hipSuccess;
+                        lo = hi;
+                    }
+                    if (!ok) {   // (something could not be enqueued: wait for what was, then the rest on the batch's stream)
+                        for (int j = 0; j < kStages; ++j) (void)hipStreamSynchronize(b->tail_stream[j]);
+                        tail_launch(b->stream, 8192u, lo, 0xFFFFFFFFu, kStages - 1);
+                    }
+                }
             }
         };
         // (the default board: the compile-time geometry, see bounce_unit.h -- 256-thread workgroups only, the shape every plan uses)

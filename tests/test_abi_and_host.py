@@ -59,7 +59,7 @@ def test_product_library_is_lean():
     import subprocess
 
     product, test = (subprocess.check_output(["strings", path], text=True) for path in LIBS)
-    for word in ("inject", "bounce_plan", "BGS_EXPERIMENT", "rollout_opening", "bounce_tail", "gather_comm_alone", "drain_serial_sync"):
+    for word in ("inject", "bounce_plan", "BGS_EXPERIMENT", "rollout_opening", "bounce_tail_handoff", "gather_comm_alone", "drain_serial_sync"):
         assert word.lower() not in product.lower(), word
         assert word.lower() in test.lower(), word
     ids = []

@@ -1144,3 +1144,31 @@ def test_bounce_tail_kernel_beside_the_bulk_kernel(batch_mod, monkeypatch):
             assert_same(dev, orc, f"handoff {handoff}, {limit} tail waves")
             assert dev.steps == total
         dev.close()
+
+
+@pytest.mark.parametrize("hint,n", [(1, 1 << 17), (8, 1 << 16), (20, 1 << 16)])
+def test_bounce_compile_time_geometry_equals_the_run_time_record(batch_mod, monkeypatch, hint, n):
+    """Round 6: the default board runs on K3p / K3w instantiated on its compile-time geometry (bounce_unit.h: DefaultBounceGeom).
+    The same batch on the run-time record (experiment bounce_static_geom=0: what every other grid gets) and the oracle: the
+    same boards, in every launch shape, at caps around the bulk caps."""
+    for cap in (4096, 241, 129, 81, 80, 5):
+        out = []
+        for static in ("1", "0"):
+            monkeypatch.setitem(knobs, "bounce_static_geom", static)
+            dev = batch_mod.BounceBatch(DEFAULT_BOUNCE, n)
+            dev.set_launches_in_flight(hint)
+            dev.set_first_game(123456789)
+            dev.rollout(SEED + cap, max_plies=cap, from_initial=True)
+            out.append(dev)
+        np.testing.assert_array_equal(out[0].grid, out[1].grid)
+        np.testing.assert_array_equal(out[0].reward, out[1].reward)
+        np.testing.assert_array_equal(out[0].plies, out[1].plies)
+        assert out[0].steps == out[1].steps
+        m = 1 << 13
+        orc = oracle.BounceOracle(DEFAULT_BOUNCE, m)
+        orc.rollout(SEED + cap, first_game=123456789, max_plies=cap)
+        np.testing.assert_array_equal(out[0].grid[:m], orc.grid)
+        np.testing.assert_array_equal(out[0].reward[:m], orc.reward)
+        np.testing.assert_array_equal(out[0].plies[:m], orc.plies)
+        for dev in out:
+            dev.close()

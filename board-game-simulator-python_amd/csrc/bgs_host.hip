@@ -23,6 +23,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -288,6 +289,22 @@ inline double mono_us() {
 }
 }  // namespace
 
+// is there a code 0 ("still running") among games [first, first + count) of the 2-bit codes?  (first is a multiple of 4)
+static bool codes_hold_a_zero(const uint8_t* codes, int64_t first, int64_t count) {
+    const uint8_t* p = codes + first / 4;
+    const int64_t whole = count / 4;
+    int64_t i = 0;
+    uint64_t seen = 0;   // bit 2k set: the k-th code of some word was 0
+    for (; i + 8 <= whole; i += 8) {
+        uint64_t x;
+        memcpy(&x, p + i, 8);
+        seen |= ~(x | (x >> 1)) & 0x5555555555555555ull;
+    }
+    for (; i < whole; ++i) seen |= (uint64_t)(~(p[i] | (p[i] >> 1)) & 0x55u);
+    for (int64_t k = 0; k < count - whole * 4; ++k) seen |= ((p[whole] >> (2 * k)) & 3u) == 0u ? 1u : 0u;
+    return seen != 0;
+}
+
 struct bgs_reward_sink {
     int device = 0;
     int64_t max_games = 0;
@@ -306,6 +323,9 @@ struct bgs_reward_sink {
         int event_slot = 0;             // the slot whose `landed` event says this job's bytes have arrived: its own, or
                                         // the LAST slot of a group of jobs that were delivered behind one event (the
                                         // in-library gather: one record per group of steps, bgs_multi.hip)
+        bool all_end = false;           // every game of this job must have ENDED (an uncapped rollout from the start): a code 0
+                                        // ("still running") among them says that a rank's step failed -- its message was zeros
+                                        // (bgs_multi.hip) -- and the job is reported as failed (round-5 advisor)
     };
     std::vector<Job> jobs;            // [slots]
     std::mutex mu;
@@ -430,6 +450,10 @@ struct bgs_reward_sink {
                 int64_t count = b1 * 4 - first;
                 if (first + count > job.n_games) count = job.n_games - first;
                 if (count > 0) expand_range(pinned[slot], first, count, job.host_reward);
+                if (count > 0 && job.all_end && codes_hold_a_zero(pinned[slot], first, count)) {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (std::find(failed_tickets.begin(), failed_tickets.end(), ticket) == failed_tickets.end()) failed_tickets.push_back(ticket);
+                }
             }
             if (sink_trace_on()) fprintf(stderr, "sink-trace ticket %lld worker %d expand %.1f .. %.1f\n", (long long)ticket, t, trace_t0, mono_us());
             {
@@ -460,11 +484,13 @@ int64_t claim(bgs_reward_sink* s) {
 
 // `ok` false: the enqueue for this ticket failed; the job is published all the same (the ring must not stall) with
 // nothing to expand, and the sink remembers the failure
-void publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok = true, int64_t event_ticket = -1) {
+void publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok = true, int64_t event_ticket = -1,
+             bool all_end = false) {
     {
         std::unique_lock<std::mutex> lock(s->mu);
         s->cv_done.wait(lock, [&] { return s->submitted == ticket; });  // (tickets of other threads publish first)
         s->jobs[ticket % s->slots].n_games = ok ? n_games : 0;
+        s->jobs[ticket % s->slots].all_end = all_end;
         s->jobs[ticket % s->slots].host_reward = host_reward;
         s->jobs[ticket % s->slots].event_slot = (int)((event_ticket >= 0 ? event_ticket : ticket) % s->slots);
         if (!ok) s->failed_tickets.push_back(ticket);
@@ -483,8 +509,8 @@ int64_t sink_claim(bgs_reward_sink* s) { return claim(s); }
 uint8_t* sink_slot_device(bgs_reward_sink* s, int64_t ticket) { return s->mapped[ticket % s->slots]; }
 uint8_t* sink_slot_host(bgs_reward_sink* s, int64_t ticket) { return s->pinned[ticket % s->slots]; }
 hipEvent_t sink_slot_event(bgs_reward_sink* s, int64_t ticket) { return s->landed[ticket % s->slots]; }
-void sink_publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok, int64_t event_ticket) {
-    publish(s, ticket, n_games, host_reward, ok, event_ticket);
+void sink_publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok, int64_t event_ticket, bool all_end) {
+    publish(s, ticket, n_games, host_reward, ok, event_ticket, all_end);
 }
 // urgent: the caller is at the END of a run (bgs_pipeline_drain): worker 0 polls the arrival events from here on and
 // the caller spins a little before it sleeps -- the last deliveries are a few tens of microseconds away and overlap
@@ -523,7 +549,8 @@ int sink_wait(bgs_reward_sink* s, int64_t ticket, bool urgent) {
         }
     }
     if (bad >= 0)
-        return fail(BGS_ERR_RUNTIME, "reward hand-over %lld failed (its enqueue or its arrival event); later deliveries are unaffected",
+        return fail(BGS_ERR_RUNTIME, "reward hand-over %lld failed (its enqueue, its arrival event, or -- a gathered step whose games all "
+                    "had to end -- a rank delivered games that are still running: its step failed there); later deliveries are unaffected",
                     (long long)bad);
     return BGS_OK;
 }

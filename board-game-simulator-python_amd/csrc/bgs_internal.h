@@ -178,7 +178,9 @@ uint8_t* sink_slot_device(bgs_reward_sink* s, int64_t ticket);
 uint8_t* sink_slot_host(bgs_reward_sink* s, int64_t ticket);
 hipEvent_t sink_slot_event(bgs_reward_sink* s, int64_t ticket);
 // event_ticket >= 0: the job's bytes have arrived when THAT ticket's slot event fires (a group of jobs behind one record)
-void sink_publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok, int64_t event_ticket = -1);
+// all_end: every game of the job must have ended (an uncapped rollout from the start): a code 0 among them fails the job
+void sink_publish(bgs_reward_sink* s, int64_t ticket, int64_t n_games, int8_t* host_reward, bool ok, int64_t event_ticket = -1,
+                  bool all_end = false);
 int sink_wait(bgs_reward_sink* s, int64_t ticket, bool urgent);  // urgent: poll / spin (the end of a run)
 int gather_wait(bgs_gather* g, int64_t ticket, bool urgent);     // bgs_multi.hip
 

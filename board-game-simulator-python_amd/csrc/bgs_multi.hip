@@ -308,6 +308,9 @@ struct bgs_gather {
     std::vector<int8_t*> host;           // [slots] rank 0: destination of the step's rewards
     std::vector<hipStream_t> step_stream;  // [slots] the stream the step's rollout was enqueued on
     std::vector<char> step_ok;           // [slots] the rollout and its event were enqueued
+    std::vector<char> step_all_end;      // [slots] every game of the step must have ended (uncapped Connect rollout from the start):
+                                         //         rank 0's sink then takes a "still running" code for what it is -- a rank whose
+                                         //         step failed and whose message was zeros -- and fails the step
     std::vector<int64_t> cover_seq;      // [slots] sequence number of the group the slot's last step left in ...
     std::vector<int> cover_ev;           // [slots] ... and the slot whose `sent` event was recorded behind that group
     int64_t group_seq = 0;
@@ -409,7 +412,8 @@ struct bgs_gather {
             // ONE arrival event for the group -- the last job's -- and every job of the group points at it
             if (ok && (he = hipEventRecord(bgs::sink_slot_event(sink, st[k - 1]), stream)) != hipSuccess) ok = false;
             for (int i = 0; i < k; ++i)
-                bgs::sink_publish(sink, st[i], n * world, host[(t + i) % slots], ok && step_ok[(t + i) % slots], st[k - 1]);
+                bgs::sink_publish(sink, st[i], n * world, host[(t + i) % slots], ok && step_ok[(t + i) % slots], st[k - 1],
+                                  step_all_end[(t + i) % slots] != 0);
         }
         if (!ok) comm_broken = true;
         if ((!ok || !all_steps_ok) && !has_failed()) {
@@ -586,6 +590,7 @@ int bgs_gather_create(int device, int rank, int world, const uint8_t* id, int64_
     g->host.assign(slots, nullptr);
     g->step_stream.assign(slots, nullptr);
     g->step_ok.assign(slots, 0);
+    g->step_all_end.assign(slots, 0);
     g->cover_seq.assign(slots, 0);
     g->cover_ev.assign(slots, 0);
     int rc = BGS_OK;
@@ -742,6 +747,9 @@ int bgs_gather_rollout(bgs_gather* g, bgs_batch* b, uint64_t seed, int32_t max_p
         g->host[slot] = host_reward;
         g->step_stream[slot] = b->stream;
         g->step_ok[slot] = ok ? 1 : 0;
+        // (a Connect game cannot outlast height x width plies; Bounce games can run to any cap)
+        g->step_all_end[slot] = (flags & BGS_ROLLOUT_FROM_INITIAL) && b->game == BGS_GAME_CONNECT && !b->generic &&
+                                        (int64_t)max_plies >= (int64_t)b->cg.h * b->cg.w ? 1 : 0;
         g->submitted = t + 1;
         if (!ok) g->flush_upto = std::max(g->flush_upto, t + 1);   // (let the failed step's group leave at once)
         // the communication thread is woken for the FIRST step of a group (it starts the group's flush timer and goes

@@ -184,7 +184,8 @@ def run_inject_one(directory, rank, world):
     """Round-4 advisor: ONE rank fails locally (BGS_EXPERIMENT: gather_inject_rank names it, gather_inject_failure the step) while
     its peers have posted -- or will post -- the matching halves of the group.  The failing rank still posts its message
     (zeros), so nobody stalls: it reports the failure itself, rank 0 gets every step, with that rank's rows of the failed
-    step reading 0 / 0 ("still running") and everything else equal to the oracle."""
+    step reading 0 / 0 ("still running") and everything else equal to the oracle -- and, round 6, rank 0's wait for THAT step
+    fails: its sink knows that every game of the step had to end and finds games that did not."""
     from simulator.batch import ConnectBatch
     from simulator.game._abi import BgsError
     from simulator.sharding import RewardGather
@@ -215,8 +216,12 @@ def run_inject_one(directory, rank, world):
         except BgsError:
             outcomes.append("failed")
     assert time.monotonic() - t0 < 30, "a peer was left waiting"
-    if rank != bad_rank:
+    if rank != bad_rank and rank != 0:
         assert outcomes == ["ok"] * steps, outcomes   # the peers' groups completed: the failing rank posted its half
+    if rank == 0 and bad_rank != 0:
+        # ... and rank 0 is TOLD (round 6): every game of an uncapped rollout from the start must have ended, so the zeros the
+        # failing rank's message carried ("still running") fail that step's hand-over on rank 0 -- the steps around it are fine
+        assert outcomes == ["ok"] * bad_step + ["failed"] + ["ok"] * (steps - bad_step - 1), outcomes
     gather.close()   # must return on every rank (and drains rank 0's sink: what was delivered is in the arrays now)
     if rank == 0:
         for s in range(steps):

@@ -931,3 +931,17 @@ def test_policy_loop_replays_from_a_hip_graph(bm, torch_mod):
         orc.step_actions(col)
     np.testing.assert_array_equal(eager_grid, orc.grid)
     np.testing.assert_array_equal(eager_reward, orc.reward)
+
+
+def test_bench_under_the_strict_rng_contract():
+    """`bench.py --rng per-ply`: `value` under the strict contract (config.rng says so, the CPU baseline's parity check runs the
+    oracle under the same contract), the default contract's rate beside it (`rng_other`), both hand-overs checked against the
+    oracle."""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--batch", str(1 << 16),
+                           "--rng", "per-ply", "--no-other-configs"], env=product_env(), capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    d = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["rng"].startswith("per-ply") and d["cpu_baseline"]["parity_with_host_rewards"] is True
+    other = d["rng_other"]
+    assert other["rng"].startswith("per-block") and other["parity_with_oracle_first_4096"] is True and other["value"] > 0
+    assert d["value"] > 0 and d["rccl_ranks"] is None
